@@ -1,0 +1,136 @@
+/*
+ * paule_hip.h -- C-ABI of the MI355X (gfx950) planning engine: libpaule_hip.so
+ *
+ * The reference (quantling/paule) has NO native interface for this path: its planning
+ * inner loop is ~60 lines of Python/torch nested inside Paule.plan_resynth()
+ * (paule/paule.py:910-1211) and its only FFI is ctypes -> VocalTractLab
+ * (paule/util.py:30-35), which is not on the path.  This header therefore DEFINES the
+ * boundary a replacement has to provide; each entry point names the reference lines it
+ * replaces.  Error convention = the one the reference already uses for its one C
+ * library (nonzero int -> Python ValueError, paule/util.py:33-34, :235-236): every
+ * function returns 0 on success and a nonzero code otherwise, with a message from
+ * pl_last_error().  Nothing aborts; HIP errors are translated.
+ *
+ * All tensor arguments are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()),
+ * dense row-major, float32 unless stated.  The caller owns everything it passes; the
+ * library copies/repacks into its own layout, so the caller may free or mutate its
+ * tensors after a call returns (needed because continued learning mutates pred_model
+ * between outer iterations, paule/paule.py:1372-1377).  One handle <-> one device <->
+ * one stream; calls on one handle are not re-entrant; different handles may be driven
+ * from different threads / processes (one per GPU).  pl_step is stream-asynchronous;
+ * pl_get_* and pl_step with output pointers enqueue their copies on the same stream.
+ */
+#ifndef PAULE_HIP_H
+#define PAULE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PL_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+enum {
+    PL_OK = 0,
+    PL_ERR_INVALID = 1,   /* bad argument / configuration */
+    PL_ERR_HIP = 2,       /* HIP runtime error (message has hipGetErrorString) */
+    PL_ERR_STATE = 3,     /* call sequence error (e.g. pl_step before weights/targets/cp are set) */
+    PL_ERR_UNSUPPORTED = 4
+};
+
+/* arithmetic type of the LSTM / linear GEMMs and of the activation stash */
+enum { PL_F32 = 0, PL_BF16 = 1 };
+
+/* objective (paule/paule.py:600, :663, :719, :775-776) */
+enum { PL_OBJ_ACOUSTIC = 0, PL_OBJ_ACOUSTIC_SEMVEC = 1, PL_OBJ_SEMVEC = 2 };
+
+/* model ids for pl_set_lstm_weights / pl_set_linear */
+enum { PL_MODEL_PRED = 0 /* ForwardModel, paule/models.py:326 */,
+       PL_MODEL_EMBED = 1 /* EmbeddingModel, paule/models.py:413 */ };
+
+/* columns of one loss_log row (weighted sub-losses as logged at paule/paule.py:942-945, :988-992) */
+enum { PL_LOSS_TOTAL = 0, PL_LOSS_MEL = 1, PL_LOSS_SEMVEC = 2, PL_LOSS_VEL = 3, PL_LOSS_JERK = 4,
+       PL_LOSS_LOCAL_LINEAR = 5, PL_LOSS_COLS = 6 };
+
+typedef struct pl_handle pl_handle;
+
+typedef struct pl_config {
+    int32_t struct_size;      /* = sizeof(pl_config); guards against ABI drift */
+    int32_t batch;            /* B independent utterances; reference: 1 (paule/paule.py:585-588) */
+    int32_t n_frames;         /* T  CP frames  (xx_new.shape[1]) */
+    int32_t cp_dim;           /* 30 (paule/util.py:50-52) */
+    int32_t mel_dim;          /* 60 */
+    int32_t sem_dim;          /* 300 */
+    int32_t pred_layers;      /* ForwardModel num_lstm_layers (paule/models.py:338) */
+    int32_t pred_hidden;      /* ForwardModel hidden_size */
+    int32_t emb_layers;       /* EmbeddingModel num_lstm_layers; 0 = no embedder (acoustic objective only) */
+    int32_t emb_hidden;
+    int32_t dtype;            /* PL_F32 | PL_BF16 */
+    int32_t objective;        /* PL_OBJ_* */
+    float w_mel, w_sem, w_vel, w_jerk, w_ll; /* 5, 10, 80, 400, 1e5 (paule/paule.py:592-597) */
+    float lr;                 /* learning_rate_planning, 0.01 (paule/paule.py:391) */
+    float beta1, beta2, eps;  /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 (paule/paule.py:797) */
+    float clamp_lo, clamp_hi; /* -1.05, 1.05 (paule/paule.py:1202) */
+    int32_t smiling;          /* paule/paule.py:1203-1208: ch 4 := -1, ch 1 := +1 after every step */
+    int32_t device;           /* HIP device ordinal */
+    int32_t use_graph;        /* 1: capture one inner iteration into a hipGraph and replay it; 0: eager launches */
+    void *stream;             /* hipStream_t the work is enqueued on (NULL = default stream) */
+} pl_config;
+
+/* Fills *cfg with the reference's defaults (weights, lr, betas, clamp, dims 30/60/300). */
+int pl_default_config(pl_config *cfg);
+
+/* Allocates every device buffer of the planner (weights, stash, Adam state, scratch). */
+int pl_create(const pl_config *cfg, pl_handle **out);
+int pl_destroy(pl_handle *h);
+
+/* torch.nn.LSTM layer `layer` of model `model_id`, torch layout: w_ih [4H, in], w_hh [4H, H],
+ * b_ih [4H], b_hh [4H], gate order i,f,g,o (paule/models.py:344, :431).  Copied + repacked. */
+int pl_set_lstm_weights(pl_handle *h, int model_id, int layer, const float *w_ih, const float *w_hh,
+                        const float *b_ih, const float *b_hh);
+/* post_linear [mel_dim, H] (paule/models.py:345) for PL_MODEL_PRED;
+ * linear_mapping [sem_dim, H] (paule/models.py:437) for PL_MODEL_EMBED. */
+int pl_set_linear(pl_handle *h, int model_id, const float *w, const float *b);
+
+/* target_mel [B, T/2, mel_dim]; target_semvec [B, sem_dim] or NULL (paule/paule.py:531-540). */
+int pl_set_targets(pl_handle *h, const float *target_mel, const float *target_semvec);
+/* cp [B, T, cp_dim]: xx_new (paule/paule.py:585-590).  Does not touch the optimiser state. */
+int pl_set_cp(pl_handle *h, const float *cp);
+/* past_cp [P, cp_dim] (per_utterance = 0, shared by all utterances) or [B, P, cp_dim]; P = 0 / NULL clears it
+ * (paule/paule.py:575-583, :1210-1211). */
+int pl_set_past_cp(pl_handle *h, const float *past_cp, int past_len, int per_utterance);
+/* Adam m = v = 0, step count = 0 (a fresh torch.optim.Adam, paule/paule.py:797). */
+int pl_reset_optimizer(pl_handle *h);
+
+/* n_iters inner iterations (paule/paule.py:910-1211 without the log-step block):
+ * forward, criterion, backward-data, Adam, clamp/smiling/past_cp.
+ * loss_log  [n_iters, B, PL_LOSS_COLS] or NULL -- losses at the PRE-step CP of each iteration
+ * grad_out  [B, T, cp_dim] or NULL            -- xx_new.grad of the LAST iteration (paule/paule.py:1056-1063) */
+int pl_step(pl_handle *h, int n_iters, float *loss_log, float *grad_out);
+
+int pl_get_cp(pl_handle *h, float *cp_out);
+/* Forward only at the current CP (paule/paule.py:822-824, :1460-1464): pred_mel [B, T/2, mel_dim],
+ * pred_semvec [B, sem_dim] (may be NULL; requires an embedder). */
+int pl_get_pred(pl_handle *h, float *pred_mel_out, float *pred_semvec_out);
+/* EmbeddingModel.forward on an arbitrary mel [B, T/2, mel_dim] (paule/paule.py:533-535, :1131):
+ * lens [B] int32 device pointer or NULL (= T/2 for every utterance, paule/paule.py:922-924). */
+int pl_embed_mel(pl_handle *h, const float *mel, const int32_t *lens, float *semvec_out);
+
+/* Test / debugging aid: copies a named internal buffer, converted to float32, into out (device pointer).
+ * Returns the element count through *n_out; out may be NULL to query the size only. */
+int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems, int64_t *n_out);
+
+/* Bytes of device memory held by the handle. */
+int64_t pl_device_bytes(const pl_handle *h);
+/* Algorithmic FLOPs (forward + backward-data GEMMs, 2 flops / MAC) of one inner iteration at this handle's shapes. */
+double pl_flops_per_iteration(const pl_handle *h);
+
+const char *pl_last_error(void); /* thread-local */
+int pl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAULE_HIP_H */

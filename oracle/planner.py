@@ -1,0 +1,240 @@
+"""Torch restatement of the PAULE planning inner loop (CPU oracle; test infrastructure).
+
+Follows the reference line by line in *behaviour* (not in text):
+
+* models       : paule/models.py:335-356 (ForwardModel), :421-448 (EmbeddingModel)
+* loss helpers : paule/util.py:564-572 (RMSELoss, eps=0 instance paule/paule.py:68),
+                 :577-600 (five-point stencil, no padding), :608-614 (local_linear),
+                 :617-637 (vel/acc/jerk = stencil applied 1x/2x/3x)
+* criterion    : paule/paule.py:592-597 (weights), :647-662 / :705-717 / :760-773
+* loop         : paule/paule.py:797 (Adam), :911-913, :921-925, :1052, :1199-1211
+
+Batch rule: the reference plans exactly one utterance
+(paule/paule.py:585-588).  For B > 1 every loss is reduced per utterance and the
+objective is the sum over utterances, so row b of a batched run equals a B = 1
+reference run on target b.
+"""
+from __future__ import annotations
+
+import torch
+
+# paule/paule.py:592-597
+MEL_WEIGHT = 5.0
+VELOCITY_WEIGHT = 80.0
+JERK_WEIGHT = 400.0
+SEMANTIC_WEIGHT = 10.0
+LOCAL_LINEAR_WEIGHT = 100_000.0
+
+OBJECTIVES = ("acoustic", "acoustic_semvec", "semvec")
+# loss_log columns (weighted sub-losses, as logged at paule/paule.py:942-945, :988-992)
+LOSS_COLUMNS = ("total", "mel", "semvec", "velocity", "jerk", "local_linear")
+
+
+# --------------------------------------------------------------------------------------
+# models (same ctor defaults and state-dict keys as paule/models.py:335-346, :421-437)
+# --------------------------------------------------------------------------------------
+class OracleForwardModel(torch.nn.Module):
+    def __init__(self, input_size=30, output_size=60, hidden_size=180, num_lstm_layers=4,
+                 apply_half_sequence=True):
+        super().__init__()
+        self.apply_half_sequence = apply_half_sequence
+        self.lstm = torch.nn.LSTM(input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
+        self.post_linear = torch.nn.Linear(hidden_size, output_size)
+
+    def forward(self, x, *args):
+        out, _ = self.lstm(x)
+        out = self.post_linear(out)
+        if self.apply_half_sequence:
+            # AvgPool1d(2, stride=2) over time; an odd last frame is dropped.
+            out = torch.nn.functional.avg_pool1d(out.permute(0, 2, 1), 2, stride=2).permute(0, 2, 1)
+        return out
+
+
+class OracleEmbeddingModel(torch.nn.Module):
+    """post_upsampling_size == 0 path only (what Paule instantiates, paule/paule.py:167)."""
+
+    def __init__(self, input_size=60, output_size=300, hidden_size=720, num_lstm_layers=1):
+        super().__init__()
+        self.lstm = torch.nn.LSTM(input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
+        self.linear_mapping = torch.nn.Linear(hidden_size, output_size)
+
+    def forward(self, x, lens, *args):
+        out, _ = self.lstm(x)
+        out = torch.stack([out[i, (last - 1).long(), :] for i, last in enumerate(lens)])
+        return self.linear_mapping(out)
+
+
+def _lstm_dims(sd):
+    n_layers = len([k for k in sd if k.startswith("lstm.weight_hh_l")])
+    hidden = sd["lstm.weight_hh_l0"].shape[1]
+    in_size = sd["lstm.weight_ih_l0"].shape[1]
+    return in_size, hidden, n_layers
+
+
+def forward_model_from_state_dict(sd, dtype=torch.float64):
+    in_size, hidden, n_layers = _lstm_dims(sd)
+    m = OracleForwardModel(in_size, sd["post_linear.weight"].shape[0], hidden, n_layers)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return m.to(dtype)
+
+
+def embedding_model_from_state_dict(sd, dtype=torch.float64):
+    in_size, hidden, n_layers = _lstm_dims(sd)
+    m = OracleEmbeddingModel(in_size, sd["linear_mapping.weight"].shape[0], hidden, n_layers)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return m.to(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# trajectory arithmetic
+# --------------------------------------------------------------------------------------
+def five_point_stencil(xx, delta_t=1.0):
+    """paule/util.py:577-600: d[t] = (-x[t+4] + 8 x[t+3] - 8 x[t+1] + x[t]) / (12 dt), length T-4."""
+    return (-xx[:, 4:, :] + 8.0 * xx[:, 3:-1, :] - 8.0 * xx[:, 1:-3, :] + xx[:, :-4, :]) / (12.0 * delta_t)
+
+
+def vel_acc_jerk(xx, delta_t=1.0):
+    """paule/util.py:617-637."""
+    vel = five_point_stencil(xx, delta_t)
+    acc = five_point_stencil(vel, delta_t)
+    jerk = five_point_stencil(acc, delta_t)
+    return vel, acc, jerk
+
+
+def local_linear(xx, delta_t=1.0):
+    """paule/util.py:608-614."""
+    return (2 * xx[:, 1:-1, :] - xx[:, :-2, :] - xx[:, 2:, :]) / (2 * delta_t)
+
+
+def _mse_per_utt(x):
+    return (x * x).flatten(1).mean(dim=1)
+
+
+def _rmse_per_utt(yhat, y):
+    """RMSELoss(eps=0) (paule/util.py:564-572, paule/paule.py:68), reduced per utterance."""
+    d = yhat - y
+    return torch.sqrt((d * d).flatten(1).mean(dim=1))
+
+
+def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_semvec=None):
+    """Weighted per-utterance losses -> (loss_b (B,), sub (B, 6)) (paule/paule.py:647-662, :705-717, :760-773).
+
+    In the 'semvec' objective the mel loss is evaluated for logging only
+    (paule/paule.py:1021) and does not enter the objective.
+    """
+    vel, _, jerk = vel_acc_jerk(cps)                       # paule/paule.py:75-88 with loss=mse_loss
+    vel_l = VELOCITY_WEIGHT * _mse_per_utt(vel)
+    jerk_l = JERK_WEIGHT * _mse_per_utt(jerk)
+    ll_l = LOCAL_LINEAR_WEIGHT * _mse_per_utt(local_linear(cps))
+    mel_l = MEL_WEIGHT * _rmse_per_utt(pred_mel, target_mel)
+    if objective in ("acoustic_semvec", "semvec"):
+        sem_l = SEMANTIC_WEIGHT * _rmse_per_utt(pred_semvec, target_semvec)
+    else:
+        sem_l = torch.zeros_like(mel_l)
+    if objective == "acoustic":
+        loss = mel_l + vel_l + jerk_l + ll_l
+    elif objective == "acoustic_semvec":
+        loss = mel_l + vel_l + jerk_l + sem_l + ll_l
+    elif objective == "semvec":
+        loss = vel_l + jerk_l + sem_l + ll_l
+    else:
+        raise ValueError("objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'")
+    sub = torch.stack([loss, mel_l, sem_l, vel_l, jerk_l, ll_l], dim=1)
+    return loss, sub
+
+
+# --------------------------------------------------------------------------------------
+# the loop
+# --------------------------------------------------------------------------------------
+class OraclePlanner:
+    """Batched planning inner loop on the CPU (torch autograd + torch.optim.Adam).
+
+    Same engine interface as the HIP engine (``paule_amd.engine.HipPlanner``):
+    ``set_targets / set_cp / set_past_cp / reset_optimizer / step / get_cp / get_pred``.
+    """
+
+    def __init__(self, pred_model, embedder=None, *, objective="acoustic", lr=0.01,
+                 betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False,
+                 dtype=torch.float64):
+        if objective not in OBJECTIVES:
+            raise ValueError("objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'")
+        self.objective = objective
+        self.dtype = dtype
+        self.pred_model = pred_model.to(dtype)
+        self.embedder = embedder.to(dtype) if embedder is not None else None
+        for m in (self.pred_model, self.embedder):
+            if m is not None:
+                for p in m.parameters():
+                    p.requires_grad_(False)   # planning needs dL/dCP only
+        self.lr, self.betas, self.eps, self.clamp, self.smiling = lr, betas, eps, clamp, smiling
+        self.xx = None
+        self.past_cp = None
+        self.optimizer = None
+        self.target_mel = None
+        self.target_semvec = None
+        self.last_grad = None
+
+    # -- state ------------------------------------------------------------------------
+    def set_targets(self, target_mel, target_semvec=None):
+        self.target_mel = torch.as_tensor(target_mel).to(self.dtype).clone()
+        self.target_semvec = None if target_semvec is None else torch.as_tensor(target_semvec).to(self.dtype).clone()
+
+    def set_cp(self, cp):
+        cp = torch.as_tensor(cp).to(self.dtype).clone()
+        if self.xx is None:
+            self.xx = cp.requires_grad_()
+            self.reset_optimizer()
+        else:                      # keeps Adam state, like assigning xx_new.data
+            with torch.no_grad():
+                self.xx.data = cp
+
+    def set_past_cp(self, past_cp):
+        self.past_cp = None if past_cp is None else torch.as_tensor(past_cp).to(self.dtype).clone()
+
+    def reset_optimizer(self):
+        # paule/paule.py:797 -- one optimiser per plan_resynth call, state persists across outer iterations
+        self.optimizer = torch.optim.Adam([self.xx], lr=self.lr, betas=self.betas, eps=self.eps)
+
+    # -- forward ----------------------------------------------------------------------
+    def _predict(self, xx):
+        pred_mel = self.pred_model(xx)
+        pred_semvec = None
+        if self.embedder is not None and (self.objective != "acoustic"):
+            lens = [torch.tensor(pred_mel.shape[1])] * pred_mel.shape[0]
+            pred_semvec = self.embedder(pred_mel, lens)
+        return pred_mel, pred_semvec
+
+    def get_pred(self):
+        """Forward only at the current CP (paule/paule.py:1460-1464); semvec whenever an embedder exists."""
+        with torch.no_grad():
+            pred_mel = self.pred_model(self.xx)
+            pred_semvec = None
+            if self.embedder is not None:
+                lens = [torch.tensor(pred_mel.shape[1])] * pred_mel.shape[0]
+                pred_semvec = self.embedder(pred_mel, lens)
+        return pred_mel, pred_semvec
+
+    def get_cp(self):
+        return self.xx.detach().clone()
+
+    # -- iterations ---------------------------------------------------------------------
+    def step(self, n_iters=1):
+        """Runs n inner iterations; returns loss_log (n_iters, B, 6) evaluated at the PRE-step CP."""
+        log = []
+        for _ in range(n_iters):
+            self.optimizer.zero_grad()                                   # paule.py:911
+            pred_mel, pred_semvec = self._predict(self.xx)               # :913, :921-925
+            loss_b, sub = criterion(self.objective, self.xx, pred_mel, self.target_mel,
+                                    pred_semvec, self.target_semvec)     # :939 / :986 / :1020
+            loss_b.sum().backward()                                      # :1052
+            self.last_grad = self.xx.grad.detach().clone()
+            log.append(sub.detach().clone())
+            self.optimizer.step()                                        # :1199
+            with torch.no_grad():                                        # :1201-1211
+                self.xx.data = self.xx.data.clamp(self.clamp[0], self.clamp[1])
+                if self.smiling:
+                    self.xx.data[:, :, 4] = -1.0   # "LP"
+                    self.xx.data[:, :, 1] = 1.0    # "HY"
+                if self.past_cp is not None:
+                    self.xx.data[:, 0:self.past_cp.shape[-2], :] = self.past_cp
+        return torch.stack(log)

@@ -1,0 +1,100 @@
+"""ctypes binding of libpaule_hip.so (C-ABI declared in include/paule_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded the
+import of the engine fails loudly (``HipLibraryError``).  The error convention mirrors the
+reference's one C library: a nonzero return code becomes a ``ValueError``
+(paule/util.py:33-34, :235-236, :246-247).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpaule_hip.so")
+
+PL_F32, PL_BF16 = 0, 1
+PL_OBJ = {"acoustic": 0, "acoustic_semvec": 1, "semvec": 2}
+PL_MODEL_PRED, PL_MODEL_EMBED = 0, 1
+PL_LOSS_COLS = 6
+
+# every symbol include/paule_hip.h declares
+EXPORTED_SYMBOLS = (
+    "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
+    "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
+    "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_device_bytes", "pl_flops_per_iteration",
+    "pl_last_error", "pl_version",
+)
+
+
+class HipLibraryError(RuntimeError):
+    """libpaule_hip.so is missing / unloadable: the product has no other execution path."""
+
+
+class PlConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("batch", C.c_int32), ("n_frames", C.c_int32), ("cp_dim", C.c_int32),
+        ("mel_dim", C.c_int32), ("sem_dim", C.c_int32), ("pred_layers", C.c_int32), ("pred_hidden", C.c_int32),
+        ("emb_layers", C.c_int32), ("emb_hidden", C.c_int32), ("dtype", C.c_int32), ("objective", C.c_int32),
+        ("w_mel", C.c_float), ("w_sem", C.c_float), ("w_vel", C.c_float), ("w_jerk", C.c_float), ("w_ll", C.c_float),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("smiling", C.c_int32), ("device", C.c_int32),
+        ("use_graph", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Loads libpaule_hip.so once and declares the prototypes.  Raises HipLibraryError if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("PAULE_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise HipLibraryError(
+            f"{p} not found: build it with `make -C paule_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
+            "g.build()'`).  paule_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise HipLibraryError(f"cannot load {p}: {e}") from e
+
+    vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as raw addresses
+    lib.pl_last_error.restype = C.c_char_p
+    lib.pl_last_error.argtypes = []
+    lib.pl_version.restype = C.c_int
+    lib.pl_version.argtypes = []
+    lib.pl_default_config.argtypes = [C.POINTER(PlConfig)]
+    lib.pl_create.argtypes = [C.POINTER(PlConfig), C.POINTER(vp)]
+    lib.pl_destroy.argtypes = [vp]
+    lib.pl_set_lstm_weights.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
+    lib.pl_set_linear.argtypes = [vp, C.c_int, fp, fp]
+    lib.pl_set_targets.argtypes = [vp, fp, fp]
+    lib.pl_set_cp.argtypes = [vp, fp]
+    lib.pl_set_past_cp.argtypes = [vp, fp, C.c_int, C.c_int]
+    lib.pl_reset_optimizer.argtypes = [vp]
+    lib.pl_step.argtypes = [vp, C.c_int, fp, fp]
+    lib.pl_get_cp.argtypes = [vp, fp]
+    lib.pl_get_pred.argtypes = [vp, fp, fp]
+    lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
+    lib.pl_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_int64, C.POINTER(C.c_int64)]
+    lib.pl_device_bytes.restype = C.c_int64
+    lib.pl_device_bytes.argtypes = [vp]
+    lib.pl_flops_per_iteration.restype = C.c_double
+    lib.pl_flops_per_iteration.argtypes = [vp]
+    for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
+                 "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
+                 "pl_get_pred", "pl_embed_mel", "pl_debug_read"):
+        getattr(lib, name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, rc: int, what: str = ""):
+    """nonzero return code -> ValueError with the library's message (paule/util.py:33-34 convention)."""
+    if rc != 0:
+        msg = lib.pl_last_error()
+        raise ValueError(f"{what}: {msg.decode() if msg else 'error'} (code {rc})")

@@ -1,0 +1,437 @@
+// HBM-bound kernels of the planner: layout packing, pooling, the criterion (per-utterance
+// reductions, paule/paule.py:647-662 / :705-717 / :760-773), its gradients, and the Adam update with
+// the post-step projection (paule/paule.py:797, :1199-1211).
+//
+// The CP master copy, the Adam moments and all trajectory (smoothness) arithmetic are kept in f64:
+// they are a few MB, cost nothing next to the LSTM products, and remove the f32 cancellation in
+// the 1e5-weighted local-linear term (the reference is float64 end to end, paule/paule.py:124).
+#include "kernels.h"
+#include "pl_types.h"
+
+namespace pl {
+
+// correlation taps: d[t] = sum_k taps[k] * x[t + k]
+//   velocity     : five-point stencil, paule/util.py:600 (delta_t = 1, paule/paule.py:78)
+//   jerk         : the same stencil applied three times (paule/util.py:633-636) = one 13-tap correlation
+//   local linear : paule/util.py:614
+__constant__ double kVelTaps[5] = {1.0 / 12, -8.0 / 12, 0.0, 8.0 / 12, -1.0 / 12};
+__constant__ double kJerkTaps[13] = {1.0 / 1728,    -24.0 / 1728, 192.0 / 1728,  -488.0 / 1728, -387.0 / 1728,
+                                     1584.0 / 1728, 0.0,          -1584.0 / 1728, 387.0 / 1728,  488.0 / 1728,
+                                     -192.0 / 1728, 24.0 / 1728,  -1.0 / 1728};
+__constant__ double kLlTaps[3] = {-0.5, 1.0, -0.5};
+
+static inline int blocks_for(int64_t n, int bs = 256) { return (int)((n + bs - 1) / bs); }
+
+// ---------------------------------------------------------------------------------------------
+// packing
+// ---------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, int nblk, int R, int C, AT* __restrict__ dst, int Rp,
+                                   int Cp, int transpose) {
+    const int64_t n = (int64_t)nblk * Rp * Cp;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int rowp, col;
+    if (transpose) {
+        col = (int)(idx / ((int64_t)nblk * Rp));
+        rowp = (int)(idx % ((int64_t)nblk * Rp));
+    } else {
+        rowp = (int)(idx / Cp);
+        col = (int)(idx % Cp);
+    }
+    const int blk = rowp / Rp, r = rowp % Rp;
+    const float v = (r < R && col < C) ? src[((size_t)blk * R + r) * C + col] : 0.f;
+    dst[idx] = from_f32<AT>(v);
+}
+
+void launch_pack_matrix(hipStream_t stream, int dt, const float* src, int nblk, int R, int C, void* dst, int Rp, int Cp,
+                        bool transpose) {
+    const int64_t n = (int64_t)nblk * Rp * Cp;
+    if (dt == BF16)
+        hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, src, nblk, R, C,
+                           static_cast<bf16_t*>(dst), Rp, Cp, transpose ? 1 : 0);
+    else
+        hipLaunchKernelGGL(pack_matrix_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, src, nblk, R, C,
+                           static_cast<float*>(dst), Rp, Cp, transpose ? 1 : 0);
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ b0, const float* __restrict__ b1, int nblk, int R,
+                                 float* __restrict__ dst, int Rp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nblk * Rp) return;
+    const int blk = idx / Rp, r = idx % Rp;
+    float v = 0.f;
+    if (r < R) v = b0[blk * R + r] + (b1 ? b1[blk * R + r] : 0.f);
+    dst[idx] = v;
+}
+
+void launch_pack_bias(hipStream_t stream, const float* b0, const float* b1, int nblk, int R, float* dst, int Rp) {
+    hipLaunchKernelGGL(pack_bias_kernel, dim3(blocks_for(nblk * Rp)), dim3(256), 0, stream, b0, b1, nblk, R, dst, Rp);
+}
+
+// batch-major source [B][T][C] (f64 CP master or f32 mel) -> time-major activation [T][Bp][Cp]
+template <typename ST, typename AT>
+__global__ void pack_tm_kernel(const ST* __restrict__ src, int B, int T, int C, AT* __restrict__ dst, int Bp, int Cp) {
+    const int64_t n = (int64_t)T * Bp * Cp;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % Cp);
+    const int b = (int)((idx / Cp) % Bp);
+    const int t = (int)(idx / ((int64_t)Cp * Bp));
+    float v = 0.f;
+    if (b < B && c < C) v = (float)src[((size_t)b * T + t) * C + c];
+    dst[idx] = from_f32<AT>(v);
+}
+
+void launch_pack_cp(hipStream_t stream, int dt, const double* x, int B, int T, int C, void* dst, int Bp, int Cp) {
+    const int64_t n = (int64_t)T * Bp * Cp;
+    if (dt == BF16)
+        hipLaunchKernelGGL((pack_tm_kernel<double, bf16_t>), dim3(blocks_for(n)), dim3(256), 0, stream, x, B, T, C,
+                           static_cast<bf16_t*>(dst), Bp, Cp);
+    else
+        hipLaunchKernelGGL((pack_tm_kernel<double, float>), dim3(blocks_for(n)), dim3(256), 0, stream, x, B, T, C,
+                           static_cast<float*>(dst), Bp, Cp);
+}
+
+void launch_pack_mel(hipStream_t stream, int dt, const float* mel, int B, int Tp, int C, void* dst, int Bp, int Cp) {
+    const int64_t n = (int64_t)Tp * Bp * Cp;
+    if (dt == BF16)
+        hipLaunchKernelGGL((pack_tm_kernel<float, bf16_t>), dim3(blocks_for(n)), dim3(256), 0, stream, mel, B, Tp, C,
+                           static_cast<bf16_t*>(dst), Bp, Cp);
+    else
+        hipLaunchKernelGGL((pack_tm_kernel<float, float>), dim3(blocks_for(n)), dim3(256), 0, stream, mel, B, Tp, C,
+                           static_cast<float*>(dst), Bp, Cp);
+}
+
+// AvgPool1d(2, stride 2) over time (paule/models.py:351-354); an odd last frame is dropped.
+template <typename AT>
+__global__ void pool_mel_kernel(const float* __restrict__ Y, int B, int Tp, int C, int Bp, int Cp,
+                                float* __restrict__ mel_bm, AT* __restrict__ mel_tm) {
+    const int64_t n = (int64_t)Tp * Bp * Cp;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % Cp);
+    const int b = (int)((idx / Cp) % Bp);
+    const int tp = (int)(idx / ((int64_t)Cp * Bp));
+    float v = 0.f;
+    if (b < B && c < C) {
+        const size_t slab = (size_t)Bp * Cp;
+        v = 0.5f * (Y[(size_t)(2 * tp) * slab + (size_t)b * Cp + c] + Y[(size_t)(2 * tp + 1) * slab + (size_t)b * Cp + c]);
+        mel_bm[((size_t)b * Tp + tp) * C + c] = v;
+    }
+    mel_tm[idx] = from_f32<AT>(v);
+}
+
+void launch_pool_mel(hipStream_t stream, int dt, const float* Y, int B, int T, int C, int Bp, int Cp, float* mel_bm,
+                     void* mel_tm) {
+    const int Tp = T / 2;
+    const int64_t n = (int64_t)Tp * Bp * Cp;
+    if (dt == BF16)
+        hipLaunchKernelGGL(pool_mel_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, Y, B, Tp, C, Bp, Cp, mel_bm,
+                           static_cast<bf16_t*>(mel_tm));
+    else
+        hipLaunchKernelGGL(pool_mel_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, Y, B, Tp, C, Bp, Cp, mel_bm,
+                           static_cast<float*>(mel_tm));
+}
+
+// output[i, lens[i]-1, :] gather of EmbeddingModel.forward (paule/models.py:442)
+template <typename AT>
+__global__ void gather_last_kernel(const AT* __restrict__ h_tm, const int32_t* __restrict__ lens, int B, int Tl, int Bp,
+                                   int Hp, AT* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Bp * Hp) return;
+    const int b = idx / Hp, k = idx % Hp;
+    AT v = from_f32<AT>(0.f);
+    if (b < B) {
+        int t = (lens ? lens[b] : Tl) - 1;
+        t = t < 0 ? 0 : (t >= Tl ? Tl - 1 : t);
+        v = h_tm[((size_t)t * Bp + b) * Hp + k];
+    }
+    dst[idx] = v;
+}
+
+void launch_gather_last(hipStream_t stream, int dt, const void* h_tm, const int32_t* lens, int B, int Tl, int Bp, int Hp,
+                        void* dst) {
+    if (dt == BF16)
+        hipLaunchKernelGGL(gather_last_kernel<bf16_t>, dim3(blocks_for(Bp * Hp)), dim3(256), 0, stream,
+                           static_cast<const bf16_t*>(h_tm), lens, B, Tl, Bp, Hp, static_cast<bf16_t*>(dst));
+    else
+        hipLaunchKernelGGL(gather_last_kernel<float>, dim3(blocks_for(Bp * Hp)), dim3(256), 0, stream,
+                           static_cast<const float*>(h_tm), lens, B, Tl, Bp, Hp, static_cast<float*>(dst));
+}
+
+// ---------------------------------------------------------------------------------------------
+// criterion: per-utterance reductions (one workgroup per utterance, fixed order -> deterministic)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+template <int K>
+__device__ __forceinline__ double corr_sumsq(const double* __restrict__ x, int T, int C, const double* taps, int tid,
+                                             int nthreads) {
+    const int n = T - K + 1;
+    double s = 0.0;
+    for (int e = tid; e < n * C; e += nthreads) {
+        const int t = e / C, c = e % C;
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) d += taps[k] * x[(size_t)(t + k) * C + c];
+        s += d * d;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    double* sc = a.scal + (size_t)b * 8;
+
+    // RMSE over the utterance's T' x M mel frames (RMSELoss eps = 0, paule/util.py:570-572)
+    double s = 0.0;
+    const int nm = a.Tp * a.M;
+    const float* mel = a.mel + (size_t)b * nm;
+    const float* tgt = a.target_mel + (size_t)b * nm;
+    for (int e = tid; e < nm; e += nt) {
+        const double d = (double)mel[e] - (double)tgt[e];
+        s += d * d;
+    }
+    s = block_sum(s, sh);
+    if (tid == 0) sc[0] = sqrt(s / nm);
+
+    if (a.sem) {
+        s = 0.0;
+        for (int e = tid; e < a.S; e += nt) {
+            const double d = (double)a.sem[(size_t)b * a.Sp + e] - (double)a.target_sem[(size_t)b * a.S + e];
+            s += d * d;
+        }
+        s = block_sum(s, sh);
+        if (tid == 0) sc[1] = sqrt(s / a.S);
+    } else if (tid == 0) {
+        sc[1] = 0.0;
+    }
+
+    const double* x = a.x + (size_t)b * a.T * a.C;
+    s = block_sum(corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt), sh);
+    if (tid == 0) sc[2] = s / ((double)(a.T - 4) * a.C);
+    s = block_sum(corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt), sh);
+    if (tid == 0) sc[3] = s / ((double)(a.T - 12) * a.C);
+    s = block_sum(corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt), sh);
+    if (tid == 0) sc[4] = s / ((double)(a.T - 2) * a.C);
+}
+
+void launch_loss_reduce(hipStream_t stream, const LossArgs& a) {
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(a.B), dim3(256), 0, stream, a);
+}
+
+// weighted sub-losses, as the reference logs them (paule/paule.py:654-662, :942-945)
+__global__ void loss_finalize_kernel(LossArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const double* sc = a.scal + (size_t)b * 8;
+    const double mel = a.w_mel * sc[0], sem = a.sem ? a.w_sem * sc[1] : 0.0;
+    const double vel = a.w_vel * sc[2], jerk = a.w_jerk * sc[3], ll = a.w_ll * sc[4];
+    double total = vel + jerk + ll;
+    if (a.use_mel) total += mel;
+    if (a.use_sem) total += sem;
+    float* row = a.loss_rows + ((size_t)(*a.iter_slot) * a.B + b) * 6;
+    row[0] = (float)total;
+    row[1] = (float)mel;
+    row[2] = (float)sem;
+    row[3] = (float)vel;
+    row[4] = (float)jerk;
+    row[5] = (float)ll;
+}
+
+void launch_loss_finalize(hipStream_t stream, const LossArgs& a) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(blocks_for(a.B, 64)), dim3(64), 0, stream, a);
+}
+
+// d(w_sem * rmse_sem)/d sem = w_sem (sem - tgt) / (S * rmse).  rmse == 0 (exact match) would be 0/0 in the
+// reference (RMSELoss eps = 0); the gradient is defined as 0 there instead of NaN.
+template <typename AT>
+__global__ void dsem_kernel(LossArgs a, AT* __restrict__ dsem) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.Bp * a.Sp) return;
+    const int b = idx / a.Sp, s = idx % a.Sp;
+    float v = 0.f;
+    if (b < a.B && s < a.S) {
+        const double rm = a.scal[(size_t)b * 8 + 1];
+        if (rm > 0.0)
+            v = (float)((double)a.w_sem * ((double)a.sem[(size_t)b * a.Sp + s] - (double)a.target_sem[(size_t)b * a.S + s]) /
+                        ((double)a.S * rm));
+    }
+    dsem[idx] = from_f32<AT>(v);
+}
+
+void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem) {
+    const int n = a.Bp * a.Sp;
+    if (dt == BF16)
+        hipLaunchKernelGGL(dsem_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, static_cast<bf16_t*>(dsem));
+    else
+        hipLaunchKernelGGL(dsem_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, static_cast<float*>(dsem));
+}
+
+// dL/dY (pre-pool linear output): each pooled frame's gradient goes half to each of its two frames.
+template <typename AT>
+__global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __restrict__ dY) {
+    const int64_t n = (int64_t)a.T * a.Bp * a.Mp;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int m = (int)(idx % a.Mp);
+    const int b = (int)((idx / a.Mp) % a.Bp);
+    const int t = (int)(idx / ((int64_t)a.Mp * a.Bp));
+    const int tp = t >> 1;
+    float v = 0.f;
+    if (b < a.B && m < a.M && tp < a.Tp) {
+        double g = 0.0;
+        if (a.use_mel) {
+            const double rm = a.scal[(size_t)b * 8 + 0];
+            const size_t e = ((size_t)b * a.Tp + tp) * a.M + m;
+            if (rm > 0.0) g = (double)a.w_mel * ((double)a.mel[e] - (double)a.target_mel[e]) / ((double)a.Tp * a.M * rm);
+        }
+        if (dmel_e) g += (double)dmel_e[((size_t)tp * a.Bp + b) * a.Mp + m];
+        v = (float)(0.5 * g);
+    }
+    dY[idx] = from_f32<AT>(v);
+}
+
+void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY) {
+    const int64_t n = (int64_t)a.T * a.Bp * a.Mp;
+    if (dt == BF16)
+        hipLaunchKernelGGL(dy_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<bf16_t*>(dY));
+    else
+        hipLaunchKernelGGL(dy_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<float*>(dY));
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient of the smoothness terms + Adam
+// ---------------------------------------------------------------------------------------------
+// loss = w * mean(d^2), d[u] = sum_j taps[j] x[u+j], u in [0, n)  =>  dloss/dx[t] = w*2/(n*C) * sum_k taps[k] d[t-k]
+template <int K>
+__device__ __forceinline__ double corr_grad(const double* __restrict__ xc, int T, int C, const double* taps, int t,
+                                            double w) {
+    const int n = T - K + 1;
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int u = t - k;
+        if (u < 0 || u >= n) continue;
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) d += taps[j] * xc[(size_t)(u + j) * C];
+        g += taps[k] * d;
+    }
+    return g * (w * 2.0 / ((double)n * C));
+}
+
+__global__ void total_grad_kernel(AdamArgs a) {
+    const int64_t n = (int64_t)a.B * a.T * a.C;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % a.C);
+    const int t = (int)((idx / a.C) % a.T);
+    const int b = (int)(idx / ((int64_t)a.C * a.T));
+    const double* xc = a.x + (size_t)b * a.T * a.C + c;   // channel c of utterance b, stride C over time
+    double g = (double)a.dX[((size_t)t * a.Bp + b) * a.Cp + c];
+    g += corr_grad<5>(xc, a.T, a.C, kVelTaps, t, (double)a.w_vel);
+    g += corr_grad<13>(xc, a.T, a.C, kJerkTaps, t, (double)a.w_jerk);
+    g += corr_grad<3>(xc, a.T, a.C, kLlTaps, t, (double)a.w_ll);
+    a.grad[idx] = g;
+}
+
+void launch_total_grad(hipStream_t stream, const AdamArgs& a) {
+    const int64_t n = (int64_t)a.B * a.T * a.C;
+    hipLaunchKernelGGL(total_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a);
+}
+
+// torch.optim.Adam (no amsgrad / weight decay) on the CP tensor, then paule/paule.py:1201-1211.
+__global__ void adam_update_kernel(AdamArgs a) {
+    const int64_t n = (int64_t)a.B * a.T * a.C;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % a.C);
+    const int t = (int)((idx / a.C) % a.T);
+    const int b = (int)(idx / ((int64_t)a.C * a.T));
+    const int k = *a.step_count + 1;
+    const double g = a.grad[idx];
+    const double m = a.beta1 * a.m[idx] + (1.0 - a.beta1) * g;
+    const double v = a.beta2 * a.v[idx] + (1.0 - a.beta2) * g * g;
+    a.m[idx] = m;
+    a.v[idx] = v;
+    const double bc1 = 1.0 - pow(a.beta1, (double)k);
+    const double bc2 = 1.0 - pow(a.beta2, (double)k);
+    const double denom = sqrt(v) / sqrt(bc2) + a.eps;
+    double x = a.x[idx] - (a.lr / bc1) * (m / denom);
+    x = fmin(fmax(x, a.clamp_lo), a.clamp_hi);
+    if (a.smiling) {
+        if (c == 4) x = -1.0;   // "LP"
+        if (c == 1) x = 1.0;    // "HY"
+    }
+    if (a.past && t < a.past_len)
+        x = a.past[((size_t)(a.past_per_utt ? b : 0) * a.past_len + t) * a.C + c];
+    a.x[idx] = x;
+}
+
+__global__ void bump_counters_kernel(int* step_count, int* iter_slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *step_count += 1;
+        *iter_slot += 1;
+    }
+}
+
+void launch_adam_update(hipStream_t stream, const AdamArgs& a) {
+    const int64_t n = (int64_t)a.B * a.T * a.C;
+    hipLaunchKernelGGL(adam_update_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, stream, a.step_count, a.iter_slot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conversions
+// ---------------------------------------------------------------------------------------------
+__global__ void f64_to_f32_kernel(const double* __restrict__ s, float* __restrict__ d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (float)s[i];
+}
+__global__ void f32_to_f64_kernel(const float* __restrict__ s, double* __restrict__ d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (double)s[i];
+}
+template <typename AT>
+__global__ void act_to_f32_kernel(const AT* __restrict__ s, float* __restrict__ d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = to_f32<AT>(s[i]);
+}
+__global__ void unpad_rows_kernel(const float* __restrict__ s, int B, int S, int Sp, float* __restrict__ d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * S) d[i] = s[(size_t)(i / S) * Sp + (i % S)];
+}
+
+void launch_f64_to_f32(hipStream_t stream, const double* src, float* dst, int64_t n) {
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, src, dst, n);
+}
+void launch_f32_to_f64(hipStream_t stream, const float* src, double* dst, int64_t n) {
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, src, dst, n);
+}
+void launch_act_to_f32(hipStream_t stream, int dt, const void* src, float* dst, int64_t n) {
+    if (dt == BF16)
+        hipLaunchKernelGGL(act_to_f32_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream,
+                           static_cast<const bf16_t*>(src), dst, n);
+    else
+        hipLaunchKernelGGL(act_to_f32_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream,
+                           static_cast<const float*>(src), dst, n);
+}
+void launch_unpad_rows(hipStream_t stream, const float* src, int B, int S, int Sp, float* dst) {
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3(blocks_for(B * S)), dim3(256), 0, stream, src, B, S, Sp, dst);
+}
+
+}  // namespace pl

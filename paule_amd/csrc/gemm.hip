@@ -1,0 +1,80 @@
+// Batched (non-recurrent) GEMMs of the planner:  C[M,N] = A[M,K] * W[N,K]^T (+ bias)
+//
+// Used for: LSTM input projections for all time steps (W_ih x_t + b), post_linear / linear_mapping,
+// and the backward-data products dA * W_ih, dY * W_p, dsem * W_m (weights pre-transposed at upload,
+// so every product is "NT").  M = T * Bp rows of a time-major activation slab.
+#include "kernels.h"
+#include "tile_gemm.h"
+
+namespace pl {
+
+template <typename AT, typename OT, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const AT* __restrict__ A, int lda, const AT* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias, OT* __restrict__ C, int ldc, int M,
+                                                      int N, int K, int n_blocks_n) {
+    using TG = TileGemm<AT, BM, BN, WM, WN>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TG::LDS_BYTES];
+    const int bid = blockIdx.x;
+    const int m0 = (bid / n_blocks_n) * BM;
+    const int n0 = (bid % n_blocks_n) * BN;
+
+    f32x4 acc[TG::TM][TG::TN];
+#pragma unroll
+    for (int i = 0; i < TG::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TG::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto arow = [&](int r) -> const AT* { return (m0 + r < M) ? A + (size_t)(m0 + r) * lda : nullptr; };
+    auto wrow = [&](int r) -> const AT* { return (n0 + r < N) ? W + (size_t)(n0 + r) * ldw : nullptr; };
+    TG::run(arow, wrow, K, acc, lds);
+
+    const auto cd = TG::coord();
+#pragma unroll
+    for (int j = 0; j < TG::TN; ++j) {
+        const int n = n0 + cd.n(j);
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TG::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + cd.m(i, r);
+                if (m < M) C[(size_t)m * ldc + n] = from_f32<OT>(acc[i][j][r] + bv);
+            }
+    }
+}
+
+template <typename AT, typename OT, int BM, int BN, int WM, int WN>
+static void launch_cfg(hipStream_t stream, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
+                       int ldc, int M, int N, int K) {
+    const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_nt_kernel<AT, OT, BM, BN, WM, WN>), dim3(nbm * nbn), dim3(256), 0, stream,
+                       static_cast<const AT*>(A), lda, static_cast<const AT*>(W), ldw, bias, static_cast<OT*>(C), ldc, M, N,
+                       K, nbn);
+}
+
+template <typename AT, typename OT>
+static void launch_typed(hipStream_t stream, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
+                         int ldc, int M, int N, int K) {
+    if (N <= 32)
+        launch_cfg<AT, OT, 256, 32, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    else if (N <= 64)
+        launch_cfg<AT, OT, 256, 64, 64, 64>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    else
+        launch_cfg<AT, OT, 128, 128, 64, 64>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+}
+
+void launch_gemm_nt(hipStream_t stream, int dt, bool out_f32, const void* A, int lda, const void* W, int ldw,
+                    const float* bias, void* C, int ldc, int M, int N, int K) {
+    if (M <= 0 || N <= 0) return;
+    if (dt == BF16) {
+        if (out_f32)
+            launch_typed<bf16_t, float>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        else
+            launch_typed<bf16_t, bf16_t>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    } else {
+        launch_typed<float, float>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    }
+}
+
+}  // namespace pl

@@ -1,0 +1,106 @@
+// Host-side launch prototypes of every device kernel of the planner (implemented in *.hip).
+// All launches are asynchronous on `stream`; none allocates or synchronises (graph-capture safe).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pl {
+
+enum DType { F32 = 0, BF16 = 1 };
+inline size_t dtype_size(int dt) { return dt == BF16 ? 2 : 4; }
+
+// ---- gemm.hip -------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]);  A, W of activation type `dt`; C float if out_f32 else `dt`.
+// lda/ldw/ldc in elements; K % 32 == 0; rows 16-byte aligned.
+void launch_gemm_nt(hipStream_t stream, int dt, bool out_f32, const void* A, int lda, const void* W, int ldw,
+                    const float* bias, void* C, int ldc, int M, int N, int K);
+
+// ---- lstm.hip -------------------------------------------------------------------------------
+struct LstmStepArgs {
+    int Bp, Hp;            // padded batch rows in a time slab, padded hidden size
+    // forward: G_t holds W_ih x_t + b on entry and the activated gates (i,f,g,o) on exit   [Bp][4*Hp]
+    // backward: G_t holds the activated gates on entry and dA_t on exit; G_next = dA_{t+1} (or null at t = T-1)
+    void* G_t;
+    const void* G_next;
+    const void* W;         // forward: Whh packed [4*Hp][Hp]; backward: Whh^T packed [Hp][4*Hp]
+    const void* h_prev;    // forward: h_{t-1} [Bp][Hp] (null at t = 0)
+    void* h_out;           // forward: h_t [Bp][Hp]
+    const float* c_in;     // forward: running c_{t-1} f32 [Bp][Hp] (null at t = 0); backward: running dc_{t+1}*f_{t+1}
+    float* c_out;          // forward: running c_t; backward: running dc_t * f_t
+    void* c_stash_t;       // forward (write) / backward (read): c_t in activation type [Bp][Hp]
+    const void* c_stash_prev;  // backward: c_{t-1} stash (null at t = 0)
+    const void* dh_ext;    // backward: dL/dh_t from the layer above [Bp][Hp] activation type (null = zeros)
+};
+void launch_lstm_fwd_step(hipStream_t stream, int dt, const LstmStepArgs& a);
+void launch_lstm_bwd_step(hipStream_t stream, int dt, const LstmStepArgs& a);
+
+// ---- elementwise.hip ------------------------------------------------------------------------
+// weight repack: src f32 [nblk*R, C] (torch layout) -> dst `dt` [nblk*Rp, Cp] (transpose = 0)
+//                                              or -> dst `dt` [Cp, nblk*Rp] (transpose = 1), zero padded
+void launch_pack_matrix(hipStream_t stream, int dt, const float* src, int nblk, int R, int C, void* dst, int Rp, int Cp,
+                        bool transpose);
+// bias: dst f32 [nblk*Rp] = b0 + b1 (b1 may be null), zero padded
+void launch_pack_bias(hipStream_t stream, const float* b0, const float* b1, int nblk, int R, float* dst, int Rp);
+
+// x master f64 [B,T,C] -> time-major activation [T][Bp][Cp] (zero padded)
+void launch_pack_cp(hipStream_t stream, int dt, const double* x, int B, int T, int C, void* dst, int Bp, int Cp);
+// user mel f32 [B,Tp,C] -> time-major activation [Tp][Bp][Cp]
+void launch_pack_mel(hipStream_t stream, int dt, const float* mel, int B, int Tp, int C, void* dst, int Bp, int Cp);
+// Y f32 [T][Bp][Cp] -> pooled mel: f32 batch-major [B][Tp][C] and activation time-major [Tp][Bp][Cp]
+void launch_pool_mel(hipStream_t stream, int dt, const float* Y, int B, int T, int C, int Bp, int Cp, float* mel_bm,
+                     void* mel_tm);
+// gather rows h[lens[b]-1][b][:] (lens null -> Tl) of a time-major activation buffer into [Bp][Hp]
+void launch_gather_last(hipStream_t stream, int dt, const void* h_tm, const int32_t* lens, int B, int Tl, int Bp, int Hp,
+                        void* dst);
+
+struct LossArgs {
+    int B, T, Tp, C, M, S;           // batch, frames, mel frames, cp dim, mel dim, sem dim
+    int Bp, Mp, Sp;                  // padded
+    float w_mel, w_sem, w_vel, w_jerk, w_ll;
+    int use_mel, use_sem;            // which terms enter the objective
+    const double* x;                 // CP master [B][T][C]
+    const float* mel;                // pred mel batch-major [B][Tp][M]
+    const float* target_mel;         // [B][Tp][M]
+    const float* sem;                // pred semvec f32 [Bp][Sp] (null if not evaluated)
+    const float* target_sem;         // [B][S]
+    double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse
+    float* loss_rows;                // [cap][B][6] internal log
+    const int* iter_slot;            // device counter: row of loss_rows written by this iteration
+};
+// per-utterance reductions (deterministic, no atomics) -> scal
+void launch_loss_reduce(hipStream_t stream, const LossArgs& a);
+// writes loss_rows[*iter_slot][b][0..5]
+void launch_loss_finalize(hipStream_t stream, const LossArgs& a);
+// dsem activation [Bp][Sp] = w_sem * (sem - target) / (S * rmse_sem)   (zero rows for b >= B, zero pad)
+void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem);
+// dY activation [T][Bp][Mp]: 0.5 * (use_mel * w_mel (mel - tgt)/(N rmse) + dmel_e[t/2][b][m]) ; dmel_e f32 [Tp][Bp][Mp] or null
+void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY);
+
+struct AdamArgs {
+    int B, T, C, Bp, Cp;
+    double lr, beta1, beta2, eps, clamp_lo, clamp_hi;
+    float w_vel, w_jerk, w_ll;
+    int smiling;
+    const float* dX;       // model gradient f32 time-major [T][Bp][Cp]
+    double* x;             // CP master [B][T][C]
+    double* m;
+    double* v;
+    double* grad;          // total gradient [B][T][C] (model + smoothness)
+    int* step_count;       // device counter k (incremented by the update kernel)
+    int* iter_slot;        // device counter (incremented by the update kernel)
+    const double* past;    // past_cp [B or 1][P][C] or null
+    int past_len, past_per_utt;
+};
+// grad = dX^T + d(smoothness)/dx     (reads x, writes grad)
+void launch_total_grad(hipStream_t stream, const AdamArgs& a);
+// Adam + clamp + smiling + past_cp, in place on x/m/v; bumps step_count and iter_slot
+void launch_adam_update(hipStream_t stream, const AdamArgs& a);
+
+// misc conversions
+void launch_f64_to_f32(hipStream_t stream, const double* src, float* dst, int64_t n);
+void launch_f32_to_f64(hipStream_t stream, const float* src, double* dst, int64_t n);
+void launch_act_to_f32(hipStream_t stream, int dt, const void* src, float* dst, int64_t n);
+// strip padding: src f32 [Bp][Sp] -> dst [B][S]
+void launch_unpad_rows(hipStream_t stream, const float* src, int B, int S, int Sp, float* dst);
+
+}  // namespace pl

@@ -1,0 +1,29 @@
+// Shared device-side types and helpers (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pl {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int WAVE = 64;
+
+// every feature dimension is padded to a multiple of 32 elements (zero filled) so that
+// K loops run in whole 16-byte chunks for both f32 (4 el) and bf16 (8 el) and MFMA k-steps
+__host__ __device__ constexpr int pad32(int x) { return (x + 31) / 32 * 32; }
+__host__ __device__ constexpr int pad16(int x) { return (x + 15) / 16 * 16; }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return static_cast<float>(v); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return static_cast<bf16_t>(v); }
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace pl

@@ -1,0 +1,687 @@
+// Planner handle, per-iteration launch sequence and the C-ABI of include/paule_hip.h.
+//
+// One inner iteration (paule/paule.py:910-1211 minus the log-step block) is the fixed kernel sequence
+// built by enqueue_iteration(); it is captured once into a hipGraph and replayed n_iters times by
+// pl_step.  Everything that varies between iterations (Adam step count, loss-log row) lives in device
+// counters, so the captured graph is static.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/paule_hip.h"
+#include "kernels.h"
+#include "pl_types.h"
+
+using namespace pl;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define PL_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+struct LstmLayer {
+    int in = 0, in_p = 0;
+    void *Wih = nullptr, *WihT = nullptr, *Whh = nullptr, *WhhT = nullptr;
+    float* bias = nullptr;
+    void *G = nullptr, *h = nullptr, *c = nullptr;   // time-major slabs [Tl][Bp][4Hp] / [Tl][Bp][Hp]
+    bool set = false;
+};
+
+struct Model {
+    int L = 0, H = 0, Hp = 0, in = 0, in_p = 0, out = 0, out_p = 0, Tl = 0;
+    std::vector<LstmLayer> layers;
+    void *Wlin = nullptr, *WlinT = nullptr;   // [out_p][Hp], [Hp][out_p]
+    float* blin = nullptr;
+    void* dh_ext = nullptr;                   // [Tl][Bp][Hp] dL/dh of the layer being back-propagated
+    bool lin_set = false;
+    bool ready() const {
+        if (!lin_set) return false;
+        for (auto& l : layers)
+            if (!l.set) return false;
+        return true;
+    }
+};
+
+}  // namespace
+
+struct pl_handle {
+    pl_config cfg{};
+    int B = 0, T = 0, Tp = 0, C = 0, M = 0, S = 0, Bp = 0, Cp = 0, Mp = 0, Sp = 0, dt = 0;
+    hipStream_t stream = nullptr;
+    Model pred, emb;
+    float* c_run[2] = {nullptr, nullptr};
+    float* dc_run[2] = {nullptr, nullptr};
+    void* X0 = nullptr;
+    float* Y = nullptr;
+    float* mel_bm = nullptr;
+    void* mel_tm = nullptr;
+    void* h_last = nullptr;
+    float* sem = nullptr;
+    void* dsem = nullptr;
+    void* dv = nullptr;
+    float* dmel_e = nullptr;
+    void* dY = nullptr;
+    float* dX = nullptr;
+    double *x = nullptr, *m = nullptr, *v = nullptr, *grad = nullptr;
+    float *target_mel = nullptr, *target_sem = nullptr;
+    float* out_tmp = nullptr;   // [B][max(S, ...)] staging for unpadded outputs
+    double* scal = nullptr;
+    float* loss_rows = nullptr;
+    int loss_cap = 0;
+    int* counters = nullptr;    // [0] Adam step count, [1] loss row of the running iteration
+    double* past = nullptr;
+    int past_len = 0, past_per_utt = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    bool have_targets = false, have_sem_target = false, have_cp = false;
+    size_t bytes = 0;
+    std::vector<void*> allocs;
+    size_t act = 4;   // bytes per activation element
+
+    bool need_emb_in_step() const { return cfg.objective != PL_OBJ_ACOUSTIC; }
+    bool use_mel() const { return cfg.objective != PL_OBJ_SEMVEC; }
+};
+
+namespace {
+
+int raw_alloc(pl_handle* h, void** p, size_t nb) {
+    void* q = nullptr;
+    PL_HIP(hipMalloc(&q, nb ? nb : 16));
+    PL_HIP(hipMemsetAsync(q, 0, nb ? nb : 16, h->stream));
+    h->allocs.push_back(q);
+    h->bytes += nb;
+    *p = q;
+    return PL_OK;
+}
+
+template <typename T>
+int dev_alloc(pl_handle* h, T** p, size_t n_elems) {
+    void* q = nullptr;
+    int rc = raw_alloc(h, &q, n_elems * sizeof(T));
+    *p = static_cast<T*>(q);
+    return rc;
+}
+
+int alloc_act(pl_handle* h, void** p, size_t n_elems) { return raw_alloc(h, p, n_elems * h->act); }
+
+int alloc_model(pl_handle* h, Model& md, int L, int H, int in, int out, int Tl) {
+    md.L = L;
+    md.H = H;
+    md.Hp = pad32(H);
+    md.in = in;
+    md.in_p = pad32(in);
+    md.out = out;
+    md.out_p = pad32(out);
+    md.Tl = Tl;
+    md.layers.resize(L);
+    const size_t Bp = h->Bp, Hp = md.Hp;
+    for (int l = 0; l < L; ++l) {
+        LstmLayer& ly = md.layers[l];
+        ly.in = l == 0 ? in : H;
+        ly.in_p = pad32(ly.in);
+        int rc;
+        if ((rc = alloc_act(h, &ly.Wih, 4 * Hp * ly.in_p))) return rc;
+        if ((rc = alloc_act(h, &ly.WihT, (size_t)ly.in_p * 4 * Hp))) return rc;
+        if ((rc = alloc_act(h, &ly.Whh, 4 * Hp * Hp))) return rc;
+        if ((rc = alloc_act(h, &ly.WhhT, Hp * 4 * Hp))) return rc;
+        if ((rc = dev_alloc(h, &ly.bias, 4 * Hp))) return rc;
+        if ((rc = alloc_act(h, &ly.G, (size_t)Tl * Bp * 4 * Hp))) return rc;
+        if ((rc = alloc_act(h, &ly.h, (size_t)Tl * Bp * Hp))) return rc;
+        if ((rc = alloc_act(h, &ly.c, (size_t)Tl * Bp * Hp))) return rc;
+    }
+    int rc;
+    if ((rc = alloc_act(h, &md.Wlin, (size_t)md.out_p * Hp))) return rc;
+    if ((rc = alloc_act(h, &md.WlinT, Hp * md.out_p))) return rc;
+    if ((rc = dev_alloc(h, &md.blin, md.out_p))) return rc;
+    if ((rc = alloc_act(h, &md.dh_ext, (size_t)Tl * Bp * Hp))) return rc;
+    return PL_OK;
+}
+
+inline char* off(void* p, size_t elems, size_t esz) { return static_cast<char*>(p) + elems * esz; }
+
+// stacked LSTM forward over all Tl steps; in_act = time-major [Tl][Bp][in_p]
+void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) {
+    const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
+    const size_t a = h->act;
+    const void* cur_in = in_act;
+    for (int l = 0; l < md.L; ++l) {
+        LstmLayer& ly = md.layers[l];
+        // input projection for every time step at once: G = in * Wih^T + (b_ih + b_hh)
+        launch_gemm_nt(st, h->dt, false, cur_in, ly.in_p, ly.Wih, ly.in_p, ly.bias, ly.G, 4 * Hp, Tl * Bp, 4 * Hp, ly.in_p);
+        for (int t = 0; t < Tl; ++t) {
+            LstmStepArgs s{};
+            s.Bp = Bp;
+            s.Hp = Hp;
+            s.G_t = off(ly.G, (size_t)t * Bp * 4 * Hp, a);
+            s.W = ly.Whh;
+            s.h_prev = t ? off(ly.h, (size_t)(t - 1) * Bp * Hp, a) : nullptr;
+            s.h_out = off(ly.h, (size_t)t * Bp * Hp, a);
+            s.c_in = t ? h->c_run[(t - 1) & 1] : nullptr;
+            s.c_out = h->c_run[t & 1];
+            s.c_stash_t = off(ly.c, (size_t)t * Bp * Hp, a);
+            launch_lstm_fwd_step(st, h->dt, s);
+        }
+        cur_in = ly.h;
+    }
+}
+
+// backward-data through the stack.  Top-layer dL/dh is either dense (md.dh_ext, all steps) or, when
+// dh_last != nullptr, a single [Bp][Hp] slab applied at the last step only (EmbeddingModel: only
+// output[:, lens-1] feeds the loss, paule/models.py:442).  dIn: f32 time-major [Tl][Bp][in_p].
+void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn) {
+    const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
+    const size_t a = h->act;
+    for (int l = md.L - 1; l >= 0; --l) {
+        LstmLayer& ly = md.layers[l];
+        const bool sparse_top = (l == md.L - 1) && dh_last;
+        for (int t = Tl - 1; t >= 0; --t) {
+            LstmStepArgs s{};
+            s.Bp = Bp;
+            s.Hp = Hp;
+            s.G_t = off(ly.G, (size_t)t * Bp * 4 * Hp, a);
+            s.G_next = (t + 1 < Tl) ? off(ly.G, (size_t)(t + 1) * Bp * 4 * Hp, a) : nullptr;
+            s.W = ly.WhhT;
+            s.c_in = (t + 1 < Tl) ? h->dc_run[(t + 1) & 1] : nullptr;
+            s.c_out = h->dc_run[t & 1];
+            s.c_stash_t = off(ly.c, (size_t)t * Bp * Hp, a);
+            s.c_stash_prev = t ? off(ly.c, (size_t)(t - 1) * Bp * Hp, a) : nullptr;
+            if (sparse_top)
+                s.dh_ext = (t == Tl - 1) ? dh_last : nullptr;
+            else
+                s.dh_ext = off(md.dh_ext, (size_t)t * Bp * Hp, a);
+            launch_lstm_bwd_step(st, h->dt, s);
+        }
+        if (l > 0)   // dL/dh of the layer below = dA * Wih
+            launch_gemm_nt(st, h->dt, false, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, md.dh_ext, Hp, Tl * Bp, Hp, 4 * Hp);
+        else
+            launch_gemm_nt(st, h->dt, true, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, dIn, ly.in_p, Tl * Bp, ly.in_p, 4 * Hp);
+    }
+}
+
+void pred_forward(pl_handle* h, hipStream_t st) {
+    launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
+    model_forward(h, st, h->pred, h->X0);
+    Model& p = h->pred;
+    launch_gemm_nt(st, h->dt, true, p.layers[p.L - 1].h, p.Hp, p.Wlin, p.Hp, p.blin, h->Y, h->Mp, h->T * h->Bp, h->Mp, p.Hp);
+    launch_pool_mel(st, h->dt, h->Y, h->B, h->T, h->M, h->Bp, h->Mp, h->mel_bm, h->mel_tm);
+}
+
+void emb_forward(pl_handle* h, hipStream_t st, const int32_t* lens) {
+    Model& e = h->emb;
+    model_forward(h, st, e, h->mel_tm);
+    launch_gather_last(st, h->dt, e.layers[e.L - 1].h, lens, h->B, e.Tl, h->Bp, e.Hp, h->h_last);
+    launch_gemm_nt(st, h->dt, true, h->h_last, e.Hp, e.Wlin, e.Hp, e.blin, h->sem, h->Sp, h->Bp, h->Sp, e.Hp);
+}
+
+LossArgs loss_args(pl_handle* h, bool with_sem) {
+    LossArgs a{};
+    a.B = h->B; a.T = h->T; a.Tp = h->Tp; a.C = h->C; a.M = h->M; a.S = h->S;
+    a.Bp = h->Bp; a.Mp = h->Mp; a.Sp = h->Sp;
+    a.w_mel = h->cfg.w_mel; a.w_sem = h->cfg.w_sem; a.w_vel = h->cfg.w_vel; a.w_jerk = h->cfg.w_jerk; a.w_ll = h->cfg.w_ll;
+    a.use_mel = h->use_mel() ? 1 : 0;
+    a.use_sem = with_sem ? 1 : 0;
+    a.x = h->x; a.mel = h->mel_bm; a.target_mel = h->target_mel;
+    a.sem = with_sem ? h->sem : nullptr;
+    a.target_sem = h->target_sem;
+    a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1;
+    return a;
+}
+
+AdamArgs adam_args(pl_handle* h) {
+    AdamArgs a{};
+    a.B = h->B; a.T = h->T; a.C = h->C; a.Bp = h->Bp; a.Cp = h->Cp;
+    a.lr = h->cfg.lr; a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.eps;
+    a.clamp_lo = h->cfg.clamp_lo; a.clamp_hi = h->cfg.clamp_hi;
+    a.w_vel = h->cfg.w_vel; a.w_jerk = h->cfg.w_jerk; a.w_ll = h->cfg.w_ll;
+    a.smiling = h->cfg.smiling;
+    a.dX = h->dX; a.x = h->x; a.m = h->m; a.v = h->v; a.grad = h->grad;
+    a.step_count = h->counters; a.iter_slot = h->counters + 1;
+    a.past = h->past_len > 0 ? h->past : nullptr;
+    a.past_len = h->past_len; a.past_per_utt = h->past_per_utt;
+    return a;
+}
+
+// one inner iteration: forward, criterion, backward-data, Adam + projection
+void enqueue_iteration(pl_handle* h, hipStream_t st) {
+    const bool with_sem = h->need_emb_in_step();
+    pred_forward(h, st);
+    if (with_sem) emb_forward(h, st, nullptr);
+    LossArgs la = loss_args(h, with_sem);
+    launch_loss_reduce(st, la);
+    launch_loss_finalize(st, la);
+    const float* dmel_e = nullptr;
+    if (with_sem) {
+        Model& e = h->emb;
+        launch_dsem(st, h->dt, la, h->dsem);
+        // dL/dh_last = dsem * W_m
+        launch_gemm_nt(st, h->dt, false, h->dsem, h->Sp, e.WlinT, h->Sp, nullptr, h->dv, e.Hp, h->Bp, e.Hp, h->Sp);
+        model_backward(h, st, e, h->dv, h->dmel_e);
+        dmel_e = h->dmel_e;
+    }
+    launch_dy(st, h->dt, la, dmel_e, h->dY);
+    Model& p = h->pred;
+    // dL/dh_top(t) = dY_t * W_p
+    launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, h->T * h->Bp, p.Hp, h->Mp);
+    model_backward(h, st, p, nullptr, h->dX);
+    AdamArgs aa = adam_args(h);
+    launch_total_grad(st, aa);
+    launch_adam_update(st, aa);
+}
+
+int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PL_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return PL_OK;
+}
+
+void drop_graph(pl_handle* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+}
+
+int build_graph(pl_handle* h) {
+    if (!h->cap_stream) PL_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    PL_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed));
+    enqueue_iteration(h, h->cap_stream);
+    hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
+    if (e != hipSuccess) return fail(PL_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    PL_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    return PL_OK;
+}
+
+double lstm_flops_per_step(int L, int H, int in) {
+    double f = 0;
+    for (int l = 0; l < L; ++l) f += 2.0 * 4 * H * ((l == 0 ? in : H) + H);
+    return f;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+const char* pl_last_error(void) { return g_last_error.c_str(); }
+int pl_version(void) { return PL_VERSION; }
+
+int pl_default_config(pl_config* cfg) {
+    if (!cfg) return fail(PL_ERR_INVALID, "cfg is NULL");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(pl_config);
+    cfg->batch = 1;
+    cfg->n_frames = 0;
+    cfg->cp_dim = 30;
+    cfg->mel_dim = 60;
+    cfg->sem_dim = 300;
+    cfg->pred_layers = 1;     // Paule default predictive model (paule/paule.py:124)
+    cfg->pred_hidden = 720;
+    cfg->emb_layers = 2;      // Paule default embedder (paule/paule.py:167)
+    cfg->emb_hidden = 720;
+    cfg->dtype = PL_F32;
+    cfg->objective = PL_OBJ_ACOUSTIC;
+    cfg->w_mel = 5.0f;        // paule/paule.py:592-597
+    cfg->w_sem = 10.0f;
+    cfg->w_vel = 80.0f;
+    cfg->w_jerk = 400.0f;
+    cfg->w_ll = 100000.0f;
+    cfg->lr = 0.01f;
+    cfg->beta1 = 0.9f;
+    cfg->beta2 = 0.999f;
+    cfg->eps = 1e-8f;
+    cfg->clamp_lo = -1.05f;
+    cfg->clamp_hi = 1.05f;
+    cfg->smiling = 0;
+    cfg->device = 0;
+    cfg->use_graph = 1;
+    cfg->stream = nullptr;
+    return PL_OK;
+}
+
+int pl_create(const pl_config* cfg, pl_handle** out) {
+    if (!cfg || !out) return fail(PL_ERR_INVALID, "pl_create: NULL argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(pl_config))
+        return fail(PL_ERR_INVALID, "pl_create: pl_config.struct_size mismatch (ABI drift)");
+    if (cfg->batch < 1 || cfg->cp_dim < 1 || cfg->mel_dim < 1 || cfg->sem_dim < 1)
+        return fail(PL_ERR_INVALID, "pl_create: batch and feature dims must be >= 1");
+    if (cfg->n_frames < 14)
+        return fail(PL_ERR_INVALID, "pl_create: n_frames must be >= 14 (jerk needs T - 12 >= 1 frames, mel needs T/2 >= 1)");
+    if (cfg->pred_layers < 1 || cfg->pred_hidden < 1) return fail(PL_ERR_INVALID, "pl_create: predictive model needs >= 1 LSTM layer");
+    if (cfg->emb_layers < 0 || (cfg->emb_layers > 0 && cfg->emb_hidden < 1)) return fail(PL_ERR_INVALID, "pl_create: bad embedder shape");
+    if (cfg->dtype != PL_F32 && cfg->dtype != PL_BF16) return fail(PL_ERR_INVALID, "pl_create: dtype must be PL_F32 or PL_BF16");
+    if (cfg->objective < PL_OBJ_ACOUSTIC || cfg->objective > PL_OBJ_SEMVEC)
+        return fail(PL_ERR_INVALID, "objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'");
+    if (cfg->objective != PL_OBJ_ACOUSTIC && cfg->emb_layers == 0)
+        return fail(PL_ERR_INVALID, "pl_create: semvec objectives need an embedder (emb_layers > 0)");
+    if (cfg->cp_dim < 5 && cfg->smiling) return fail(PL_ERR_INVALID, "pl_create: smiling needs cp_dim >= 5");
+    int ndev = 0;
+    PL_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(PL_ERR_INVALID, "pl_create: no such HIP device");
+    DeviceGuard guard(cfg->device);
+
+    pl_handle* h = new pl_handle();
+    h->cfg = *cfg;
+    h->stream = static_cast<hipStream_t>(cfg->stream);
+    h->B = cfg->batch; h->T = cfg->n_frames; h->Tp = cfg->n_frames / 2;
+    h->C = cfg->cp_dim; h->M = cfg->mel_dim; h->S = cfg->sem_dim;
+    h->Bp = pad16(h->B); h->Cp = pad32(h->C); h->Mp = pad32(h->M); h->Sp = pad32(h->S);
+    h->dt = cfg->dtype == PL_BF16 ? BF16 : F32;
+    h->act = dtype_size(h->dt);
+    h->loss_cap = 256;
+
+    int rc = PL_OK;
+    auto bail = [&](int code) { pl_destroy(h); return code; };
+    if ((rc = alloc_model(h, h->pred, cfg->pred_layers, cfg->pred_hidden, h->C, h->M, h->T))) return bail(rc);
+    int hmax = h->pred.Hp;
+    if (cfg->emb_layers > 0) {
+        if ((rc = alloc_model(h, h->emb, cfg->emb_layers, cfg->emb_hidden, h->M, h->S, h->Tp))) return bail(rc);
+        hmax = hmax > h->emb.Hp ? hmax : h->emb.Hp;
+    }
+    const size_t Bp = h->Bp, T = h->T, Tp = h->Tp, B = h->B;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = dev_alloc(h, &h->c_run[i], Bp * hmax))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->dc_run[i], Bp * hmax))) return bail(rc);
+    }
+    if ((rc = alloc_act(h, &h->X0, T * Bp * h->Cp))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->Y, T * Bp * h->Mp))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->mel_bm, B * Tp * h->M))) return bail(rc);
+    if ((rc = alloc_act(h, &h->mel_tm, Tp * Bp * h->Mp))) return bail(rc);
+    if ((rc = alloc_act(h, &h->dY, T * Bp * h->Mp))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->dX, T * Bp * h->Cp))) return bail(rc);
+    if (cfg->emb_layers > 0) {
+        if ((rc = alloc_act(h, &h->h_last, Bp * h->emb.Hp))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->sem, Bp * h->Sp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->dsem, Bp * h->Sp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->dv, Bp * h->emb.Hp))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->dmel_e, Tp * Bp * h->Mp))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->target_sem, B * h->S))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->out_tmp, B * h->S))) return bail(rc);
+    }
+    if ((rc = dev_alloc(h, &h->x, B * T * h->C))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->m, B * T * h->C))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->v, B * T * h->C))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->grad, B * T * h->C))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->target_mel, B * Tp * h->M))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->scal, B * 8))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->loss_rows, (size_t)h->loss_cap * B * PL_LOSS_COLS))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->counters, 4))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->past, B * T * h->C))) return bail(rc);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { bail(PL_ERR_HIP); return fail(PL_ERR_HIP, std::string("pl_create: ") + hipGetErrorString(e)); }
+    *out = h;
+    return PL_OK;
+}
+
+int pl_destroy(pl_handle* h) {
+    if (!h) return PL_OK;
+    DeviceGuard guard(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return PL_OK;
+}
+
+int pl_set_lstm_weights(pl_handle* h, int model_id, int layer, const float* w_ih, const float* w_hh, const float* b_ih,
+                        const float* b_hh) {
+    if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: NULL argument");
+    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (layer < 0 || layer >= md.L) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: layer out of range for this model");
+    DeviceGuard guard(h->cfg.device);
+    LstmLayer& ly = md.layers[layer];
+    hipStream_t st = h->stream;
+    launch_pack_matrix(st, h->dt, w_ih, 4, md.H, ly.in, ly.Wih, md.Hp, ly.in_p, false);
+    launch_pack_matrix(st, h->dt, w_ih, 4, md.H, ly.in, ly.WihT, md.Hp, ly.in_p, true);
+    launch_pack_matrix(st, h->dt, w_hh, 4, md.H, md.H, ly.Whh, md.Hp, md.Hp, false);
+    launch_pack_matrix(st, h->dt, w_hh, 4, md.H, md.H, ly.WhhT, md.Hp, md.Hp, true);
+    launch_pack_bias(st, b_ih, b_hh, 4, md.H, ly.bias, md.Hp);
+    ly.set = true;
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(st));   // caller may free/mutate its tensors on return
+    return PL_OK;
+}
+
+int pl_set_linear(pl_handle* h, int model_id, const float* w, const float* b) {
+    if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_set_linear: NULL argument");
+    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_set_linear: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (md.L == 0) return fail(PL_ERR_INVALID, "pl_set_linear: this handle has no such model");
+    DeviceGuard guard(h->cfg.device);
+    hipStream_t st = h->stream;
+    launch_pack_matrix(st, h->dt, w, 1, md.out, md.H, md.Wlin, md.out_p, md.Hp, false);
+    launch_pack_matrix(st, h->dt, w, 1, md.out, md.H, md.WlinT, md.out_p, md.Hp, true);
+    launch_pack_bias(st, b, nullptr, 1, md.out, md.blin, md.out_p);
+    md.lin_set = true;
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(st));
+    return PL_OK;
+}
+
+int pl_set_targets(pl_handle* h, const float* target_mel, const float* target_semvec) {
+    if (!h || !target_mel) return fail(PL_ERR_INVALID, "pl_set_targets: target_mel is NULL");
+    DeviceGuard guard(h->cfg.device);
+    PL_HIP(hipMemcpyAsync(h->target_mel, target_mel, sizeof(float) * h->B * h->Tp * h->M, hipMemcpyDeviceToDevice, h->stream));
+    h->have_targets = true;
+    if (target_semvec) {
+        if (!h->target_sem) return fail(PL_ERR_INVALID, "pl_set_targets: target_semvec given but the handle has no embedder");
+        PL_HIP(hipMemcpyAsync(h->target_sem, target_semvec, sizeof(float) * h->B * h->S, hipMemcpyDeviceToDevice, h->stream));
+        h->have_sem_target = true;
+    }
+    PL_HIP(hipStreamSynchronize(h->stream));
+    return PL_OK;
+}
+
+int pl_set_cp(pl_handle* h, const float* cp) {
+    if (!h || !cp) return fail(PL_ERR_INVALID, "pl_set_cp: NULL argument");
+    DeviceGuard guard(h->cfg.device);
+    launch_f32_to_f64(h->stream, cp, h->x, (int64_t)h->B * h->T * h->C);
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(h->stream));
+    h->have_cp = true;
+    return PL_OK;
+}
+
+int pl_set_past_cp(pl_handle* h, const float* past_cp, int past_len, int per_utterance) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_set_past_cp: NULL handle");
+    if (!past_cp || past_len <= 0) {
+        if (h->past_len != 0) drop_graph(h);
+        h->past_len = 0;
+        return PL_OK;
+    }
+    if (past_len % 2 != 0)   // paule/paule.py:575-576
+        return fail(PL_ERR_INVALID, "past_cp have to be None or the sequence length has to be an even number");
+    if (past_len > h->T) return fail(PL_ERR_INVALID, "pl_set_past_cp: past_len exceeds n_frames");
+    DeviceGuard guard(h->cfg.device);
+    const int64_t n = (int64_t)(per_utterance ? h->B : 1) * past_len * h->C;
+    launch_f32_to_f64(h->stream, past_cp, h->past, n);
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(h->stream));
+    if (h->past_len != past_len || h->past_per_utt != (per_utterance ? 1 : 0)) drop_graph(h);   // kernel args change
+    h->past_len = past_len;
+    h->past_per_utt = per_utterance ? 1 : 0;
+    return PL_OK;
+}
+
+int pl_reset_optimizer(pl_handle* h) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_reset_optimizer: NULL handle");
+    DeviceGuard guard(h->cfg.device);
+    const size_t nb = sizeof(double) * h->B * h->T * h->C;
+    PL_HIP(hipMemsetAsync(h->m, 0, nb, h->stream));
+    PL_HIP(hipMemsetAsync(h->v, 0, nb, h->stream));
+    PL_HIP(hipMemsetAsync(h->counters, 0, sizeof(int) * 4, h->stream));
+    return PL_OK;
+}
+
+static int check_ready(pl_handle* h, bool need_sem, const char* who) {
+    if (!h->pred.ready()) return fail(PL_ERR_STATE, std::string(who) + ": predictive-model weights are not set");
+    if (need_sem && !h->emb.ready()) return fail(PL_ERR_STATE, std::string(who) + ": embedder weights are not set");
+    if (!h->have_cp) return fail(PL_ERR_STATE, std::string(who) + ": pl_set_cp has not been called");
+    return PL_OK;
+}
+
+int pl_step(pl_handle* h, int n_iters, float* loss_log, float* grad_out) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_step: NULL handle");
+    if (n_iters < 0) return fail(PL_ERR_INVALID, "pl_step: n_iters < 0");
+    const bool with_sem = h->need_emb_in_step();
+    int rc = check_ready(h, with_sem, "pl_step");
+    if (rc) return rc;
+    if (!h->have_targets) return fail(PL_ERR_STATE, "pl_step: pl_set_targets has not been called");
+    if (with_sem && !h->have_sem_target) return fail(PL_ERR_STATE, "pl_step: objective needs a target_semvec");
+    DeviceGuard guard(h->cfg.device);
+    if (h->cfg.use_graph && !h->graph_exec && n_iters > 0) {
+        rc = build_graph(h);
+        if (rc) return rc;
+    }
+    int done = 0;
+    while (done < n_iters) {
+        const int chunk = (n_iters - done) < h->loss_cap ? (n_iters - done) : h->loss_cap;
+        PL_HIP(hipMemsetAsync(h->counters + 1, 0, sizeof(int), h->stream));
+        for (int i = 0; i < chunk; ++i) {
+            if (h->graph_exec)
+                PL_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+            else
+                enqueue_iteration(h, h->stream);
+        }
+        if (loss_log)
+            PL_HIP(hipMemcpyAsync(loss_log + (size_t)done * h->B * PL_LOSS_COLS, h->loss_rows,
+                                  sizeof(float) * chunk * h->B * PL_LOSS_COLS, hipMemcpyDeviceToDevice, h->stream));
+        done += chunk;
+    }
+    if (grad_out && n_iters > 0) launch_f64_to_f32(h->stream, h->grad, grad_out, (int64_t)h->B * h->T * h->C);
+    return check_launch();
+}
+
+int pl_get_cp(pl_handle* h, float* cp_out) {
+    if (!h || !cp_out) return fail(PL_ERR_INVALID, "pl_get_cp: NULL argument");
+    DeviceGuard guard(h->cfg.device);
+    launch_f64_to_f32(h->stream, h->x, cp_out, (int64_t)h->B * h->T * h->C);
+    return check_launch();
+}
+
+int pl_get_pred(pl_handle* h, float* pred_mel_out, float* pred_semvec_out) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_get_pred: NULL handle");
+    int rc = check_ready(h, pred_semvec_out != nullptr, "pl_get_pred");
+    if (rc) return rc;
+    if (pred_semvec_out && h->emb.L == 0) return fail(PL_ERR_INVALID, "pl_get_pred: pred_semvec requested but the handle has no embedder");
+    DeviceGuard guard(h->cfg.device);
+    hipStream_t st = h->stream;
+    pred_forward(h, st);
+    if (pred_mel_out)
+        PL_HIP(hipMemcpyAsync(pred_mel_out, h->mel_bm, sizeof(float) * h->B * h->Tp * h->M, hipMemcpyDeviceToDevice, st));
+    if (pred_semvec_out) {
+        emb_forward(h, st, nullptr);
+        launch_unpad_rows(st, h->sem, h->B, h->S, h->Sp, pred_semvec_out);
+    }
+    return check_launch();
+}
+
+int pl_embed_mel(pl_handle* h, const float* mel, const int32_t* lens, float* semvec_out) {
+    if (!h || !mel || !semvec_out) return fail(PL_ERR_INVALID, "pl_embed_mel: NULL argument");
+    if (h->emb.L == 0) return fail(PL_ERR_INVALID, "pl_embed_mel: the handle has no embedder");
+    if (!h->emb.ready()) return fail(PL_ERR_STATE, "pl_embed_mel: embedder weights are not set");
+    DeviceGuard guard(h->cfg.device);
+    hipStream_t st = h->stream;
+    launch_pack_mel(st, h->dt, mel, h->B, h->Tp, h->M, h->mel_tm, h->Bp, h->Mp);
+    emb_forward(h, st, lens);
+    launch_unpad_rows(st, h->sem, h->B, h->S, h->Sp, semvec_out);
+    return check_launch();
+}
+
+int64_t pl_device_bytes(const pl_handle* h) { return h ? (int64_t)h->bytes : 0; }
+
+double pl_flops_per_iteration(const pl_handle* h) {
+    if (!h) return 0.0;
+    // forward + backward-data = 2 x forward; elementwise work excluded
+    double f = (lstm_flops_per_step(h->pred.L, h->pred.H, h->C) + 2.0 * h->pred.H * h->M) * h->T;
+    if (h->need_emb_in_step())
+        f += lstm_flops_per_step(h->emb.L, h->emb.H, h->M) * h->Tp + 2.0 * h->emb.H * h->S;
+    return 2.0 * f * h->B;
+}
+
+int pl_debug_read(pl_handle* h, const char* name, float* out, int64_t max_elems, int64_t* n_out) {
+    if (!h || !name) return fail(PL_ERR_INVALID, "pl_debug_read: NULL argument");
+    DeviceGuard guard(h->cfg.device);
+    const std::string nm(name);
+    const void* src = nullptr;
+    int64_t n = 0;
+    int kind = 0;   // 0 activation type, 1 f32, 2 f64
+    auto model_buf = [&](Model& md, const std::string& rest) -> bool {
+        if (rest == "dh_ext") { src = md.dh_ext; n = (int64_t)md.Tl * h->Bp * md.Hp; kind = 0; return true; }
+        if (rest.size() < 2) return false;
+        const int l = std::atoi(rest.c_str() + 1);
+        if (l < 0 || l >= md.L) return false;
+        LstmLayer& ly = md.layers[l];
+        switch (rest[0]) {
+            case 'G': src = ly.G; n = (int64_t)md.Tl * h->Bp * 4 * md.Hp; kind = 0; return true;
+            case 'h': src = ly.h; n = (int64_t)md.Tl * h->Bp * md.Hp; kind = 0; return true;
+            case 'c': src = ly.c; n = (int64_t)md.Tl * h->Bp * md.Hp; kind = 0; return true;
+            case 'W': src = ly.Whh; n = (int64_t)4 * md.Hp * md.Hp; kind = 0; return true;
+            case 'b': src = ly.bias; n = (int64_t)4 * md.Hp; kind = 1; return true;
+            default: return false;
+        }
+    };
+    bool ok = false;
+    if (nm.rfind("pred.", 0) == 0) ok = model_buf(h->pred, nm.substr(5));
+    else if (nm.rfind("emb.", 0) == 0 && h->emb.L > 0) ok = model_buf(h->emb, nm.substr(4));
+    else if (nm == "X0") { src = h->X0; n = (int64_t)h->T * h->Bp * h->Cp; kind = 0; ok = true; }
+    else if (nm == "Y") { src = h->Y; n = (int64_t)h->T * h->Bp * h->Mp; kind = 1; ok = true; }
+    else if (nm == "mel") { src = h->mel_bm; n = (int64_t)h->B * h->Tp * h->M; kind = 1; ok = true; }
+    else if (nm == "mel_tm") { src = h->mel_tm; n = (int64_t)h->Tp * h->Bp * h->Mp; kind = 0; ok = true; }
+    else if (nm == "dY") { src = h->dY; n = (int64_t)h->T * h->Bp * h->Mp; kind = 0; ok = true; }
+    else if (nm == "dX") { src = h->dX; n = (int64_t)h->T * h->Bp * h->Cp; kind = 1; ok = true; }
+    else if (nm == "sem" && h->sem) { src = h->sem; n = (int64_t)h->Bp * h->Sp; kind = 1; ok = true; }
+    else if (nm == "dsem" && h->dsem) { src = h->dsem; n = (int64_t)h->Bp * h->Sp; kind = 0; ok = true; }
+    else if (nm == "dv" && h->dv) { src = h->dv; n = (int64_t)h->Bp * h->emb.Hp; kind = 0; ok = true; }
+    else if (nm == "dmel_e" && h->dmel_e) { src = h->dmel_e; n = (int64_t)h->Tp * h->Bp * h->Mp; kind = 1; ok = true; }
+    else if (nm == "grad") { src = h->grad; n = (int64_t)h->B * h->T * h->C; kind = 2; ok = true; }
+    else if (nm == "x") { src = h->x; n = (int64_t)h->B * h->T * h->C; kind = 2; ok = true; }
+    else if (nm == "m") { src = h->m; n = (int64_t)h->B * h->T * h->C; kind = 2; ok = true; }
+    else if (nm == "v") { src = h->v; n = (int64_t)h->B * h->T * h->C; kind = 2; ok = true; }
+    else if (nm == "scal") { src = h->scal; n = (int64_t)h->B * 8; kind = 2; ok = true; }
+    if (!ok) return fail(PL_ERR_INVALID, "pl_debug_read: unknown buffer '" + nm + "'");
+    if (n_out) *n_out = n;
+    if (!out) return PL_OK;
+    if (max_elems < n) return fail(PL_ERR_INVALID, "pl_debug_read: output too small");
+    if (kind == 0) launch_act_to_f32(h->stream, h->dt, src, out, n);
+    else if (kind == 1) PL_HIP(hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
+    else launch_f64_to_f32(h->stream, static_cast<const double*>(src), out, n);
+    return check_launch();
+}
+
+}  // extern "C"

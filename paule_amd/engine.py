@@ -1,0 +1,200 @@
+"""Host-side driver of the MI355X planning engine (one handle <-> one GPU <-> one stream).
+
+``HipPlanner`` owns a ``pl_handle`` of libpaule_hip.so and exposes the inner loop of
+``Paule.plan_resynth`` (paule/paule.py:910-1211) as ``step(n_iters)``; PyTorch-ROCm is used
+only to allocate device tensors and hand their addresses across the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+
+DTYPES = {"f32": _capi.PL_F32, "fp32": _capi.PL_F32, "float32": _capi.PL_F32,
+          "bf16": _capi.PL_BF16, "bfloat16": _capi.PL_BF16}
+
+
+def _lstm_dims(sd):
+    n_layers = len([k for k in sd if k.startswith("lstm.weight_hh_l")])
+    return int(sd["lstm.weight_ih_l0"].shape[1]), int(sd["lstm.weight_hh_l0"].shape[1]), n_layers
+
+
+def _state_dict(model_or_sd):
+    if model_or_sd is None:
+        return None
+    if hasattr(model_or_sd, "state_dict"):
+        return model_or_sd.state_dict()
+    return model_or_sd
+
+
+class HipPlanner:
+    """Batched gradient planning of CP trajectories on one MI355X.
+
+    pred_model / embedder: ``torch.nn.Module`` or state dict with the reference's key layout
+    (``lstm.weight_ih_l{k}``, ``lstm.weight_hh_l{k}``, ``lstm.bias_ih_l{k}``, ``lstm.bias_hh_l{k}``,
+    ``post_linear.*`` / ``linear_mapping.*``; paule/models.py:344-346, :431-437).
+    """
+
+    def __init__(self, pred_model, embedder=None, *, batch, n_frames, objective="acoustic", dtype="f32",
+                 lr=0.01, betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False,
+                 weights=None, device=None, use_graph=True):
+        self.lib = _capi.load_library()          # raises HipLibraryError when the extension is missing
+        if not torch.cuda.is_available():
+            raise _capi.HipLibraryError("no HIP device visible: paule_amd runs on MI355X only (no CPU fallback)")
+        if objective not in _capi.PL_OBJ:
+            raise ValueError("objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'")
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype has to be one of {sorted(DTYPES)}")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError("HipPlanner needs a cuda (HIP) device")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        pred_sd, emb_sd = _state_dict(pred_model), _state_dict(embedder)
+        self.B, self.T, self.Tp = int(batch), int(n_frames), int(n_frames) // 2
+        self.objective, self.dtype = objective, dtype
+        in_p, hid_p, lay_p = _lstm_dims(pred_sd)
+        self.C = in_p
+        self.M = int(pred_sd["post_linear.weight"].shape[0])
+        cfg = _capi.PlConfig()
+        _capi.check(self.lib, self.lib.pl_default_config(C.byref(cfg)), "pl_default_config")
+        cfg.batch, cfg.n_frames, cfg.cp_dim, cfg.mel_dim = self.B, self.T, self.C, self.M
+        cfg.pred_layers, cfg.pred_hidden = lay_p, hid_p
+        if emb_sd is not None:
+            in_e, hid_e, lay_e = _lstm_dims(emb_sd)
+            if in_e != self.M:
+                raise ValueError("embedder input size does not match the predictive model's output size")
+            self.S = int(emb_sd["linear_mapping.weight"].shape[0])
+            cfg.emb_layers, cfg.emb_hidden, cfg.sem_dim = lay_e, hid_e, self.S
+        else:
+            self.S = 0
+            cfg.emb_layers, cfg.emb_hidden = 0, 0
+        cfg.dtype, cfg.objective = DTYPES[dtype], _capi.PL_OBJ[objective]
+        if weights:
+            for k in ("w_mel", "w_sem", "w_vel", "w_jerk", "w_ll"):
+                if k in weights:
+                    setattr(cfg, k, float(weights[k]))
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        cfg.clamp_lo, cfg.clamp_hi = float(clamp[0]), float(clamp[1])
+        cfg.smiling, cfg.device, cfg.use_graph = int(bool(smiling)), dev_index, int(bool(use_graph))
+        self._stream = torch.cuda.current_stream(self.device)
+        cfg.stream = self._stream.cuda_stream
+        self._h = C.c_void_p()
+        _capi.check(self.lib, self.lib.pl_create(C.byref(cfg), C.byref(self._h)), "pl_create")
+        self.has_embedder = emb_sd is not None
+        self.set_weights(pred_sd, emb_sd)
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def _dev(self, a, shape=None):
+        t = torch.as_tensor(a) if not isinstance(a, torch.Tensor) else a
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def _call(self, fn, *args):
+        _capi.check(self.lib, fn(self._h, *args), fn.__name__ if hasattr(fn, "__name__") else "pl call")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.pl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights (re-upload after continued learning, paule/paule.py:1372-1377) ----------------
+    def set_weights(self, pred_model=None, embedder=None):
+        for model_id, sd, lin in ((_capi.PL_MODEL_PRED, _state_dict(pred_model), "post_linear"),
+                                  (_capi.PL_MODEL_EMBED, _state_dict(embedder), "linear_mapping")):
+            if sd is None:
+                continue
+            _, _, n_layers = _lstm_dims(sd)
+            for l in range(n_layers):
+                ts = [self._dev(sd[f"lstm.{k}_l{l}"]) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                self._call(self.lib.pl_set_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
+            w, b = self._dev(sd[f"{lin}.weight"]), self._dev(sd[f"{lin}.bias"])
+            self._call(self.lib.pl_set_linear, model_id, w.data_ptr(), b.data_ptr())
+
+    # ---- state --------------------------------------------------------------------------------
+    def set_targets(self, target_mel, target_semvec=None):
+        tm = self._dev(target_mel, (self.B, self.Tp, self.M))
+        ts = self._dev(target_semvec, (self.B, self.S)) if target_semvec is not None else None
+        self._call(self.lib.pl_set_targets, tm.data_ptr(), ts.data_ptr() if ts is not None else None)
+
+    def set_cp(self, cp):
+        t = self._dev(cp, (self.B, self.T, self.C))
+        self._call(self.lib.pl_set_cp, t.data_ptr())
+
+    def set_past_cp(self, past_cp):
+        if past_cp is None:
+            self._call(self.lib.pl_set_past_cp, None, 0, 0)
+            return
+        t = self._dev(past_cp)
+        per_utt = 1 if t.dim() == 3 else 0
+        if per_utt and t.shape[0] != self.B:
+            raise ValueError("per-utterance past_cp needs shape (B, P, cp_dim)")
+        self._call(self.lib.pl_set_past_cp, t.data_ptr(), int(t.shape[-2]), per_utt)
+
+    def reset_optimizer(self):
+        self._call(self.lib.pl_reset_optimizer)
+
+    # ---- the hot path -------------------------------------------------------------------------
+    def step(self, n_iters=1, *, return_loss=True, return_grad=False):
+        """n inner iterations.  Returns loss_log (n_iters, B, 6) [total, mel, semvec, vel, jerk, local_linear]
+        at the pre-step CP (device tensor, stream-asynchronous) and optionally the last gradient."""
+        loss = torch.empty((n_iters, self.B, _capi.PL_LOSS_COLS), dtype=torch.float32, device=self.device) \
+            if return_loss else None
+        grad = torch.empty((self.B, self.T, self.C), dtype=torch.float32, device=self.device) if return_grad else None
+        self._call(self.lib.pl_step, int(n_iters), loss.data_ptr() if loss is not None else None,
+                   grad.data_ptr() if grad is not None else None)
+        if return_grad:
+            return loss, grad
+        return loss
+
+    def get_cp(self):
+        out = torch.empty((self.B, self.T, self.C), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_get_cp, out.data_ptr())
+        return out
+
+    def get_pred(self, with_semvec=None):
+        if with_semvec is None:
+            with_semvec = self.has_embedder
+        mel = torch.empty((self.B, self.Tp, self.M), dtype=torch.float32, device=self.device)
+        sem = torch.empty((self.B, self.S), dtype=torch.float32, device=self.device) if with_semvec else None
+        self._call(self.lib.pl_get_pred, mel.data_ptr(), sem.data_ptr() if sem is not None else None)
+        return mel, sem
+
+    def embed_mel(self, mel, lens=None):
+        m = self._dev(mel, (self.B, self.Tp, self.M))
+        ln = None
+        if lens is not None:
+            ln = torch.as_tensor([int(x) for x in lens], dtype=torch.int32, device=self.device)
+        out = torch.empty((self.B, self.S), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_embed_mel, m.data_ptr(), ln.data_ptr() if ln is not None else None, out.data_ptr())
+        return out
+
+    # ---- introspection ------------------------------------------------------------------------
+    def debug_read(self, name):
+        n = C.c_int64(0)
+        self._call(self.lib.pl_debug_read, name.encode(), None, 0, C.byref(n))
+        out = torch.empty((n.value,), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_debug_read, name.encode(), out.data_ptr(), n.value, C.byref(n))
+        return out
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.pl_device_bytes(self._h))
+
+    @property
+    def flops_per_iteration(self):
+        return float(self.lib.pl_flops_per_iteration(self._h))
+
+    def synchronize(self):
+        self._stream.synchronize()

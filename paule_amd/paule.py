@@ -1,0 +1,446 @@
+"""``paule.Paule`` API surface for the gradient-planning path, driving the MI355X engine.
+
+Keeps the reference's keyword-only signatures (paule/paule.py:101-107, :391-414), argument
+validation (the ``ValueError``s pinned by tests/test_paule.py:31-62) and the 33-field
+``PlanningResults`` (paule/paule.py:57), and routes the inner loop (paule/paule.py:910-1211) to
+``HipPlanner.step``.  Everything the reference does around the loop with VocalTractLab / librosa
+(synthesis, mel extraction; host code, out of scope here) is injectable:
+
+* ``synthesizer(cp_normalised (T, 30) ndarray) -> (sig, sr)``  -- stands in for
+  ``speak(inv_normalize_cp(cp))`` (paule/paule.py:859, :1097);
+* ``mel_extractor(sig, sr) -> (T', 60) ndarray``               -- stands in for
+  ``normalize_mel_librosa(librosa_melspec(sig, sr))`` (paule/paule.py:861-862, :1102-1103);
+
+when they are ``None`` the produced-* result fields stay ``None`` / empty.  Extensions that the
+reference does not have (it always plans one utterance, paule/paule.py:585-588): ``target_acoustic``
+may be a ``(B, T', 60)`` mel array and ``initial_cp`` a ``(B, T, 30)`` array; B independent
+utterances are then planned together (per-utterance losses).
+"""
+from __future__ import annotations
+
+import random
+import time
+import warnings
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+# Set seed (paule/paule.py:37-39)
+torch.manual_seed(20200905)
+random.seed(20200905)
+
+PlanningResults = namedtuple(
+    "PlanningResults",
+    "planned_cp, initial_cp, initial_sig, initial_sr, initial_prod_mel,initial_pred_mel, target_sig, target_sr, "
+    "target_mel, prod_sig, prod_sr, prod_mel, pred_mel, initial_prod_semvec, initial_pred_semvec, prod_semvec, "
+    "pred_semvec, prod_loss_steps, planned_loss_steps, planned_mel_loss_steps, vel_loss_steps, jerk_loss_steps, "
+    "pred_semvec_loss_steps, prod_semvec_loss_steps, cp_steps, pred_semvec_steps, prod_semvec_steps, grad_steps, "
+    "sig_steps, prod_mel_steps, pred_mel_steps, pred_model_loss, inv_model_loss")
+
+BestSynthesisAcoustic = namedtuple("BestSynthesisAcoustic", "mel_loss, planned_cp, prod_sig, prod_mel, pred_mel")
+BestSynthesisSemantic = namedtuple("BestSynthesisSemantic", "semvec_loss, planned_cp, prod_sig, prod_semvec, pred_semvec")
+
+# paule/paule.py:592-597
+MEL_WEIGHT = 5.0
+VELOCITY_WEIGHT = 80.0
+JERK_WEIGHT = 400.0
+SEMANTIC_WEIGHT = 10.0
+LOCAL_LINEAR_WEIGHT = 100_000
+
+_COL = dict(total=0, mel=1, semvec=2, vel=3, jerk=4, ll=5)
+
+
+def _default_planner_factory(pred_model, embedder, **kw):
+    from .engine import HipPlanner   # imported lazily: raises HipLibraryError if libpaule_hip.so is missing
+    return HipPlanner(pred_model, embedder, **kw)
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def _scalar_or_vec(v):
+    v = np.asarray(v, dtype=np.float64)
+    return float(v[0]) if v.shape[0] == 1 else v.copy()
+
+
+def _rmse_rows(a, b):
+    d = (np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).reshape(a.shape[0], -1)
+    return np.sqrt((d * d).mean(axis=1))
+
+
+class Paule():
+    """State of the Predictive Articulatory speech synthesis Using Lexical Embeddings planner
+    (paule/paule.py:92-318), restricted to what the planning path needs."""
+
+    def __init__(self, *, pred_model=None, pred_optimizer=None, inv_model=None, inv_optimizer=None,
+                 embedder=None, cp_gen_model=None, mel_gen_model=None,
+                 use_somatosensory_feedback=False, cp_tube_model=None, tube_optimizer=None,
+                 tube_mel_model=None, tube_mel_optimizer=None, tube_embedder=None,
+                 continue_data=None, device=torch.device('cuda'), smiling=False,
+                 use_speech_classifier=False, speech_classifier=None,
+                 speech_classifier_optimizer=None,
+                 compute_dtype="f32", synthesizer=None, mel_extractor=None, planner_factory=None,
+                 continue_learning_hook=None):
+        self.device = device
+        self.smiling = smiling
+        if use_somatosensory_feedback and use_speech_classifier:   # paule/paule.py:117-118
+            raise NotImplementedError("at the moment you have to choose either to use `use_somatosenrosry_feedback=True` OR to use `use_speech_classifier=True` or none")
+        if use_somatosensory_feedback:
+            raise NotImplementedError("use_somatosensory_feedback is not on the MI355X planning path (SURVEY.md 8f rank 4)")
+        if use_speech_classifier:
+            raise NotImplementedError("use_speech_classifier is not on the MI355X planning path yet (SURVEY.md 8f rank 1)")
+        self.use_somatosensory_feedback = False
+        self.use_speech_classifier = False
+        if pred_model is None or embedder is None:
+            # the reference loads paule/pretrained_models/*.pt here (paule/paule.py:121-175); that 200 MB download
+            # (paule/util.py:936-955) does not exist offline, so the models have to be handed in.
+            raise FileNotFoundError("pretrained weights are not bundled: pass pred_model= and embedder= "
+                                    "(paule_amd.models.ForwardModel / EmbeddingModel or state dicts)")
+        self.pred_model = pred_model
+        self.embedder = embedder
+        self.inv_model = inv_model
+        self.cp_gen_model = cp_gen_model
+        self.mel_gen_model = mel_gen_model
+        self.pred_optimizer = pred_optimizer
+        self.inv_optimizer = inv_optimizer
+        self.continue_data = continue_data
+        self.compute_dtype = compute_dtype
+        self.synthesizer = synthesizer
+        self.mel_extractor = mel_extractor
+        self.continue_learning_hook = continue_learning_hook
+        self._planner_factory = planner_factory or _default_planner_factory
+        self.best_synthesis_acoustic = None
+        self.best_synthesis_semantic = None
+        self.planner = None
+
+    def plan_iterative(self, *, target_acoustic=None, target_semvecs=None, target_seq_lengths=None, overlap=8, **kwargs):
+        pass   # a stub in the reference too (paule/paule.py:383-388)
+
+    # ------------------------------------------------------------------------------------------
+    def _produce(self, cp_bt):
+        """synthesis checkpoint (host, outside the timed path): CP (B,T,30) -> (sigs, sr, prod_mel (B,T',60)) or None"""
+        if self.synthesizer is None or self.mel_extractor is None:
+            return None
+        sigs, mels, sr = [], [], None
+        for b in range(cp_bt.shape[0]):
+            sig, sr = self.synthesizer(cp_bt[b])
+            sigs.append(sig)
+            mels.append(np.asarray(self.mel_extractor(sig, sr), dtype=np.float64))
+        return sigs, sr, np.stack(mels)
+
+    def plan_resynth(self, *, learning_rate_planning=0.01, learning_rate_learning=0.001,
+                     learning_rate_learning_inv=None,
+                     target_acoustic=None,
+                     target_semvec=None,
+                     target_seq_length=None,
+                     initial_cp=None,
+                     past_cp=None,
+                     initialize_from="acoustic",
+                     objective="acoustic",
+                     n_outer=5, n_inner=24,
+                     continue_learning=True,
+                     continue_learning_inv=False,
+                     continue_learning_tube=False,
+                     add_training_data_pred=False,
+                     add_training_data_inv=False,
+                     n_batches=3, batch_size=8, n_epochs=10,
+                     log_ii=1,
+                     log_semantics=True,
+                     log_gradients=False,
+                     log_signals=False,
+                     log_cps=False,
+                     plot=False,
+                     seed=None,
+                     verbose=True):
+        """plans resynthesis cp trajectories (paule/paule.py:391-1550); see the module docstring for the
+        differences (injectable synthesis, batched targets)."""
+        if seed:
+            torch.manual_seed(seed)
+            random.seed(seed)
+
+        if target_acoustic is None and target_semvec is None:
+            raise ValueError("Either target_acoustic or target_semvec has to be not None.")
+
+        if learning_rate_learning and self.pred_optimizer is not None:
+            for param_group in self.pred_optimizer.param_groups:
+                param_group['lr'] = learning_rate_learning
+        if learning_rate_learning_inv and self.inv_optimizer is not None:
+            for param_group in self.inv_optimizer.param_groups:
+                param_group['lr'] = learning_rate_learning_inv
+
+        if log_ii is None:
+            log_ii = n_inner
+        if log_ii > n_inner:
+            raise ValueError('results can only be logged between first and last planning step')
+
+        # ---- target (paule/paule.py:486-531) ----
+        target_sig = target_sr = None
+        target_mel = None
+        if isinstance(target_acoustic, str) or (target_acoustic is not None and not hasattr(target_acoustic, "shape")
+                                                and len(target_acoustic) == 2):
+            if self.mel_extractor is None:
+                raise NotImplementedError("audio targets need mel_extractor= (librosa/soundfile are host code outside "
+                                          "the planning path); pass a (T', 60) mel array instead")
+            if isinstance(target_acoustic, str):
+                import soundfile as sf   # noqa: deferred, optional
+                target_sig, target_sr = sf.read(target_acoustic)
+                if len(target_sig.shape) == 2:
+                    target_sig = target_sig.mean(axis=1)
+            else:
+                target_sig, target_sr = target_acoustic
+            target_mel = np.asarray(self.mel_extractor(target_sig, target_sr), dtype=np.float64)
+            target_mel = target_mel - target_mel.min()
+            target_mel = target_mel[None]
+            target_seq_length = target_mel.shape[1]
+        elif target_acoustic is not None:
+            target_mel = _np(target_acoustic).astype(np.float64)
+            if target_mel.ndim == 2:
+                target_mel = target_mel[None]
+            if target_mel.ndim != 3:
+                raise ValueError("target_acoustic has to be torch.Tensor at this point")
+            target_seq_length = target_mel.shape[1]
+
+        if target_acoustic is None and (target_seq_length is None or target_semvec is None):
+            raise ValueError("if target_acoustic is None you need to give a target_seq_length and a target_semvec")
+        elif target_acoustic is None:
+            if self.mel_gen_model is None:
+                raise NotImplementedError("semvec-only targets need mel_gen_model= (paule/paule.py:515-521)")
+            noise = torch.randn(1, 1, 100)
+            sv = torch.as_tensor(_np(target_semvec)).view(1, -1)
+            target_mel = _np(self.mel_gen_model(noise, target_seq_length, sv)).astype(np.float64)
+
+        # argument checks the reference reaches only after running the inverse model / building the criterion
+        # (paule/paule.py:566-576, :775-776); they are pure validation, so they are done before any model is needed
+        if initial_cp is None and initialize_from not in ("acoustic", "semvec"):
+            raise ValueError("initialize_from has to be either 'acoustic' or 'semvec'")
+        if initial_cp is not None and initialize_from is not None:
+            raise ValueError('one of initial_cp and initialize_from has to be None')
+        if past_cp is not None and np.asarray(_np(past_cp)).shape[0] % 2 != 0:
+            raise ValueError("past_cp have to be None or the sequence length has to be an even number")
+        if objective not in ("acoustic", "acoustic_semvec", "semvec"):
+            raise ValueError("objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'")
+
+        B = target_mel.shape[0]
+
+        # ---- initial cp (paule/paule.py:550-573) ----
+        if initial_cp is None:
+            if initialize_from == "acoustic":
+                if self.inv_model is None:
+                    raise NotImplementedError("initialize_from='acoustic' needs inv_model= (the inverse model is not on "
+                                              "the planning path); or pass initial_cp= with initialize_from=None")
+                with torch.no_grad():
+                    initial_cp = _np(self.inv_model(torch.as_tensor(target_mel))).clip(min=-1, max=1)
+            elif initialize_from == "semvec":
+                if self.cp_gen_model is None:
+                    raise NotImplementedError("initialize_from='semvec' needs cp_gen_model=")
+                noise = torch.randn(1, 1, 100)
+                sv = torch.as_tensor(_np(target_semvec)).view(1, -1)
+                initial_cp = _np(self.cp_gen_model(noise, 2 * target_seq_length, sv))
+            else:
+                raise ValueError("initialize_from has to be either 'acoustic' or 'semvec'")
+            initial_cp = np.asarray(initial_cp, dtype=np.float64)
+            if initial_cp.ndim == 2:
+                initial_cp = initial_cp[None]
+        else:
+            if initialize_from is not None:
+                raise ValueError('one of initial_cp and initialize_from has to be None')
+            initial_cp = _np(initial_cp).astype(np.float64)
+            if initial_cp.ndim == 2:
+                initial_cp = initial_cp[None]
+            if not initial_cp.shape[1] == (target_mel.shape[1] * 2):
+                raise ValueError(f"initial_cp {initial_cp.shape[1]}, target_mel {target_mel.shape[1] * 2}")
+        if initial_cp.shape[0] != B:
+            raise ValueError(f"initial_cp holds {initial_cp.shape[0]} utterances, target {B}")
+
+        if past_cp is not None:
+            past_cp = _np(past_cp).astype(np.float64)
+            if past_cp.shape[0] % 2 != 0:
+                raise ValueError("past_cp have to be None or the sequence length has to be an even number")
+            initial_cp = np.concatenate((np.broadcast_to(past_cp, (B,) + past_cp.shape), initial_cp), axis=1)
+
+        T = initial_cp.shape[1]
+        Tp = T // 2
+
+        # ---- target semvec (paule/paule.py:533-540) ----
+        emb_for_target = None
+        if target_semvec is None:
+            emb_for_target = target_mel   # embedded below, once the engine exists
+        else:
+            target_semvec = _np(target_semvec).astype(np.float64)
+            target_semvec = target_semvec.reshape(-1, target_semvec.shape[-1])   # .view(1, 300), paule/paule.py:539
+            if target_semvec.shape[0] == 1 and B > 1:
+                target_semvec = np.repeat(target_semvec, B, axis=0)
+
+        # ---- engine ----
+        planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=T, objective=objective,
+                                        dtype=self.compute_dtype, lr=learning_rate_planning, smiling=self.smiling,
+                                        device=self.device)
+        self.planner = planner
+        planner.set_cp(initial_cp)
+        planner.reset_optimizer()                       # a fresh Adam per call (paule/paule.py:797)
+        if past_cp is not None:
+            planner.set_past_cp(past_cp)
+
+        # initial results (paule/paule.py:821-878)
+        initial_pred_mel, initial_pred_semvec = planner.get_pred()
+        initial_pred_mel, initial_pred_semvec = _np(initial_pred_mel), _np(initial_pred_semvec)
+        produced = self._produce(initial_cp)
+        initial_sig = initial_sr = initial_prod_mel = initial_prod_semvec = None
+        if produced is not None:
+            initial_sig, initial_sr, initial_prod_mel = produced
+
+        if past_cp is not None:
+            # the reference prepends the initial PRODUCTION's first P/2 frames (paule/paule.py:868-870); without a
+            # synthesizer the initial prediction stands in for it
+            head = initial_prod_mel if initial_prod_mel is not None else initial_pred_mel
+            target_mel = np.concatenate((head[:, 0:(past_cp.shape[0] // 2), :], target_mel), axis=1)
+        if target_mel.shape[1] != Tp:
+            raise ValueError(f"initial_cp {T}, target_mel {target_mel.shape[1] * 2}")
+
+        if emb_for_target is not None:
+            if emb_for_target.shape[1] == Tp:
+                target_semvec = _np(planner.embed_mel(emb_for_target))
+            else:   # past_cp changed the length: embed the un-prefixed target with its own handle
+                target_semvec = _np(self.embedder(torch.as_tensor(emb_for_target, device=self.device),
+                                                  (torch.tensor(emb_for_target.shape[1]),)))
+        planner.set_targets(target_mel, target_semvec)
+        if initial_prod_mel is not None:
+            initial_prod_semvec = _np(planner.embed_mel(initial_prod_mel))
+
+        self.best_synthesis_acoustic = BestSynthesisAcoustic(np.inf, initial_cp, initial_sig, initial_prod_mel, initial_pred_mel)
+        self.best_synthesis_semantic = BestSynthesisSemantic(np.inf, initial_cp, initial_sig, initial_prod_semvec, initial_pred_semvec)
+
+        # ---- logging variables (paule/paule.py:778-795) ----
+        prod_loss_steps, planned_loss_steps, planned_mel_loss_steps = [], [], []
+        vel_loss_steps, jerk_loss_steps, pred_semvec_loss_steps, prod_semvec_loss_steps = [], [], [], []
+        cp_steps, pred_semvec_steps, prod_semvec_steps, grad_steps, sig_steps = [], [], [], [], []
+        pred_mel_steps, prod_mel_steps, pred_model_loss, inv_model_loss = [], [], [], []
+        sig = sr = prod_mel = None
+        pred_mel = initial_pred_mel
+        squeeze = (lambda a: a[-1]) if B == 1 else (lambda a: a)
+
+        def log_rows(rows, first_ii):
+            if not verbose:
+                return
+            for k, row in enumerate(rows):   # paule/paule.py:964-978
+                print("Iteration %d" % (first_ii + k))
+                print("Planned Loss: ", _scalar_or_vec(row[:, _COL["total"]]))
+                print("Mel Loss: ", _scalar_or_vec(row[:, _COL["mel"]]))
+                print("Vel Loss: ", _scalar_or_vec(row[:, _COL["vel"]]))
+                print("Jerk Loss: ", _scalar_or_vec(row[:, _COL["jerk"]]))
+                print("Local Linear Loss: ", _scalar_or_vec(row[:, _COL["ll"]]))
+                if objective != "acoustic":
+                    print("Semvec Loss: ", _scalar_or_vec(row[:, _COL["semvec"]]))
+
+        def run(n, first_ii):
+            """n plain iterations (no log step inside)"""
+            if n <= 0:
+                return
+            if log_gradients:
+                for k in range(n):
+                    loss, grad = planner.step(1, return_grad=True)
+                    grad_steps.append(grad.detach().clone())
+                    log_rows(_np(loss), first_ii + k)
+            else:
+                log_rows(_np(planner.step(n)), first_ii)
+
+        start_time = time.time()
+        for ii_outer in range(n_outer):                                        # paule/paule.py:894
+            pred_mel_steps_ii, prod_mel_steps_ii, cp_steps_ii = [], [], []
+            pred_semvec_steps_ii, prod_semvec_steps_ii = [], []
+            ii = 0
+            while ii < n_inner:
+                to_log = log_ii - 1 - (ii % log_ii)            # plain iterations before the next log step
+                if ii + to_log >= n_inner:                     # no further log step in this outer iteration
+                    run(n_inner - ii, ii)
+                    break
+                run(to_log, ii)
+                ii += to_log
+                # ---- log step (paule/paule.py:941-962, :1065-1197): losses, CP and predictions at the PRE-step CP ----
+                xx_pre = _np(planner.get_cp())
+                pm, ps = planner.get_pred(with_semvec=(objective != "acoustic" or log_semantics))
+                pred_mel = _np(pm)
+                pred_semvec = _np(ps) if ps is not None else None
+                if log_gradients:
+                    loss, grad = planner.step(1, return_grad=True)
+                    grad_steps.append(grad.detach().clone())
+                else:
+                    loss = planner.step(1)
+                row = _np(loss)[0]
+                log_rows([row], ii)
+                planned_loss_steps.append(_scalar_or_vec(row[:, _COL["total"]]))
+                planned_mel_loss_steps.append(_scalar_or_vec(row[:, _COL["mel"]]))
+                vel_loss_steps.append(_scalar_or_vec(row[:, _COL["vel"]]))
+                jerk_loss_steps.append(_scalar_or_vec(row[:, _COL["jerk"]]))
+                if objective != "acoustic":
+                    pred_semvec_loss_steps.append(_scalar_or_vec(row[:, _COL["semvec"]]))
+                elif log_semantics and pred_semvec is not None:
+                    pred_semvec_loss_steps.append(_scalar_or_vec(SEMANTIC_WEIGHT * _rmse_rows(pred_semvec, target_semvec)))
+                if pred_semvec is not None:
+                    pred_semvec_steps_ii.append(squeeze(pred_semvec))
+                cp_steps_ii.append(squeeze(xx_pre))
+                pred_mel_steps_ii.append(squeeze(pred_mel))
+                produced = self._produce(xx_pre)
+                if produced is not None:
+                    sig, sr, prod_mel = produced
+                    if log_signals:
+                        sig_steps.append(sig if B > 1 else sig[0])
+                    prod_mel_steps_ii.append(squeeze(prod_mel))
+                    prod_loss = MEL_WEIGHT * _rmse_rows(prod_mel, target_mel)
+                    prod_loss_steps.append(_scalar_or_vec(prod_loss))
+                    if verbose:
+                        print("Produced Mel Loss: ", _scalar_or_vec(prod_loss))
+                    new_ac = BestSynthesisAcoustic(float(prod_loss.mean()), xx_pre, sig, prod_mel, pred_mel)
+                    if self.best_synthesis_acoustic.mel_loss > new_ac.mel_loss:
+                        self.best_synthesis_acoustic = new_ac
+                    if objective in ('semvec', 'acoustic_semvec') or log_semantics:
+                        prod_semvec = _np(planner.embed_mel(prod_mel))
+                        prod_semvec_steps_ii.append(squeeze(prod_semvec))
+                        prod_semvec_loss = SEMANTIC_WEIGHT * _rmse_rows(prod_semvec, target_semvec)
+                        prod_semvec_loss_steps.append(_scalar_or_vec(prod_semvec_loss))
+                        if verbose:
+                            print("Produced Semvec Loss: ", _scalar_or_vec(prod_semvec_loss))
+                        new_se = BestSynthesisSemantic(float(prod_semvec_loss.mean()), xx_pre, sig, prod_semvec, pred_semvec)
+                        if self.best_synthesis_semantic.semvec_loss > new_se.semvec_loss:
+                            self.best_synthesis_semantic = new_se
+                ii += 1
+
+            prod_mel_steps.append(prod_mel_steps_ii)
+            if log_cps:
+                cp_steps.append(cp_steps_ii)
+            pred_mel_steps.append(pred_mel_steps_ii)
+            pred_semvec_steps.append(pred_semvec_steps_ii)
+            prod_semvec_steps.append(prod_semvec_steps_ii)
+
+            # execute and continue learning (paule/paule.py:1243-1454): model TRAINING is host/torch work outside the
+            # planning path; a hook may run it, after which the new weights are re-uploaded for the next inner loop.
+            if continue_learning:
+                if self.continue_learning_hook is not None:
+                    losses = self.continue_learning_hook(self, cp_steps_ii, prod_mel_steps_ii, n_batches=n_batches,
+                                                         batch_size=batch_size, n_epochs=n_epochs)
+                    if losses:
+                        pred_model_loss.extend(losses)
+                    planner.set_weights(self.pred_model, None)
+                elif ii_outer == 0:
+                    warnings.warn("continue_learning=True but no continue_learning_hook was given: the predictive model "
+                                  "is kept fixed (model training is outside the MI355X planning path)", stacklevel=2)
+
+        if verbose:
+            print("--- %.2f min ---" % ((time.time() - start_time) / 60))
+
+        # ---- results (paule/paule.py:1456-1550): CP AFTER the last step, predictions recomputed from it ----
+        planned_cp = _np(planner.get_cp())
+        pm, ps = planner.get_pred()
+        pred_mel, pred_semvec = _np(pm), _np(ps)
+        prod_semvec = _np(planner.embed_mel(prod_mel)) if prod_mel is not None else None
+        sq = (lambda a: None if a is None else a[-1]) if B == 1 else (lambda a: a)
+        sqs = (lambda s: None if s is None else s[0]) if B == 1 else (lambda s: s)
+        return PlanningResults(
+            sq(planned_cp), sq(initial_cp), sqs(initial_sig), initial_sr, sq(initial_prod_mel), sq(initial_pred_mel),
+            target_sig, target_sr, sq(target_mel), sqs(sig), sr, sq(prod_mel), sq(pred_mel),
+            sq(initial_prod_semvec), sq(initial_pred_semvec), sq(prod_semvec), sq(pred_semvec),
+            prod_loss_steps, planned_loss_steps, planned_mel_loss_steps, vel_loss_steps, jerk_loss_steps,
+            pred_semvec_loss_steps, prod_semvec_loss_steps, cp_steps, pred_semvec_steps, prod_semvec_steps,
+            grad_steps, sig_steps, prod_mel_steps, pred_mel_steps, pred_model_loss, inv_model_loss)

@@ -1,0 +1,70 @@
+"""Synthetic planning workloads: random-init models of the named architecture,
+random smooth targets and initial CP trajectories.  There is no network for the pretrained weights
+(paule/util.py:936-955) or data, so benchmarks and parity tests use these; timing is data independent.
+
+Model sets:
+  A -- what ``Paule`` instantiates: ForwardModel(L=1, H=720) (paule/paule.py:124) and
+       EmbeddingModel(L=2, H=720) (paule/paule.py:167)                      [primary]
+  B -- the class defaults: ForwardModel(L=4, H=180) (paule/models.py:335-339) and
+       EmbeddingModel(L=1, H=720) (paule/models.py:421-427)                 [secondary, "stacked"]
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+
+SEED = 20200905   # the reference's own module-level seed (paule/paule.py:38)
+
+MODEL_SETS = {
+    "A": dict(pred=dict(num_lstm_layers=1, hidden_size=720), emb=dict(num_lstm_layers=2, hidden_size=720)),
+    "B": dict(pred=dict(num_lstm_layers=4, hidden_size=180), emb=dict(num_lstm_layers=1, hidden_size=720)),
+}
+
+Workload = namedtuple("Workload", "pred_sd emb_sd target_mel target_semvec cp0 batch n_frames")
+
+
+def _lstm_linear_state_dict(in_size, hidden, layers, out_size, lin_name, dtype):
+    """torch default init (U(-1/sqrt(H), 1/sqrt(H))) in the reference's parameter-creation order."""
+    lstm = torch.nn.LSTM(in_size, hidden, num_layers=layers, batch_first=True)
+    lin = torch.nn.Linear(hidden, out_size)
+    sd = {f"lstm.{k}": v.detach().to(dtype) for k, v in lstm.state_dict().items()}
+    sd.update({f"{lin_name}.{k}": v.detach().to(dtype) for k, v in lin.state_dict().items()})
+    return sd
+
+
+def smooth_time(x, k):
+    """Moving average over time (dim 1) with window k, same length, borders averaged over valid samples."""
+    return torch.nn.functional.avg_pool1d(x.permute(0, 2, 1), kernel_size=k, stride=1, padding=k // 2,
+                                          count_include_pad=False).permute(0, 2, 1).contiguous()
+
+
+def make_models(model_set="A", *, pred=None, emb=None, cp_dim=30, mel_dim=60, sem_dim=300, dtype=torch.float64,
+                seed=SEED, with_embedder=True):
+    """State dicts of (ForwardModel, EmbeddingModel) with default torch init under ``seed``."""
+    spec = MODEL_SETS[model_set] if model_set else dict(pred=pred, emb=emb)
+    pspec, espec = dict(spec["pred"]), dict(spec["emb"]) if spec.get("emb") else None
+    with torch.random.fork_rng():
+        torch.manual_seed(seed)
+        pred_sd = _lstm_linear_state_dict(cp_dim, pspec["hidden_size"], pspec["num_lstm_layers"], mel_dim,
+                                          "post_linear", dtype)
+        emb_sd = None
+        if with_embedder and espec:
+            emb_sd = _lstm_linear_state_dict(mel_dim, espec["hidden_size"], espec["num_lstm_layers"], sem_dim,
+                                             "linear_mapping", dtype)
+    return pred_sd, emb_sd
+
+
+def make_workload(batch, n_frames, model_set="A", *, pred=None, emb=None, cp_dim=30, mel_dim=60, sem_dim=300,
+                  dtype=torch.float64, seed=SEED, with_embedder=True):
+    """Models + targets + initial CP, generated on the CPU in this fixed order."""
+    pred_sd, emb_sd = make_models(model_set, pred=pred, emb=emb, cp_dim=cp_dim, mel_dim=mel_dim, sem_dim=sem_dim,
+                                  dtype=dtype, seed=seed, with_embedder=with_embedder)
+    with torch.random.fork_rng():
+        torch.manual_seed(seed + 1)
+        tp = n_frames // 2
+        target_mel = smooth_time(torch.rand(batch, tp, mel_dim, dtype=dtype), 5)
+        target_semvec = 0.1 * torch.randn(batch, sem_dim, dtype=dtype)
+        # smooth start, like the inverse model's output clipped to [-1, 1] (paule/paule.py:555)
+        cp0 = smooth_time(2.0 * torch.rand(batch, n_frames, cp_dim, dtype=dtype) - 1.0, 25)
+    return Workload(pred_sd, emb_sd, target_mel, target_semvec, cp0, batch, n_frames)

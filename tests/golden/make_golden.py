@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE's own code objects.
+
+Runs only in the build container (needs /root/reference); it embeds none of the reference's
+source and is a no-op when the reference is absent.  What is imported from the reference:
+
+* ``paule/models.py`` loaded stand-alone by file path (it depends only on torch / math):
+  ``ForwardModel`` (paule/models.py:326-356) and ``EmbeddingModel`` (:413-448);
+* the pure-torch helpers of ``paule/util.py`` -- ``RMSELoss``, the five-point stencil,
+  ``numeric_derivative``, ``local_linear``, ``get_vel_acc_jerk`` (:564-637) -- and
+  ``velocity_jerk_loss`` of ``paule/paule.py`` (:75-88), extracted by AST (definitions only, so the
+  module-level librosa / soundfile / VocalTractLab side effects never run; those packages are not
+  installed here, which is why ``import paule`` itself fails with an ordinary ModuleNotFoundError).
+
+The ~25 lines of loop glue are nested inside ``plan_resynth`` and cannot be extracted; they are
+restated below, each line citing the reference line it follows.  The fixtures hold inputs and the
+reference's outputs only (float64).
+"""
+from __future__ import annotations
+
+import ast
+import importlib.util
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference/paule/"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from paule_amd import synthetic  # noqa: E402  (workload generator of this repo: inputs only)
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("ref_models", REF + "models.py")
+    ref_models = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_models)
+
+    def extract(path, names):
+        tree = ast.parse(open(path).read())
+        keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+        assert {n.name for n in keep} == set(names), "reference layout changed"
+        return compile(ast.Module(body=keep, type_ignores=[]), path, "exec")
+
+    ns = {"torch": torch, "warnings": warnings}
+    exec(extract(REF + "util.py", ["RMSELoss", "calculate_five_point_stencil_without_padding",
+                                   "numeric_derivative", "local_linear", "get_vel_acc_jerk"]), ns)
+    ns["rmse_loss"] = ns["RMSELoss"](eps=0)          # paule/paule.py:68
+    ns["mse_loss"] = torch.nn.MSELoss()              # paule/paule.py:69
+    exec(extract(REF + "paule.py", ["velocity_jerk_loss"]), ns)
+    return ref_models, ns
+
+
+# loss weights, paule/paule.py:592-597
+MEL_WEIGHT, VELOCITY_WEIGHT, JERK_WEIGHT, SEMANTIC_WEIGHT, LOCAL_LINEAR_WEIGHT = 5.0, 80.0, 400.0, 10.0, 100_000
+
+
+def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, cps):
+    """The plain criterion closures (paule/paule.py:647-662, :705-717, :760-773) on ONE utterance."""
+    rmse_loss, mse_loss = ns["rmse_loss"], ns["mse_loss"]
+    velocity_loss, jerk_loss = ns["velocity_jerk_loss"](cps, loss=mse_loss)
+    ll = ns["local_linear"](cps)
+    local_linear_loss = mse_loss(ll, torch.zeros_like(ll, dtype=ll.dtype))
+    mel_loss = MEL_WEIGHT * rmse_loss(pred_mel, target_mel)          # semvec objective: logged only (:1021)
+    velocity_loss = VELOCITY_WEIGHT * velocity_loss
+    jerk_loss = JERK_WEIGHT * jerk_loss
+    local_linear_loss = LOCAL_LINEAR_WEIGHT * local_linear_loss
+    semvec_loss = torch.zeros((), dtype=cps.dtype)
+    if objective in ("acoustic_semvec", "semvec"):
+        semvec_loss = SEMANTIC_WEIGHT * rmse_loss(pred_semvec, target_semvec)
+    if objective == "acoustic":
+        loss = mel_loss + velocity_loss + jerk_loss + local_linear_loss
+    elif objective == "acoustic_semvec":
+        loss = mel_loss + velocity_loss + jerk_loss + semvec_loss + local_linear_loss
+    else:
+        loss = velocity_loss + jerk_loss + semvec_loss + local_linear_loss
+    return loss, torch.stack([loss, mel_loss, semvec_loss, velocity_loss, jerk_loss, local_linear_loss])
+
+
+def ref_plan_one(ns, pred_model, embedder, objective, cp0, target_mel, target_semvec, n_iters, lr=0.01,
+                 smiling=False, past_cp=None, snapshots=()):
+    """Inner loop for ONE utterance exactly as the reference runs it (batch 1, paule/paule.py:585-588)."""
+    xx_new = cp0.clone().view(1, *cp0.shape).requires_grad_()          # :585-590
+    target_mel = target_mel.view(1, *target_mel.shape)
+    target_semvec = target_semvec.view(1, -1)                           # :539
+    optimizer = torch.optim.Adam([xx_new], lr=lr)                       # :797
+    log, snaps, grads = [], {}, {}
+    for ii in range(n_iters):                                           # :910
+        optimizer.zero_grad()                                           # :911
+        pred_mel = pred_model(xx_new)                                   # :913
+        pred_semvec = None
+        if objective in ("semvec", "acoustic_semvec"):                  # :921-925
+            seq_length = pred_mel.shape[1]
+            embedder = embedder.train()
+            pred_semvec = embedder(pred_mel, (torch.tensor(seq_length),))
+        discrepancy, sub = ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, xx_new)
+        log.append(sub.detach().clone())
+        discrepancy.backward()                                          # :1052
+        if ii + 1 in snapshots:
+            grads[ii + 1] = xx_new.grad.detach().clone()[0]
+        optimizer.step()                                                # :1199
+        with torch.no_grad():                                           # :1201-1211
+            xx_new.data = xx_new.data.clamp(-1.05, 1.05)
+            if smiling:
+                xx_new.data[:, :, 4] = -1.0
+                xx_new.data[:, :, 1] = 1.0
+            if past_cp is not None:
+                xx_new.data[:, 0:past_cp.shape[0], :] = past_cp
+        if ii + 1 in snapshots:
+            snaps[ii + 1] = xx_new.detach().clone()[0]
+    with torch.no_grad():                                               # :1460-1464
+        pred_mel = pred_model(xx_new)
+        pred_semvec = embedder.eval()(pred_mel, (torch.tensor(pred_mel.shape[1]),)) if embedder is not None else None
+    return torch.stack(log), snaps, grads, pred_mel[0], None if pred_semvec is None else pred_semvec[0]
+
+
+def build_ref_models(ref_models, pspec, espec, pred_sd, emb_sd):
+    pm = ref_models.ForwardModel(**pspec).double()
+    pm.load_state_dict(pred_sd)
+    em = ref_models.EmbeddingModel(**espec).double()
+    em.load_state_dict(emb_sd)
+    for m in (pm, em):
+        for p in m.parameters():
+            p.requires_grad_(True)   # the reference leaves parameter grads on (unused by planning)
+    return pm, em
+
+
+def npz_state(prefix, sd):
+    return {f"{prefix}/{k}": v.numpy() for k, v in sd.items()}
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present: nothing to do")
+        return 0
+    torch.set_num_threads(4)
+    ref_models, ns = load_reference()
+    SNAP = (1, 5, 20)
+
+    # ---- fixture 1: small stacked models, weights stored -------------------------------------
+    pspec = dict(num_lstm_layers=2, hidden_size=24)
+    espec = dict(num_lstm_layers=2, hidden_size=20)
+    B, T = 3, 40
+    wl = synthetic.make_workload(B, T, None, pred=pspec, emb=espec)
+    pm, em = build_ref_models(ref_models, pspec, espec, wl.pred_sd, wl.emb_sd)
+    out = dict(B=B, T=T, target_mel=wl.target_mel.numpy(), target_semvec=wl.target_semvec.numpy(), cp0=wl.cp0.numpy())
+    out.update(npz_state("pred", wl.pred_sd))
+    out.update(npz_state("emb", wl.emb_sd))
+    with torch.no_grad():   # level (i): model outputs
+        mel0 = pm(wl.cp0)
+        out["fwd/pred_mel"] = mel0.numpy()
+        out["fwd/pred_semvec"] = torch.stack([em(mel0[b:b + 1], (torch.tensor(mel0.shape[1]),))[0] for b in range(B)]).numpy()
+        out["fwd/pred_mel_oddT"] = pm(wl.cp0[:, :39]).numpy()
+        out["fwd/embed_lens"] = np.array([20, 13, 7])
+        out["fwd/embed_semvec_lens"] = em(wl.target_mel, [torch.tensor(20), torch.tensor(13), torch.tensor(7)]).numpy()
+    past = wl.cp0[0, :6].clone() * 0.5
+    cases = {"acoustic": dict(objective="acoustic"), "acoustic_semvec": dict(objective="acoustic_semvec"),
+             "semvec": dict(objective="semvec"), "smiling": dict(objective="acoustic_semvec", smiling=True),
+             "past_cp": dict(objective="acoustic", past_cp=past)}
+    out["past_cp"] = past.numpy()
+    for name, kw in cases.items():   # level (iv): trajectories, one reference run per utterance
+        logs, cps, grads = [], {k: [] for k in SNAP}, {k: [] for k in SNAP}
+        fm, fs = [], []
+        for b in range(B):
+            log, snaps, gr, fmel, fsem = ref_plan_one(ns, pm, em, kw["objective"], wl.cp0[b], wl.target_mel[b],
+                                                      wl.target_semvec[b], 20, smiling=kw.get("smiling", False),
+                                                      past_cp=kw.get("past_cp"), snapshots=SNAP)
+            logs.append(log)
+            fm.append(fmel)
+            fs.append(fsem)
+            for k in SNAP:
+                cps[k].append(snaps[k])
+                grads[k].append(gr[k])
+        out[f"{name}/loss_log"] = torch.stack(logs, dim=1).numpy()            # (20, B, 6)
+        out[f"{name}/final_pred_mel"] = torch.stack(fm).numpy()
+        out[f"{name}/final_pred_semvec"] = torch.stack(fs).numpy()
+        for k in SNAP:
+            out[f"{name}/cp_after_{k}"] = torch.stack(cps[k]).numpy()
+            out[f"{name}/grad_at_{k}"] = torch.stack(grads[k]).numpy()
+    # level (ii): each loss term and its gradient in isolation (utterance 0)
+    x = wl.cp0[0:1].clone().requires_grad_()
+    vel, jerk = ns["velocity_jerk_loss"](x, loss=ns["mse_loss"])
+    ll = ns["local_linear"](x)
+    lll = ns["mse_loss"](ll, torch.zeros_like(ll))
+    for nm, val in (("vel", vel), ("jerk", jerk), ("ll", lll)):
+        g, = torch.autograd.grad(val, x, retain_graph=True)
+        out[f"terms/{nm}"] = val.detach().numpy()
+        out[f"terms/{nm}_grad"] = g[0].numpy()
+    mel = pm(x)
+    ml = ns["rmse_loss"](mel, wl.target_mel[0:1])
+    g, = torch.autograd.grad(ml, x, retain_graph=True)
+    out["terms/mel"], out["terms/mel_grad"] = ml.detach().numpy(), g[0].numpy()
+    sem = em(mel, (torch.tensor(mel.shape[1]),))
+    sl = ns["rmse_loss"](sem, wl.target_semvec[0:1])
+    g, = torch.autograd.grad(sl, x)
+    out["terms/sem"], out["terms/sem_grad"] = sl.detach().numpy(), g[0].numpy()
+    # level (iii): one Adam + clamp step from given (x, g) with non-trivial state (3 steps on a fixed gradient field)
+    xa = wl.cp0[0:1].clone().requires_grad_()
+    opt = torch.optim.Adam([xa], lr=0.01)
+    gfield = torch.sin(torch.arange(xa.numel(), dtype=torch.float64).view_as(xa) * 0.37) * 3.0
+    for k in range(3):
+        opt.zero_grad()
+        xa.grad = (gfield * (k + 1)).clone()
+        opt.step()
+        with torch.no_grad():
+            xa.data = xa.data.clamp(-1.05, 1.05)
+    out["adam/gfield"], out["adam/x_after_3"] = gfield[0].numpy(), xa.detach()[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "small_stacked.npz"), **out)
+    print("small_stacked.npz:", len(out), "arrays")
+
+    # ---- fixture 2: the Paule default models (set A, H = 720), weights regenerated from the seed --
+    B, T = 2, 32
+    wl = synthetic.make_workload(B, T, "A")
+    pspec, espec = synthetic.MODEL_SETS["A"]["pred"], synthetic.MODEL_SETS["A"]["emb"]
+    # the reference's own constructors under the same seed must give the same weights (default torch init)
+    torch.manual_seed(synthetic.SEED)
+    pm_seed = ref_models.ForwardModel(**pspec).double()
+    em_seed = ref_models.EmbeddingModel(**espec).double()
+    for k, v in pm_seed.state_dict().items():
+        assert torch.equal(v, wl.pred_sd[k]), k
+    for k, v in em_seed.state_dict().items():
+        assert torch.equal(v, wl.emb_sd[k]), k
+    pm, em = build_ref_models(ref_models, pspec, espec, wl.pred_sd, wl.emb_sd)
+    out = dict(B=B, T=T, seed=synthetic.SEED, target_mel=wl.target_mel.numpy(), target_semvec=wl.target_semvec.numpy(),
+               cp0=wl.cp0.numpy())
+    out["weights_checksum"] = np.array([float(sum(v.double().abs().sum() for v in wl.pred_sd.values())),
+                                        float(sum(v.double().abs().sum() for v in wl.emb_sd.values()))])
+    with torch.no_grad():
+        mel0 = pm(wl.cp0)
+        out["fwd/pred_mel"] = mel0.numpy()
+        out["fwd/pred_semvec"] = torch.stack([em(mel0[b:b + 1], (torch.tensor(mel0.shape[1]),))[0] for b in range(B)]).numpy()
+    for name in ("acoustic", "acoustic_semvec"):
+        logs, cps, grads = [], {k: [] for k in SNAP}, {k: [] for k in SNAP}
+        for b in range(B):
+            log, snaps, gr, _, _ = ref_plan_one(ns, pm, em, name, wl.cp0[b], wl.target_mel[b], wl.target_semvec[b], 20,
+                                                snapshots=SNAP)
+            logs.append(log)
+            for k in SNAP:
+                cps[k].append(snaps[k])
+                grads[k].append(gr[k])
+        out[f"{name}/loss_log"] = torch.stack(logs, dim=1).numpy()
+        for k in SNAP:
+            out[f"{name}/cp_after_{k}"] = torch.stack(cps[k]).numpy()
+            out[f"{name}/grad_at_{k}"] = torch.stack(grads[k]).numpy()
+    np.savez_compressed(os.path.join(HERE, "set_a_h720.npz"), **out)
+    print("set_a_h720.npz:", len(out), "arrays")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,64 @@
+"""Adapter giving the CPU oracle the HipPlanner interface -- TEST INFRASTRUCTURE (host-logic tests on CPU,
+gloo multi-process tests).  The product never imports this."""
+import numpy as np
+import torch
+
+from oracle import planner as op
+
+
+class OracleEngine:
+    def __init__(self, pred_model, embedder=None, *, batch, n_frames, objective="acoustic", dtype="f32", lr=0.01,
+                 betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False, weights=None, device=None,
+                 use_graph=True):
+        sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
+        self.pred_sd, self.emb_sd = sd(pred_model), sd(embedder) if embedder is not None else None
+        self.B, self.T, self.Tp = batch, n_frames, n_frames // 2
+        self.kw = dict(objective=objective, lr=lr, betas=betas, eps=eps, clamp=clamp, smiling=smiling)
+        self.has_embedder = self.emb_sd is not None
+        self._build()
+
+    def _build(self):
+        pm = op.forward_model_from_state_dict(self.pred_sd)
+        em = op.embedding_model_from_state_dict(self.emb_sd) if self.emb_sd is not None else None
+        old = getattr(self, "p", None)
+        self.p = op.OraclePlanner(pm, em, **self.kw)
+        if old is not None:
+            self.p.xx, self.p.optimizer = old.xx, old.optimizer
+            self.p.target_mel, self.p.target_semvec, self.p.past_cp = old.target_mel, old.target_semvec, old.past_cp
+
+    def set_weights(self, pred_model=None, embedder=None):
+        sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
+        if pred_model is not None:
+            self.pred_sd = sd(pred_model)
+        if embedder is not None:
+            self.emb_sd = sd(embedder)
+        self._build()
+
+    def set_targets(self, target_mel, target_semvec=None):
+        self.p.set_targets(np.asarray(target_mel), None if target_semvec is None else np.asarray(target_semvec))
+
+    def set_cp(self, cp):
+        self.p.set_cp(np.asarray(cp))
+
+    def set_past_cp(self, past):
+        self.p.set_past_cp(past)
+
+    def reset_optimizer(self):
+        self.p.reset_optimizer()
+
+    def step(self, n_iters=1, *, return_loss=True, return_grad=False):
+        log = self.p.step(n_iters)
+        return (log, self.p.last_grad) if return_grad else log
+
+    def get_cp(self):
+        return self.p.get_cp()
+
+    def get_pred(self, with_semvec=None):
+        mel, sem = self.p.get_pred()
+        return mel, (sem if with_semvec in (None, True) else None)
+
+    def embed_mel(self, mel, lens=None):
+        mel = torch.as_tensor(np.asarray(mel)).to(self.p.dtype)
+        lens = [torch.tensor(mel.shape[1])] * mel.shape[0] if lens is None else [torch.tensor(int(l)) for l in lens]
+        with torch.no_grad():
+            return self.p.embedder(mel, lens)
