@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the planning hot path: python bench.py --gpus N --steps K --warmup W
+
+One "step" = one inner planning iteration (forward, criterion, backward-data, Adam + projection;
+paule/paule.py:910-1211 without the log-step block) over the whole per-GPU batch, on synthetic
+inputs already resident in HBM.  Default workload = the configuration BASELINE.json's metric is quoted
+on (cfg3): B = 256 utterances x 300 CP frames per GPU, objective acoustic_semvec, model set A
+(ForwardModel L1/H720 + EmbeddingModel L2/H720), bf16 GEMMs.  N > 1: the batch dimension is sharded,
+one process per GPU, no collective inside the loop; one RCCL all_gather of the final CP trajectories
+afterwards (timed separately).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (batch per GPU, frames, objective, dtype, model set)
+    "cfg2": dict(batch=64, frames=300, objective="acoustic", dtype="f32", model_set="A"),
+    "cfg3": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+    "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
+    "cfg3_setB": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="B"),
+    "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+}
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md chip-level parameters
+
+
+def cpu_baseline(wl_args, objective, seconds_budget=25.0):
+    """The CPU oracle (torch nn.LSTM + autograd + Adam: the operators the reference executes) on a bounded sample
+    of the same workload, float32, all host cores.  Baseline, not target."""
+    import torch
+    from oracle import planner as op
+    from paule_amd import synthetic
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    sample_b = 16
+    wl = synthetic.make_workload(sample_b, wl_args["frames"], wl_args["model_set"])
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, torch.float32),
+                           op.embedding_model_from_state_dict(wl.emb_sd, torch.float32), objective=objective,
+                           dtype=torch.float32)
+    orc.set_targets(wl.target_mel, wl.target_semvec)
+    orc.set_cp(wl.cp0)
+    orc.step(1)   # warm-up
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 or (time.perf_counter() - t0 < seconds_budget and iters < 50):
+        orc.step(1)
+        iters += 1
+    dt = time.perf_counter() - t0
+    utt_it_s = sample_b * iters / dt
+    return dict(value=utt_it_s / wl_args["batch"], unit=f"planning iters/sec at batch={wl_args['batch']} (extrapolated from the sample)",
+                utt_iters_per_s=utt_it_s, cores=torch.get_num_threads(), kind="port",
+                sample=f"{sample_b} utterances x {iters} iterations, T={wl_args['frames']}, {objective}, model set "
+                       f"{wl_args['model_set']}, float32, torch CPU oracle ({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+    import torch.distributed as dist
+    from paule_amd import synthetic
+    from paule_amd.engine import HipPlanner
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    B, T = cfg["batch"], cfg["frames"]
+    # same random-init weights on every rank (same seed), different utterances per rank (weak scaling)
+    wl = synthetic.make_workload(B, T, cfg["model_set"], seed=synthetic.SEED)
+    if rank:
+        wl_r = synthetic.make_workload(B, T, cfg["model_set"], seed=synthetic.SEED + 1000 * rank)
+        wl = wl._replace(target_mel=wl_r.target_mel, target_semvec=wl_r.target_semvec, cp0=wl_r.cp0)
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective=cfg["objective"], dtype=cfg["dtype"],
+                     device=device, use_graph=not args.no_graph)
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if args.warmup > 0:
+        eng.step(args.warmup, return_loss=False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = eng.step(args.steps)                 # EXACTLY K steps
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # the single collective of the path: gather the final CP trajectories (outside the timed loop)
+    gather_ms = None
+    cp = eng.get_cp()
+    if world > 1:
+        outs = [torch.empty_like(cp) for _ in range(world)]
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        dist.all_gather(outs, cp)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+    finite = bool(torch.isfinite(loss).all().item() and torch.isfinite(cp).all().item())
+
+    if rank == 0:
+        it_s = world * args.steps / elapsed
+        flops_it = eng.flops_per_iteration
+        # dominant kernel: the LSTM backward step (one launch per time step per layer); hipEvents on the engine stream
+        roof = {}
+        for name in ("bwd", "fwd"):
+            ms, fl = eng.bench_kernel(name, "pred", reps=min(298, T - 2) * 2)
+            roof[name] = (ms, fl)
+        ms, fl = roof["bwd"]
+        achieved = fl / (ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[cfg["dtype"]]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC pass (rocprofv3 --pmc), see profiles/README.md
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.config, {}).get("lstm_bwd_step_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "planning iters/sec, batch=256 x 300-frame CP trajs" if args.config.startswith("cfg3") else
+                      f"planning iters/sec, batch={B} x {T}-frame CP trajs",
+            "value": it_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic (random-init weights, random smooth targets)",
+            "config": {"workload": f"{args.config}: {B} utterances/GPU x {T} CP frames, objective {cfg['objective']}, "
+                                   f"model set {cfg['model_set']}", "objective": cfg["objective"],
+                       "batch_per_gpu": B, "global_batch": B * world, "n_frames": T, "model_set": cfg["model_set"],
+                       "parallelism": f"batch-sharded x{world}, no collective in the loop", "hip_graph": not args.no_graph},
+            "utt_iters_per_s": it_s * B,
+            "algorithmic_gflop_per_iter": flops_it / 1e9,
+            "whole_iteration_mfma_frac": (flops_it * it_s / world) / (peak * 1e12),
+            "finite": finite, "final_loss_mean": float(loss[-1, :, 0].mean().item()),
+            "device_bytes": eng.device_bytes,
+            "roofline": {"bound": "mfma", "kernel": "lstm_bwd_step_kernel", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "avg_launch_us": ms * 1e3, "flops_per_launch": fl,
+                         "fwd_step_avg_launch_us": roof["fwd"][0] * 1e3,
+                         "fwd_step_achieved": roof["fwd"][1] / (roof["fwd"][0] * 1e-3) / 1e12},
+        }
+        if gather_ms is not None:
+            out["final_cp_all_gather_ms"] = gather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, cfg["objective"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

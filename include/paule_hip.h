@@ -122,6 +122,14 @@ int pl_embed_mel(pl_handle *h, const float *mel, const int32_t *lens, float *sem
  * Returns the element count through *n_out; out may be NULL to query the size only. */
 int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems, int64_t *n_out);
 
+/* Measurement aid for bench.py's roofline line: launches ONE kernel of the hot path `reps` times back to back
+ * on the handle's stream with real operands (cycling over the time steps of layer 0 of `model_id`), bracketed
+ * by hipEvents on that stream, and returns the average launch-to-launch time (ms, inter-launch gap included)
+ * and the algorithmic FLOPs of one launch (2 * B * 4H * H).  Clobbers only scratch that every pl_step rebuilds. */
+enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1 };
+int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg_ms_out /* host */,
+                    double *flops_per_launch_out /* host */);
+
 /* Bytes of device memory held by the handle. */
 int64_t pl_device_bytes(const pl_handle *h);
 /* Algorithmic FLOPs (forward + backward-data GEMMs, 2 flops / MAC) of one inner iteration at this handle's shapes. */

@@ -22,7 +22,7 @@ PL_LOSS_COLS = 6
 EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
     "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
-    "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_device_bytes", "pl_flops_per_iteration",
+    "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_last_error", "pl_version",
 )
 
@@ -80,13 +80,14 @@ def load_library(path: str | None = None):
     lib.pl_get_pred.argtypes = [vp, fp, fp]
     lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
     lib.pl_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_int64, C.POINTER(C.c_int64)]
+    lib.pl_bench_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     lib.pl_device_bytes.restype = C.c_int64
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double
     lib.pl_flops_per_iteration.argtypes = [vp]
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
-                 "pl_get_pred", "pl_embed_mel", "pl_debug_read"):
+                 "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib

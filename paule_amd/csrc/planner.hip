@@ -623,6 +623,54 @@ int pl_embed_mel(pl_handle* h, const float* mel, const int32_t* lens, float* sem
     return check_launch();
 }
 
+int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg_ms_out, double* flops_per_launch_out) {
+    if (!h || !avg_ms_out || reps < 1) return fail(PL_ERR_INVALID, "pl_bench_kernel: bad argument");
+    if (kernel != PL_KERNEL_LSTM_FWD_STEP && kernel != PL_KERNEL_LSTM_BWD_STEP) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
+    Model& md = model_id == PL_MODEL_EMBED ? h->emb : h->pred;
+    if (md.L == 0 || !md.ready()) return fail(PL_ERR_STATE, "pl_bench_kernel: model weights are not set");
+    DeviceGuard guard(h->cfg.device);
+    LstmLayer& ly = md.layers[0];
+    const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
+    const size_t a = h->act;
+    hipEvent_t e0, e1;
+    PL_HIP(hipEventCreate(&e0));
+    PL_HIP(hipEventCreate(&e1));
+    PL_HIP(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) {
+        const int t = 1 + i % (Tl - 2);   // interior steps: every operand present
+        LstmStepArgs s{};
+        s.Bp = Bp;
+        s.Hp = Hp;
+        s.G_t = off(ly.G, (size_t)t * Bp * 4 * Hp, a);
+        s.c_stash_t = off(ly.c, (size_t)t * Bp * Hp, a);
+        if (kernel == PL_KERNEL_LSTM_FWD_STEP) {
+            s.W = ly.Whh;
+            s.h_prev = off(ly.h, (size_t)(t - 1) * Bp * Hp, a);
+            s.h_out = off(ly.h, (size_t)t * Bp * Hp, a);
+            s.c_in = h->c_run[(t - 1) & 1];
+            s.c_out = h->c_run[t & 1];
+            launch_lstm_fwd_step(h->stream, h->dt, s);
+        } else {
+            s.W = ly.WhhT;
+            s.G_next = off(ly.G, (size_t)(t + 1) * Bp * 4 * Hp, a);
+            s.c_in = h->dc_run[(t + 1) & 1];
+            s.c_out = h->dc_run[t & 1];
+            s.c_stash_prev = off(ly.c, (size_t)(t - 1) * Bp * Hp, a);
+            s.dh_ext = off(md.dh_ext, (size_t)t * Bp * Hp, a);
+            launch_lstm_bwd_step(h->stream, h->dt, s);
+        }
+    }
+    PL_HIP(hipEventRecord(e1, h->stream));
+    PL_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms_out = ms / reps;
+    if (flops_per_launch_out) *flops_per_launch_out = 2.0 * h->B * 4.0 * md.H * md.H;
+    return check_launch();
+}
+
 int64_t pl_device_bytes(const pl_handle* h) { return h ? (int64_t)h->bytes : 0; }
 
 double pl_flops_per_iteration(const pl_handle* h) {

@@ -188,6 +188,14 @@ class HipPlanner:
         self._call(self.lib.pl_debug_read, name.encode(), out.data_ptr(), n.value, C.byref(n))
         return out
 
+    def bench_kernel(self, kernel="bwd", model="pred", reps=300):
+        """(avg ms per launch, algorithmic FLOPs per launch) of one LSTM step kernel, timed with hipEvents on the
+        engine's stream (see pl_bench_kernel)."""
+        ms, fl = C.c_float(0), C.c_double(0)
+        self._call(self.lib.pl_bench_kernel, 0 if kernel == "fwd" else 1,
+                   _capi.PL_MODEL_PRED if model == "pred" else _capi.PL_MODEL_EMBED, int(reps), C.byref(ms), C.byref(fl))
+        return ms.value, fl.value
+
     @property
     def device_bytes(self):
         return int(self.lib.pl_device_bytes(self._h))

@@ -1,0 +1,234 @@
+"""HIP path (through the C-ABI) against the CPU oracle and the reference-generated fixtures.  GPU only.
+
+Tolerances (written here): f32 engine vs float64 oracle over 20 iterations:
+  CP atol 1e-5, loss curve rtol 1e-5, forward outputs atol 2e-5;
+bf16 engine: loss curve rtol 2e-2, per-term gradient cosine >= 0.999, CP atol 2 * lr * n_iters * 1 %... stated below.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import state_dict_from
+from oracle import manual as om
+from oracle import planner as op
+from paule_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+CP_ATOL_F32, LOSS_RTOL_F32, FWD_ATOL_F32 = 1e-5, 1e-5, 2e-5
+LOSS_RTOL_BF16, COS_BF16 = 2e-2, 0.999
+CASES = {"acoustic": dict(objective="acoustic"), "acoustic_semvec": dict(objective="acoustic_semvec"),
+         "semvec": dict(objective="semvec"), "smiling": dict(objective="acoustic_semvec", smiling=True),
+         "past_cp": dict(objective="acoustic")}
+
+
+@pytest.fixture(scope="module")
+def HipPlanner():
+    from paule_amd.engine import HipPlanner
+    return HipPlanner
+
+
+def _n(t):
+    return t.detach().cpu().double().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
+
+
+def _cos(a, b):
+    a, b = _n(a).ravel(), _n(b).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def _engine(HipPlanner, g, name, dtype="f32", **extra):
+    kw = dict(CASES[name])
+    eng = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, "emb"), batch=int(g["B"]), n_frames=int(g["T"]),
+                     dtype=dtype, **kw, **extra)
+    eng.set_targets(g["target_mel"], g["target_semvec"])
+    eng.set_cp(g["cp0"])
+    if name == "past_cp":
+        eng.set_past_cp(g["past_cp"])
+    return eng
+
+
+def test_forward_matches_reference_fixture(HipPlanner, golden_small):
+    g = golden_small
+    eng = _engine(HipPlanner, g, "acoustic_semvec")
+    mel, sem = eng.get_pred()
+    np.testing.assert_allclose(_n(mel), g["fwd/pred_mel"], atol=FWD_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(_n(sem), g["fwd/pred_semvec"], atol=FWD_ATOL_F32, rtol=0)
+    sem_l = eng.embed_mel(g["target_mel"], lens=g["fwd/embed_lens"])
+    np.testing.assert_allclose(_n(sem_l), g["fwd/embed_semvec_lens"], atol=FWD_ATOL_F32, rtol=0)
+
+
+def test_forward_stash_matches_manual(HipPlanner, golden_small):
+    """gate stash / h / c of every layer against the explicit numpy forward (localises kernel bugs)."""
+    g = golden_small
+    eng = _engine(HipPlanner, g, "acoustic_semvec")
+    eng.get_pred()
+    B, T = int(g["B"]), int(g["T"])
+    mm = om.ManualModels(state_dict_from(g, "pred"), state_dict_from(g, "emb"))
+    mel, st_p = mm.pred_forward(g["cp0"])
+    _, st_e = mm.emb_forward(mel)
+    Bp = 16
+    for tag, stashes, Tl in (("pred", st_p, T), ("emb", st_e, T // 2)):
+        for l, st in enumerate(stashes):
+            H = st["c"].shape[2]
+            Hp = (H + 31) // 32 * 32
+            c = _n(eng.debug_read(f"{tag}.c{l}")).reshape(Tl, Bp, Hp)[:, :B, :H].transpose(1, 0, 2)
+            np.testing.assert_allclose(c, st["c"], atol=2e-5, rtol=0, err_msg=f"{tag}.c{l}")
+            G = _n(eng.debug_read(f"{tag}.G{l}")).reshape(Tl, Bp, 4, Hp)[:, :B, :, :H].transpose(1, 0, 2, 3)
+            for gi, k in enumerate("ifgo"):
+                np.testing.assert_allclose(G[:, :, gi], st[k], atol=2e-5, rtol=0, err_msg=f"{tag}.G{l}.{k}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_trajectory_f32_vs_reference_fixture(HipPlanner, golden_small, name, use_graph):
+    g = golden_small
+    eng = _engine(HipPlanner, g, name, use_graph=use_graph)
+    logs, done = [], 0
+    for k in (1, 5, 20):
+        loss, grad = eng.step(k - done, return_grad=True)
+        logs.append(_n(loss))
+        done = k
+        np.testing.assert_allclose(_n(eng.get_cp()), g[f"{name}/cp_after_{k}"], atol=CP_ATOL_F32, rtol=0,
+                                   err_msg=f"cp after {k}")
+        ref_g = g[f"{name}/grad_at_{k}"]
+        np.testing.assert_allclose(_n(grad), ref_g, atol=1e-5 * max(1.0, np.abs(ref_g).max()), rtol=0,
+                                   err_msg=f"grad at {k}")
+    np.testing.assert_allclose(np.concatenate(logs), g[f"{name}/loss_log"], rtol=LOSS_RTOL_F32, atol=1e-7)
+    mel, sem = eng.get_pred()
+    np.testing.assert_allclose(_n(mel), g[f"{name}/final_pred_mel"], atol=FWD_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(_n(sem), g[f"{name}/final_pred_semvec"], atol=FWD_ATOL_F32, rtol=0)
+
+
+def test_gradient_terms_in_isolation_f32(HipPlanner, golden_small):
+    """Each loss term's gradient alone (the 1e5-weighted local-linear term otherwise hides the model gradients)."""
+    g = golden_small
+    for term, key, obj in (("w_mel", "terms/mel_grad", "acoustic"), ("w_sem", "terms/sem_grad", "semvec"),
+                           ("w_vel", "terms/vel_grad", "acoustic"), ("w_jerk", "terms/jerk_grad", "acoustic"),
+                           ("w_ll", "terms/ll_grad", "acoustic")):
+        w = dict(w_mel=0.0, w_sem=0.0, w_vel=0.0, w_jerk=0.0, w_ll=0.0)
+        w[term] = 1.0
+        eng = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, "emb"), batch=int(g["B"]), n_frames=int(g["T"]),
+                         objective=obj, weights=w)
+        eng.set_targets(g["target_mel"], g["target_semvec"])
+        eng.set_cp(g["cp0"])
+        _, grad = eng.step(1, return_grad=True)
+        ref = g[key]
+        got = _n(grad)[0]
+        assert _cos(got, ref) > 1 - 1e-9, term
+        np.testing.assert_allclose(got, ref, atol=2e-5 * np.abs(ref).max(), rtol=0, err_msg=term)
+
+
+@pytest.mark.parametrize("name", ["acoustic", "acoustic_semvec"])
+def test_trajectory_f32_set_a(HipPlanner, golden_set_a, name):
+    """Paule's default architecture (ForwardModel L1/H720, EmbeddingModel L2/H720) against the reference fixture."""
+    g = golden_set_a
+    wl = synthetic.make_workload(int(g["B"]), int(g["T"]), "A")
+    chk = np.array([float(sum(v.double().abs().sum() for v in wl.pred_sd.values())),
+                    float(sum(v.double().abs().sum() for v in wl.emb_sd.values()))])
+    if not np.allclose(chk, g["weights_checksum"], rtol=1e-13):
+        pytest.skip("torch RNG stream differs from the one the fixture was generated with")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=int(g["B"]), n_frames=int(g["T"]), objective=name)
+    eng.set_targets(g["target_mel"], g["target_semvec"])
+    eng.set_cp(g["cp0"])
+    mel, sem = eng.get_pred()
+    np.testing.assert_allclose(_n(mel), g["fwd/pred_mel"], atol=FWD_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(_n(sem), g["fwd/pred_semvec"], atol=FWD_ATOL_F32, rtol=0)
+    loss = eng.step(20)
+    np.testing.assert_allclose(_n(loss), g[f"{name}/loss_log"], rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(_n(eng.get_cp()), g[f"{name}/cp_after_20"], atol=CP_ATOL_F32, rtol=0)
+
+
+@pytest.mark.parametrize("shape", [dict(B=1, T=46, set="B"), dict(B=19, T=33, set="B"), dict(B=5, T=64, set="A")])
+def test_ragged_shapes_vs_oracle_f32(HipPlanner, shape):
+    """B = 1 (the reference's only case), batches that are not a multiple of the tile, odd T (last frame dropped),
+    the stacked class-default models (set B: L = 4, H = 180 -> padded hidden size)."""
+    wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=shape["B"], n_frames=shape["T"], objective="acoustic_semvec")
+    for pl in (orc, eng):
+        pl.set_targets(wl.target_mel, wl.target_semvec)
+        pl.set_cp(wl.cp0)
+    lo, lh = _n(orc.step(8)), _n(eng.step(8))
+    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(_n(eng.get_cp()), _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+
+
+def test_optimizer_state_persists_and_resets(HipPlanner, golden_small):
+    """Adam state continues across pl_step calls (= outer iterations, paule/paule.py:797) and resets on request."""
+    g = golden_small
+    a = _engine(HipPlanner, g, "acoustic")
+    a.step(20)
+    b = _engine(HipPlanner, g, "acoustic")
+    for _ in range(4):
+        b.step(5)
+    np.testing.assert_array_equal(_n(a.get_cp()), _n(b.get_cp()))
+    b.set_cp(g["cp0"])
+    b.reset_optimizer()
+    b.step(20)
+    np.testing.assert_array_equal(_n(a.get_cp()), _n(b.get_cp()))
+
+
+def test_weight_reupload(HipPlanner, golden_small):
+    g = golden_small
+    eng = _engine(HipPlanner, g, "acoustic")
+    mel0, _ = eng.get_pred(with_semvec=False)
+    sd = {k: v * 0.5 for k, v in state_dict_from(g, "pred").items()}
+    eng.set_weights(pred_model=sd)
+    mel1, _ = eng.get_pred(with_semvec=False)
+    ref = op.forward_model_from_state_dict(sd)(torch.from_numpy(g["cp0"]))
+    np.testing.assert_allclose(_n(mel1), _n(ref), atol=FWD_ATOL_F32, rtol=0)
+    assert np.abs(_n(mel0) - _n(mel1)).max() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["acoustic", "acoustic_semvec"])
+def test_bf16_against_oracle(HipPlanner, golden_small, name):
+    g = golden_small
+    eng = _engine(HipPlanner, g, name, dtype="bf16")
+    loss, grad = eng.step(1, return_grad=True)
+    assert _cos(grad, g[f"{name}/grad_at_1"]) >= COS_BF16
+    more = eng.step(19)
+    full = np.concatenate([_n(loss), _n(more)])
+    np.testing.assert_allclose(full, g[f"{name}/loss_log"], rtol=LOSS_RTOL_BF16, atol=1e-4)
+    # lr * n_iters bounds how far Adam can move a coordinate; bf16 must stay within 5 % of that budget
+    np.testing.assert_allclose(_n(eng.get_cp()), g[f"{name}/cp_after_20"], atol=0.05 * 0.01 * 20, rtol=0)
+
+
+def test_bf16_model_gradients_in_isolation(HipPlanner, golden_small):
+    g = golden_small
+    for term, key, obj in (("w_mel", "terms/mel_grad", "acoustic"), ("w_sem", "terms/sem_grad", "semvec")):
+        w = dict(w_mel=0.0, w_sem=0.0, w_vel=0.0, w_jerk=0.0, w_ll=0.0)
+        w[term] = 1.0
+        eng = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, "emb"), batch=int(g["B"]), n_frames=int(g["T"]),
+                         objective=obj, weights=w, dtype="bf16")
+        eng.set_targets(g["target_mel"], g["target_semvec"])
+        eng.set_cp(g["cp0"])
+        _, grad = eng.step(1, return_grad=True)
+        assert _cos(_n(grad)[0], g[key]) >= COS_BF16, term
+
+
+def test_full_size_properties_bf16(HipPlanner):
+    """BASELINE.json's headline shape (B = 256, T = 300, set A, acoustic_semvec, bf16): size-independent properties.
+    (1) batch rows are independent: utterance b of the big batch == the same utterance planned in a batch of 16;
+    (2) the loss decreases; (3) CP stays inside the clamp; (4) replaying from the same start is bit-identical."""
+    B, T = 256, 300
+    wl = synthetic.make_workload(B, T, "A")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(6))
+    cp = _n(eng.get_cp())
+    assert np.isfinite(loss).all() and np.isfinite(cp).all()
+    assert (loss[-1, :, 0] < loss[0, :, 0]).all()
+    assert np.abs(cp).max() <= 1.05 + 1e-6
+    sub = HipPlanner(wl.pred_sd, wl.emb_sd, batch=16, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    sl = slice(100, 116)
+    sub.set_targets(wl.target_mel[sl], wl.target_semvec[sl])
+    sub.set_cp(wl.cp0[sl])
+    loss_s = _n(sub.step(6))
+    np.testing.assert_array_equal(loss_s, loss[:, sl])
+    np.testing.assert_array_equal(_n(sub.get_cp()), cp[sl])
+    eng.set_cp(wl.cp0)
+    eng.reset_optimizer()
+    np.testing.assert_array_equal(_n(eng.step(6)), loss)
