@@ -38,7 +38,13 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
     import torch
     from oracle import planner as op
     from paule_amd import synthetic
-    nthreads = os.cpu_count() or 1
+    # the GPU box gives one GPU a share of 16 host cores; os.cpu_count() reports the whole machine and
+    # over-subscribing OpenMP threads stalls torch for minutes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 16))
     torch.set_num_threads(nthreads)
     sample_b = 16
     wl = synthetic.make_workload(sample_b, wl_args["frames"], wl_args["model_set"])
@@ -47,6 +53,7 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
                            dtype=torch.float32)
     orc.set_targets(wl.target_mel, wl.target_semvec)
     orc.set_cp(wl.cp0)
+    progress(f"cpu baseline: {nthreads} threads, sample of {sample_b} utterances")
     orc.step(1)   # warm-up
     iters, t0 = 0, time.perf_counter()
     while iters < 2 or (time.perf_counter() - t0 < seconds_budget and iters < 50):
@@ -58,6 +65,10 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
                 utt_iters_per_s=utt_it_s, cores=torch.get_num_threads(), kind="port",
                 sample=f"{sample_b} utterances x {iters} iterations, T={wl_args['frames']}, {objective}, model set "
                        f"{wl_args['model_set']}, float32, torch CPU oracle ({dt:.1f} s)")
+
+
+def progress(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -102,6 +113,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    progress(f"engine ready ({eng.device_bytes / 2**30:.2f} GiB on device); warm-up")
     if args.warmup > 0:
         eng.step(args.warmup, return_loss=False)
     torch.cuda.synchronize()
@@ -130,6 +142,7 @@ def main():
     finite = bool(torch.isfinite(loss).all().item() and torch.isfinite(cp).all().item())
 
     if rank == 0:
+        progress(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
         it_s = world * args.steps / elapsed
         flops_it = eng.flops_per_iteration
         # dominant kernel: the LSTM backward step (one launch per time step per layer); hipEvents on the engine stream
@@ -170,6 +183,7 @@ def main():
         }
         if gather_ms is not None:
             out["final_cp_all_gather_ms"] = gather_ms
+        progress("kernel timing done; cpu baseline")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, cfg["objective"])
         print(json.dumps(out), flush=True)

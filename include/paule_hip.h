@@ -110,6 +110,10 @@ int pl_reset_optimizer(pl_handle *h);
  * grad_out  [B, T, cp_dim] or NULL            -- xx_new.grad of the LAST iteration (paule/paule.py:1056-1063) */
 int pl_step(pl_handle *h, int n_iters, float *loss_log, float *grad_out);
 
+/* Waits for everything enqueued on the handle's stream and reports device-side failures that cannot be returned
+ * asynchronously (a bounded in-kernel wait of a persistent LSTM sweep timed out -> PL_ERR_HIP). */
+int pl_synchronize(pl_handle *h);
+
 int pl_get_cp(pl_handle *h, float *cp_out);
 /* Forward only at the current CP (paule/paule.py:822-824, :1460-1464): pred_mel [B, T/2, mel_dim],
  * pred_semvec [B, sem_dim] (may be NULL; requires an embedder). */

@@ -21,7 +21,7 @@ PL_LOSS_COLS = 6
 # every symbol include/paule_hip.h declares
 EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
-    "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
+    "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
     "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_last_error", "pl_version",
 )
@@ -76,6 +76,7 @@ def load_library(path: str | None = None):
     lib.pl_set_past_cp.argtypes = [vp, fp, C.c_int, C.c_int]
     lib.pl_reset_optimizer.argtypes = [vp]
     lib.pl_step.argtypes = [vp, C.c_int, fp, fp]
+    lib.pl_synchronize.argtypes = [vp]
     lib.pl_get_cp.argtypes = [vp, fp]
     lib.pl_get_pred.argtypes = [vp, fp, fp]
     lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
@@ -87,7 +88,7 @@ def load_library(path: str | None = None):
     lib.pl_flops_per_iteration.argtypes = [vp]
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
-                 "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel"):
+                 "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib

@@ -176,9 +176,10 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return r;
 }
 
+// sum of squares of the correlation d[t] = sum_k taps[k] x[t+k]; d itself is kept (d_out [n][C]) for the gradient pass
 template <int K>
 __device__ __forceinline__ double corr_sumsq(const double* __restrict__ x, int T, int C, const double* taps, int tid,
-                                             int nthreads) {
+                                             int nthreads, double* __restrict__ d_out) {
     const int n = T - K + 1;
     double s = 0.0;
     for (int e = tid; e < n * C; e += nthreads) {
@@ -186,6 +187,7 @@ __device__ __forceinline__ double corr_sumsq(const double* __restrict__ x, int T
         double d = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) d += taps[k] * x[(size_t)(t + k) * C + c];
+        d_out[e] = d;
         s += d * d;
     }
     return s;
@@ -221,11 +223,13 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
     }
 
     const double* x = a.x + (size_t)b * a.T * a.C;
-    s = block_sum(corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt), sh);
+    const size_t per = (size_t)a.T * a.C;
+    double* dws = a.dwork + (size_t)b * 3 * per;     // [vel | jerk | ll] correlations of this utterance
+    s = block_sum(corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws), sh);
     if (tid == 0) sc[2] = s / ((double)(a.T - 4) * a.C);
-    s = block_sum(corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt), sh);
+    s = block_sum(corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per), sh);
     if (tid == 0) sc[3] = s / ((double)(a.T - 12) * a.C);
-    s = block_sum(corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt), sh);
+    s = block_sum(corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per), sh);
     if (tid == 0) sc[4] = s / ((double)(a.T - 2) * a.C);
 }
 
@@ -317,19 +321,16 @@ void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_
 // gradient of the smoothness terms + Adam
 // ---------------------------------------------------------------------------------------------
 // loss = w * mean(d^2), d[u] = sum_j taps[j] x[u+j], u in [0, n)  =>  dloss/dx[t] = w*2/(n*C) * sum_k taps[k] d[t-k]
+// dc: the correlations d[u] of this channel (stride C over u), computed by loss_reduce_kernel of the same iteration
 template <int K>
-__device__ __forceinline__ double corr_grad(const double* __restrict__ xc, int T, int C, const double* taps, int t,
+__device__ __forceinline__ double corr_grad(const double* __restrict__ dc, int T, int C, const double* taps, int t,
                                             double w) {
     const int n = T - K + 1;
     double g = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int u = t - k;
-        if (u < 0 || u >= n) continue;
-        double d = 0.0;
-#pragma unroll
-        for (int j = 0; j < K; ++j) d += taps[j] * xc[(size_t)(u + j) * C];
-        g += taps[k] * d;
+        if (u >= 0 && u < n) g += taps[k] * dc[(size_t)u * C];
     }
     return g * (w * 2.0 / ((double)n * C));
 }
@@ -341,11 +342,12 @@ __global__ void total_grad_kernel(AdamArgs a) {
     const int c = (int)(idx % a.C);
     const int t = (int)((idx / a.C) % a.T);
     const int b = (int)(idx / ((int64_t)a.C * a.T));
-    const double* xc = a.x + (size_t)b * a.T * a.C + c;   // channel c of utterance b, stride C over time
+    const size_t per = (size_t)a.T * a.C;
+    const double* dws = a.dwork + (size_t)b * 3 * per + c;   // channel c of utterance b, stride C over time
     double g = (double)a.dX[((size_t)t * a.Bp + b) * a.Cp + c];
-    g += corr_grad<5>(xc, a.T, a.C, kVelTaps, t, (double)a.w_vel);
-    g += corr_grad<13>(xc, a.T, a.C, kJerkTaps, t, (double)a.w_jerk);
-    g += corr_grad<3>(xc, a.T, a.C, kLlTaps, t, (double)a.w_ll);
+    g += corr_grad<5>(dws, a.T, a.C, kVelTaps, t, (double)a.w_vel);
+    g += corr_grad<13>(dws + per, a.T, a.C, kJerkTaps, t, (double)a.w_jerk);
+    g += corr_grad<3>(dws + 2 * per, a.T, a.C, kLlTaps, t, (double)a.w_ll);
     a.grad[idx] = g;
 }
 

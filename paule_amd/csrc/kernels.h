@@ -30,9 +30,32 @@ struct LstmStepArgs {
     void* c_stash_t;       // forward (write) / backward (read): c_t in activation type [Bp][Hp]
     const void* c_stash_prev;  // backward: c_{t-1} stash (null at t = 0)
     const void* dh_ext;    // backward: dL/dh_t from the layer above [Bp][Hp] activation type (null = zeros)
+    unsigned long long* stamps;  // diagnostic builds (-DPL_STAMPS) only: [block][8] s_memrealtime stamps; null otherwise
 };
 void launch_lstm_fwd_step(hipStream_t stream, int dt, const LstmStepArgs& a);
 void launch_lstm_bwd_step(hipStream_t stream, int dt, const LstmStepArgs& a);
+
+// ---- lstm_persist.hip -----------------------------------------------------------------------
+// One launch = all T steps of one layer (bf16, register-resident W_hh, in-launch exchange).
+struct LstmSweepArgs {
+    int Bp, T;
+    void* G;               // [T][Bp][4*Hp]: forward: W_ih x + b in, activated gates out; backward: gates in, dA out
+    const void* W;         // forward: Whh [4*Hp][Hp]; backward: Whh^T [Hp][4*Hp]
+    void* h;               // forward: h stash [T][Bp][Hp] (written; h_{t-1} is read back by the whole group)
+    void* c;               // c stash [T][Bp][Hp] (forward writes, backward reads)
+    const void* dh_ext;    // backward: dL/dh from above [T][Bp][Hp], or null
+    const void* dh_last;   // backward: [Bp][Hp] applied at t = T-1 only (when dh_ext is null), or null
+    int* counters;         // [groups][T] arrival counters, zeroed before the launch
+    int* status;           // set to 1 when a bounded spin timed out (the sweep is then abandoned)
+    unsigned long long spin_ticks;   // bound of every in-kernel wait, in 100 MHz s_memrealtime ticks
+    unsigned long long* stamps;      // diagnostic builds (-DPL_STAMPS) only: [block][8] accumulated phase ticks
+};
+bool lstm_sweep_supported(int dt, int Hp);
+// workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit
+int lstm_sweep_grid(int Hp, int Bp, int n_cu);
+void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
+// zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
+void launch_zero_counters(hipStream_t stream, int* p, int n);
 
 // ---- elementwise.hip ------------------------------------------------------------------------
 // weight repack: src f32 [nblk*R, C] (torch layout) -> dst `dt` [nblk*Rp, Cp] (transpose = 0)
@@ -63,6 +86,7 @@ struct LossArgs {
     const float* target_mel;         // [B][Tp][M]
     const float* sem;                // pred semvec f32 [Bp][Sp] (null if not evaluated)
     const float* target_sem;         // [B][S]
+    double* dwork;                   // [B][3][T][C] velocity / jerk / local-linear correlations (kept for the gradient)
     double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse
     float* loss_rows;                // [cap][B][6] internal log
     const int* iter_slot;            // device counter: row of loss_rows written by this iteration
@@ -86,6 +110,7 @@ struct AdamArgs {
     double* m;
     double* v;
     double* grad;          // total gradient [B][T][C] (model + smoothness)
+    const double* dwork;   // correlations written by the loss reduction of this iteration
     int* step_count;       // device counter k (incremented by the update kernel)
     int* iter_slot;        // device counter (incremented by the update kernel)
     const double* past;    // past_cp [B or 1][P][C] or null

@@ -1,0 +1,421 @@
+// Persistent LSTM layer sweeps (bf16): ONE launch runs all T time steps of one layer.
+//
+// Why: a launch per time step has to pull its W_hh slice (94-188 KB per CU) out of L2 again every step,
+// at the ~70 GB/s a single CU ingests, plus a kernel boundary per step (measured 12.4 us per step).  Here
+// every workgroup keeps its W_hh slice in REGISTERS for the whole sweep (184 VGPRs per lane at H = 720) and
+// only the recurrent operand moves.
+//
+// Decomposition.  Utterances are independent, so the batch is cut into groups of 32 rows; a group is served
+// by P = Hp / 32 workgroups (one per CU), workgroup p owning hidden units [32p, 32p + 32) for all four
+// gates.  grid = P x (resident groups); further groups are processed in sequence by the same workgroups.
+//   forward : wave w owns 8 hidden units x 4 gates = 32 gate rows (MFMA 32x32x16 A operand, rows ordered
+//             [i(8) f(8) g(8) o(8)] so that a lane ends up with all four gates of 4 units of one batch
+//             row); B operand = h_{t-1} of the group's 32 batch rows, staged once per step in LDS.
+//             The running cell state c never leaves registers.
+//   backward: contraction over all 4*Hp gate rows; wave w takes gate block w (K split over the waves),
+//             A operand = W_hh^T rows of the 32 hidden units; the four partial 32 x 32 tiles are reduced
+//             through LDS, then each thread runs the cell backward for (1 batch row x 4 hidden units).
+//             The running dc never leaves registers.
+//
+// In-launch exchange (all P workgroups of a group need the whole h_t / dA_t of the group): the producers
+// store their slice WRITE-THROUGH (sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup
+// barriers, ONE lane adds 1 to the group's per-step arrival counter (agent scope).  Consumers: one lane
+// polls the counter with sc1 loads until it reads P, the workgroup barriers, then EVERY load of the
+// handed-off bytes is an sc1 buffer load (L1 bypass) -- the form of the MI355X guide's hand-off table,
+// row 1 (one lane per storing workgroup signals for all its stores; 8/16-byte sc1 stores and loads; one
+// workgroup per CU; hipMalloc memory).  Counters are zeroed by a memset node before every launch.
+// Every spin is bounded (s_memrealtime); on timeout a status word is set and every workgroup leaves.
+// Results do not depend on placement or dispatch order; same-XCD placement of a group (blockIdx % groups)
+// is a speed choice only.
+#include "kernels.h"
+#include "pl_types.h"
+
+namespace pl {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kAuxSc1 = 16;                       // cache-policy bit sc1 of raw buffer loads / stores on gfx950
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kAuxSc1);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st8_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, uint2 v) {
+    u32x2 d;
+    d[0] = v.x;
+    d[1] = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, kAuxSc1);
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+    bf16x4 o;
+    o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d;
+    return __builtin_bit_cast(uint2, o);
+}
+__device__ __forceinline__ void unpack_bf16x4(uint2 u, float (&f)[4]) {
+    const bf16x4 v = __builtin_bit_cast(bf16x4, u);
+    f[0] = (float)v[0]; f[1] = (float)v[1]; f[2] = (float)v[2]; f[3] = (float)v[3];
+}
+
+// One lane of wave 0 waits until *cnt == target (relaxed agent-scope = sc1 loads), bounded; the verdict is
+// shared through LDS so that the whole workgroup leaves together on a timeout.  Ends with a barrier.
+__device__ __forceinline__ bool wait_arrivals(const int* cnt, int target, int* status, int* lds_flag, unsigned long long spin_ticks) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                __builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+                __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *lds_flag = ok;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
+// every storing wave has drained its hand-off stores (all but its N youngest memory operations, which are not
+// part of the hand-off); one lane signals for the workgroup
+template <int N>
+__device__ __forceinline__ void publish(int* cnt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifdef PL_STAMPS
+#define PL_ST(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
+#define PL_ST_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
+#define PL_ST_DUMP(ptr) do { if ((ptr) && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) (ptr)[(size_t)blockIdx.x * 8 + i_] = st_acc[i_]; } } while (0)
+#else
+#define PL_ST(i) do { } while (0)
+#define PL_ST_DECL
+#define PL_ST_DUMP(ptr) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// forward sweep
+// ---------------------------------------------------------------------------------------------------
+template <int KS>   // KS = Hp / 16 MFMA k-steps
+__global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int ROWB = Hp * 2;                 // bytes of one h row
+    constexpr int RS = ROWB + 16;                // LDS row stride: odd number of 16-byte chunks -> conflict-free b128 reads
+    constexpr int CPR = Hp / 8;                  // 16-byte chunks per row
+    constexpr int NLD = (32 * CPR + 255) / 256;  // loads per thread per step
+    __shared__ __attribute__((aligned(16))) unsigned char himg[32 * RS];
+    __shared__ int lds_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = Hp / 32;
+    const int n_res = gridDim.x / P;             // resident groups
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int n_groups = (Bp + 31) / 32;
+    const bf16_t* __restrict__ W = static_cast<const bf16_t*>(a.W);
+
+    // weights -> registers: A-operand row (lane & 31) = gate (row >> 3), unit 32p + 8 wave + (row & 7)
+    uint4 wreg[KS];
+    {
+        const int ar = lane & 31;
+        const bf16_t* wrow = W + (size_t)((ar >> 3) * Hp + 32 * p + 8 * wave + (ar & 7)) * Hp + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wreg[ks] = *reinterpret_cast<const uint4*>(wrow + 16 * ks);
+    }
+
+    const int bl = lane & 31, hh = lane >> 5;
+    const int j = 32 * p + 8 * wave + 4 * hh;     // this lane's 4 hidden units
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(a.G);
+    bf16_t* __restrict__ Hs = static_cast<bf16_t*>(a.h);
+    bf16_t* __restrict__ Cs = static_cast<bf16_t*>(a.c);
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = 32 * g + bl;
+        const bool ok = b < Bp;
+        const int bc = ok ? b : Bp - 1;
+        float c_state[4] = {0.f, 0.f, 0.f, 0.f};
+        int* cnt = a.counters + (size_t)g * T;
+
+        for (int t = 0; t < T; ++t) {
+            // input projection of this step (written by the preceding GEMM launch): plain loads, issued before the wait
+            const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
+            uint2 gx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gx[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            PL_ST(0);   // top of step (prefetch issue)
+            if (t > 0) {
+                if (!wait_arrivals(cnt + (t - 1), P, a.status, &lds_flag, a.spin_ticks)) return;
+                PL_ST(1);   // waiting for the group's arrivals
+                // h_{t-1} of the group's 32 batch rows -> LDS (sc1 loads: handed-off bytes)
+                const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t - 1) * slabH, (unsigned)(slabH * 2));
+                uint4 v[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int q = tid + 256 * i;
+                    const int row = q / CPR, c = q % CPR;
+                    int rb = 32 * g + row;
+                    rb = rb < Bp ? rb : Bp - 1;
+                    v[i] = (q < 32 * CPR) ? ld16_sc1(rh, (unsigned)(rb * ROWB + c * 16)) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int q = tid + 256 * i;
+                    if (q < 32 * CPR) *reinterpret_cast<uint4*>(himg + (q / CPR) * RS + (q % CPR) * 16) = v[i];
+                }
+                __syncthreads();
+                PL_ST(2);   // h tile: sc1 loads + LDS image
+                const unsigned char* bsrc = himg + bl * RS + hh * 16;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const uint4 bv = *reinterpret_cast<const uint4*>(bsrc + ks * 32);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks]),
+                                                                  __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                }
+            }
+
+            PL_ST(3);   // MFMA chain
+            // cell update: acc[4 * gate + unit]
+            float gxi[4], gxf[4], gxg[4], gxo[4];
+            unpack_bf16x4(gx[0], gxi);
+            unpack_bf16x4(gx[1], gxf);
+            unpack_bf16x4(gx[2], gxg);
+            unpack_bf16x4(gx[3], gxo);
+            float vi[4], vf[4], vg[4], vo[4], vc[4], vh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vi[u] = sigmoid_fast(acc[u] + gxi[u]);
+                vf[u] = sigmoid_fast(acc[4 + u] + gxf[u]);
+                vg[u] = tanh_fast(acc[8 + u] + gxg[u]);
+                vo[u] = sigmoid_fast(acc[12 + u] + gxo[u]);
+                c_state[u] = vf[u] * c_state[u] + vi[u] * vg[u];
+                vc[u] = c_state[u];
+                vh[u] = vo[u] * tanh_fast(vc[u]);
+            }
+            if (ok) {
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                st8_sc1(ro, (unsigned)((b * Hp + j) * 2), pack_bf16x4(vh[0], vh[1], vh[2], vh[3]));   // hand-off first
+                asm volatile("" ::: "memory");   // keep the five stash stores behind it
+                bf16_t* go = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                *reinterpret_cast<uint2*>(go) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);
+                *reinterpret_cast<uint2*>(go + Hp) = pack_bf16x4(vf[0], vf[1], vf[2], vf[3]);
+                *reinterpret_cast<uint2*>(go + 2 * Hp) = pack_bf16x4(vg[0], vg[1], vg[2], vg[3]);
+                *reinterpret_cast<uint2*>(go + 3 * Hp) = pack_bf16x4(vo[0], vo[1], vo[2], vo[3]);
+                *reinterpret_cast<uint2*>(Cs + (size_t)t * slabH + (size_t)b * Hp + j) = pack_bf16x4(vc[0], vc[1], vc[2], vc[3]);
+            }
+            PL_ST(4);   // cell update + store issue
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            PL_ST(5);   // hand-off store drain (the five stash stores stay in flight)
+            publish<5>(cnt + t);   // also orders this step's LDS reads before the next step's LDS writes
+            PL_ST(6);   // barrier + arrival add
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward sweep (backward-DATA only)
+// ---------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int KSH = KS / 2;                  // k-steps per half of a gate block
+    constexpr int HB = Hp;                       // bytes of half a gate block of one row (Hp / 2 bf16)
+    constexpr int RS = HB + 16;                  // LDS row stride (odd chunk count)
+    constexpr int BLK = 32 * RS;                 // one wave's image
+    constexpr int CH = HB / 16;                  // chunks per row-half
+    constexpr int NLD = (4 * 32 * CH) / 256;     // loads per thread per half  (= Hp / 32, exact)
+    static_assert((4 * 32 * CH) % 256 == 0, "half image splits evenly");
+    constexpr int LDR = 33;
+    __shared__ __attribute__((aligned(16))) unsigned char img[4 * BLK];
+    __shared__ float red[4 * 32 * LDR];
+    __shared__ int lds_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = Hp / 32;
+    const int n_res = gridDim.x / P;
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int n_groups = (Bp + 31) / 32;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);
+
+    // weights -> registers: wave = gate block; A-operand row = hidden unit 32p + (lane & 31); k inside the gate block
+    uint4 wreg[KS];
+    {
+        const bf16_t* wrow = WT + (size_t)(32 * p + (lane & 31)) * G4 + wave * Hp + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wreg[ks] = *reinterpret_cast<const uint4*>(wrow + 16 * ks);
+    }
+
+    // epilogue ownership: thread -> batch row (tid >> 3), hidden units 32p + 4 (tid & 7) .. +3
+    const int erow = tid >> 3, jq = tid & 7;
+    PL_ST_DECL
+    const int j = 32 * p + 4 * jq;
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(a.G);
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(a.c);
+    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(a.dh_ext);
+    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(a.dh_last);
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = 32 * g + erow;
+        const bool ok = b < Bp;
+        const int bc = ok ? b : Bp - 1;
+        float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+        int* cnt = a.counters + (size_t)g * T;
+
+        for (int t = T - 1; t >= 0; --t) {
+            // stash operands of this step (written by the forward launch): plain loads before the wait
+            const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
+            uint2 sg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+            const uint2 sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+            uint2 scp = make_uint2(0u, 0u);
+            if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
+            uint2 sdh = make_uint2(0u, 0u);
+            if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
+            else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
+
+            float dh[4];
+            unpack_bf16x4(sdh, dh);
+            PL_ST(0);
+            if (t + 1 < T) {
+                if (!wait_arrivals(cnt + (t + 1), P, a.status, &lds_flag, a.spin_ticks)) return;
+                PL_ST(1);
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)(t + 1) * slabG, (unsigned)(slabG * 2));
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    // dA_{t+1}: this half of every gate block, 32 batch rows -> LDS (sc1 loads: handed-off bytes)
+                    uint4 v[NLD];
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) {
+                        const int q = tid + 256 * i;
+                        const int blk = q / (32 * CH), rem = q % (32 * CH);
+                        const int row = rem / CH, c = rem % CH;
+                        int rb = 32 * g + row;
+                        rb = rb < Bp ? rb : Bp - 1;
+                        v[i] = ld16_sc1(rg, (unsigned)((rb * G4 + blk * Hp + hf * (Hp / 2)) * 2 + c * 16));
+                    }
+                    if (hf) __syncthreads();   // the first half's MFMA reads are done before the image is overwritten
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) {
+                        const int q = tid + 256 * i;
+                        const int blk = q / (32 * CH), rem = q % (32 * CH);
+                        *reinterpret_cast<uint4*>(img + blk * BLK + (rem / CH) * RS + (rem % CH) * 16) = v[i];
+                    }
+                    __syncthreads();
+                    const unsigned char* bsrc = img + wave * BLK + (lane & 31) * RS + (lane >> 5) * 16;
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) {
+                        const uint4 bv = *reinterpret_cast<const uint4*>(bsrc + ks * 32);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[hf * KSH + ks]),
+                                                                      __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                    }
+                }
+                PL_ST(2);   // both halves: sc1 loads + LDS image + MFMA
+                // reduce the four gate-block partials: acc[r] = out[row (r&3) + 8 (r>>2) + 4 (lane>>5)][col lane & 31]
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDR + (lane & 31)] = acc[r];
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) dh[u] += red[(w * 32 + 4 * jq + u) * LDR + erow];
+            }
+
+            PL_ST(3);   // partial reduction
+            float gi[4], gf[4], gg[4], go[4], c[4], cp[4];
+            unpack_bf16x4(sg[0], gi);
+            unpack_bf16x4(sg[1], gf);
+            unpack_bf16x4(sg[2], gg);
+            unpack_bf16x4(sg[3], go);
+            unpack_bf16x4(sc, c);
+            unpack_bf16x4(scp, cp);
+            float dai[4], daf[4], dag[4], dao[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float tc = tanh_fast(c[u]);
+                const float dc = dc_next[u] + dh[u] * go[u] * (1.f - tc * tc);
+                dai[u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
+                daf[u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
+                dag[u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
+                dao[u] = dh[u] * tc * go[u] * (1.f - go[u]);
+                dc_next[u] = dc * gf[u];
+            }
+            if (ok) {   // dA_t overwrites the gate stash in place: the hand-off of the next (earlier) step
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+                const unsigned o = (unsigned)((b * G4 + j) * 2);
+                st8_sc1(ro, o, pack_bf16x4(dai[0], dai[1], dai[2], dai[3]));
+                st8_sc1(ro, o + Hp * 2, pack_bf16x4(daf[0], daf[1], daf[2], daf[3]));
+                st8_sc1(ro, o + 2 * Hp * 2, pack_bf16x4(dag[0], dag[1], dag[2], dag[3]));
+                st8_sc1(ro, o + 3 * Hp * 2, pack_bf16x4(dao[0], dao[1], dao[2], dao[3]));
+            }
+            PL_ST(4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PL_ST(5);
+            publish<0>(cnt + t);
+            PL_ST(6);
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define PL_SWEEP_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
+
+__global__ void zero_counters_kernel(int* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __hip_atomic_store(p + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+void launch_zero_counters(hipStream_t stream, int* p, int n) {
+    hipLaunchKernelGGL(zero_counters_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n);
+}
+
+bool lstm_sweep_supported(int dt, int Hp) {
+    if (dt != BF16) return false;
+#define PL_CASE(K) if (Hp == 16 * K) return true;
+    PL_SWEEP_KS_LIST(PL_CASE)
+#undef PL_CASE
+    return false;
+}
+
+int lstm_sweep_grid(int Hp, int Bp, int n_cu) {
+    const int P = Hp / 32, groups = (Bp + 31) / 32;
+    int res = n_cu / P;
+    if (res > groups) res = groups;
+    if (res >= 8) res = res / 8 * 8;   // a multiple of the XCD count keeps a group's workgroups on one XCD (speed only)
+    return res < 1 ? 0 : res * P;
+}
+
+void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a) {
+#define PL_CASE(K)                                                                                          \
+    if (Hp == 16 * K) {                                                                                     \
+        if (backward) hipLaunchKernelGGL(lstm_bwd_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);    \
+        else hipLaunchKernelGGL(lstm_fwd_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);             \
+        return;                                                                                             \
+    }
+    PL_SWEEP_KS_LIST(PL_CASE)
+#undef PL_CASE
+}
+
+}  // namespace pl

@@ -26,4 +26,21 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// bf16 path: hardware exp2 / rcp (v_exp_f32, v_rcp_f32; ~1 ulp each), far inside the bf16 output rounding
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {   // 1 - 2 / (1 + e^{2x}); saturates cleanly at +-1
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+
+// activation functions by arithmetic type: exact libm forms on the f32 path (parity bar 1e-5), hardware forms on bf16
+template <typename AT> __device__ __forceinline__ float act_sigmoid(float x);
+template <> __device__ __forceinline__ float act_sigmoid<float>(float x) { return sigmoid_f(x); }
+template <> __device__ __forceinline__ float act_sigmoid<bf16_t>(float x) { return sigmoid_fast(x); }
+template <typename AT> __device__ __forceinline__ float act_tanh(float x);
+template <> __device__ __forceinline__ float act_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ float act_tanh<bf16_t>(float x) { return tanh_fast(x); }
+
 }  // namespace pl

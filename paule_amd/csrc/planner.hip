@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -88,13 +89,21 @@ struct pl_handle {
     float* dmel_e = nullptr;
     void* dY = nullptr;
     float* dX = nullptr;
-    double *x = nullptr, *m = nullptr, *v = nullptr, *grad = nullptr;
+    double *x = nullptr, *m = nullptr, *v = nullptr, *grad = nullptr, *dwork = nullptr;
     float *target_mel = nullptr, *target_sem = nullptr;
     float* out_tmp = nullptr;   // [B][max(S, ...)] staging for unpadded outputs
     double* scal = nullptr;
     float* loss_rows = nullptr;
     int loss_cap = 0;
     int* counters = nullptr;    // [0] Adam step count, [1] loss row of the running iteration
+    int* sweep_cnt = nullptr;   // arrival counters of the persistent LSTM sweeps [groups][T] (own allocation: memset target)
+    size_t sweep_cnt_bytes = 0;
+    int* sweep_status = nullptr;
+    int n_cu = 0;
+    bool use_sweep = true;
+    int zero_mode = 0;          // 0: own sc1 zeroing kernel, 1: hipMemsetAsync (experiments)
+    unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
+    unsigned long long spin_ticks = 200000000ull;   // 2 s
     double* past = nullptr;
     int past_len = 0, past_per_utt = 0;
     hipGraph_t graph = nullptr;
@@ -166,6 +175,13 @@ int alloc_model(pl_handle* h, Model& md, int L, int H, int in, int out, int Tl) 
 
 inline char* off(void* p, size_t elems, size_t esz) { return static_cast<char*>(p) + elems * esz; }
 
+void zero_sweep_counters(pl_handle* h, hipStream_t st) {
+    if (h->zero_mode == 1)
+        (void)hipMemsetAsync(h->sweep_cnt, 0, h->sweep_cnt_bytes, st);
+    else
+        launch_zero_counters(st, h->sweep_cnt, (int)(h->sweep_cnt_bytes / sizeof(int)));
+}
+
 // stacked LSTM forward over all Tl steps; in_act = time-major [Tl][Bp][in_p]
 void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) {
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
@@ -175,6 +191,24 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
         LstmLayer& ly = md.layers[l];
         // input projection for every time step at once: G = in * Wih^T + (b_ih + b_hh)
         launch_gemm_nt(st, h->dt, false, cur_in, ly.in_p, ly.Wih, ly.in_p, ly.bias, ly.G, 4 * Hp, Tl * Bp, 4 * Hp, ly.in_p);
+        const int sweep_grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        if (sweep_grid > 0) {
+            LstmSweepArgs s{};
+            s.Bp = Bp;
+            s.T = Tl;
+            s.G = ly.G;
+            s.W = ly.Whh;
+            s.h = ly.h;
+            s.c = ly.c;
+            s.counters = h->sweep_cnt;
+            s.status = h->sweep_status;
+            s.spin_ticks = h->spin_ticks;
+            s.stamps = h->sweep_stamps;
+            zero_sweep_counters(h, st);
+            launch_lstm_sweep(st, false, Hp, sweep_grid, s);
+            cur_in = ly.h;
+            continue;
+        }
         for (int t = 0; t < Tl; ++t) {
             LstmStepArgs s{};
             s.Bp = Bp;
@@ -201,6 +235,23 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
     for (int l = md.L - 1; l >= 0; --l) {
         LstmLayer& ly = md.layers[l];
         const bool sparse_top = (l == md.L - 1) && dh_last;
+        const int sweep_grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        if (sweep_grid > 0) {
+            LstmSweepArgs s{};
+            s.Bp = Bp;
+            s.T = Tl;
+            s.G = ly.G;
+            s.W = ly.WhhT;
+            s.c = ly.c;
+            s.dh_ext = sparse_top ? nullptr : md.dh_ext;
+            s.dh_last = sparse_top ? dh_last : nullptr;
+            s.counters = h->sweep_cnt;
+            s.status = h->sweep_status;
+            s.spin_ticks = h->spin_ticks;
+            s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
+            zero_sweep_counters(h, st);
+            launch_lstm_sweep(st, true, Hp, sweep_grid, s);
+        } else
         for (int t = Tl - 1; t >= 0; --t) {
             LstmStepArgs s{};
             s.Bp = Bp;
@@ -250,7 +301,7 @@ LossArgs loss_args(pl_handle* h, bool with_sem) {
     a.x = h->x; a.mel = h->mel_bm; a.target_mel = h->target_mel;
     a.sem = with_sem ? h->sem : nullptr;
     a.target_sem = h->target_sem;
-    a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1;
+    a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1; a.dwork = h->dwork;
     return a;
 }
 
@@ -261,7 +312,7 @@ AdamArgs adam_args(pl_handle* h) {
     a.clamp_lo = h->cfg.clamp_lo; a.clamp_hi = h->cfg.clamp_hi;
     a.w_vel = h->cfg.w_vel; a.w_jerk = h->cfg.w_jerk; a.w_ll = h->cfg.w_ll;
     a.smiling = h->cfg.smiling;
-    a.dX = h->dX; a.x = h->x; a.m = h->m; a.v = h->v; a.grad = h->grad;
+    a.dX = h->dX; a.x = h->x; a.m = h->m; a.v = h->v; a.grad = h->grad; a.dwork = h->dwork;
     a.step_count = h->counters; a.iter_slot = h->counters + 1;
     a.past = h->past_len > 0 ? h->past : nullptr;
     a.past_len = h->past_len; a.past_per_utt = h->past_per_utt;
@@ -431,10 +482,28 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if ((rc = dev_alloc(h, &h->m, B * T * h->C))) return bail(rc);
     if ((rc = dev_alloc(h, &h->v, B * T * h->C))) return bail(rc);
     if ((rc = dev_alloc(h, &h->grad, B * T * h->C))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->dwork, 3 * B * T * h->C))) return bail(rc);
     if ((rc = dev_alloc(h, &h->target_mel, B * Tp * h->M))) return bail(rc);
     if ((rc = dev_alloc(h, &h->scal, B * 8))) return bail(rc);
     if ((rc = dev_alloc(h, &h->loss_rows, (size_t)h->loss_cap * B * PL_LOSS_COLS))) return bail(rc);
     if ((rc = dev_alloc(h, &h->counters, 4))) return bail(rc);
+    {
+        hipDeviceProp_t prop;
+        hipError_t pe = hipGetDeviceProperties(&prop, cfg->device);
+        if (pe != hipSuccess) { bail(PL_ERR_HIP); return fail(PL_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(pe)); }
+        h->n_cu = prop.multiProcessorCount;
+        const char* env = std::getenv("PAULE_HIP_NO_SWEEP");
+        h->use_sweep = !(env && env[0] == '1');
+        if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
+        if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
+        const size_t n = (size_t)((Bp + 31) / 32) * T;
+        h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
+        if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int)))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
+#ifdef PL_STAMPS
+        if ((rc = dev_alloc(h, &h->sweep_stamps, 2 * 256 * 8))) return bail(rc);
+#endif
+    }
     if ((rc = dev_alloc(h, &h->past, B * T * h->C))) return bail(rc);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { bail(PL_ERR_HIP); return fail(PL_ERR_HIP, std::string("pl_create: ") + hipGetErrorString(e)); }
@@ -587,6 +656,30 @@ int pl_step(pl_handle* h, int n_iters, float* loss_log, float* grad_out) {
     return check_launch();
 }
 
+int pl_synchronize(pl_handle* h) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_synchronize: NULL handle");
+    DeviceGuard guard(h->cfg.device);
+    PL_HIP(hipStreamSynchronize(h->stream));
+#ifdef PL_STAMPS
+    if (const char* path = std::getenv("PL_STAMP_FILE")) {   // phase ticks of the LAST forward / backward sweep
+        std::vector<unsigned long long> host(2 * 256 * 8);
+        PL_HIP(hipMemcpy(host.data(), h->sweep_stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen((std::string(path) + ".sweep").c_str(), "wb")) {
+            std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+            std::fclose(f);
+        }
+    }
+#endif
+    int st = 0;
+    PL_HIP(hipMemcpy(&st, h->sweep_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        (void)hipMemset(h->sweep_status, 0, sizeof(int));
+        return fail(PL_ERR_HIP, "persistent LSTM sweep: a bounded in-kernel wait timed out (workgroups of one batch group were not "
+                                "co-resident?); results of the last pl_step are invalid");
+    }
+    return PL_OK;
+}
+
 int pl_get_cp(pl_handle* h, float* cp_out) {
     if (!h || !cp_out) return fail(PL_ERR_INVALID, "pl_get_cp: NULL argument");
     DeviceGuard guard(h->cfg.device);
@@ -632,6 +725,13 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
     LstmLayer& ly = md.layers[0];
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
     const size_t a = h->act;
+#ifdef PL_STAMPS
+    // diagnostic build: every launch writes [block][8] s_memrealtime stamps; dumped raw to $PL_STAMP_FILE
+    const int nblk = kernel == PL_KERNEL_LSTM_FWD_STEP ? (Hp / 16) * ((Bp + 63) / 64) : (Hp / 32) * ((Bp + 31) / 32);
+    unsigned long long* stamps = nullptr;
+    PL_HIP(hipMalloc(&stamps, sizeof(unsigned long long) * 8 * nblk * reps));
+    PL_HIP(hipMemset(stamps, 0, sizeof(unsigned long long) * 8 * nblk * reps));
+#endif
     hipEvent_t e0, e1;
     PL_HIP(hipEventCreate(&e0));
     PL_HIP(hipEventCreate(&e1));
@@ -643,6 +743,9 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         s.Hp = Hp;
         s.G_t = off(ly.G, (size_t)t * Bp * 4 * Hp, a);
         s.c_stash_t = off(ly.c, (size_t)t * Bp * Hp, a);
+#ifdef PL_STAMPS
+        s.stamps = stamps + (size_t)i * nblk * 8;
+#endif
         if (kernel == PL_KERNEL_LSTM_FWD_STEP) {
             s.W = ly.Whh;
             s.h_prev = off(ly.h, (size_t)(t - 1) * Bp * Hp, a);
@@ -666,6 +769,20 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
     PL_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+#ifdef PL_STAMPS
+    if (const char* path = std::getenv("PL_STAMP_FILE")) {
+        std::vector<unsigned long long> host((size_t)8 * nblk * reps);
+        PL_HIP(hipMemcpy(host.data(), stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::string fn = std::string(path) + (kernel == PL_KERNEL_LSTM_FWD_STEP ? ".fwd" : ".bwd");
+        if (FILE* f = std::fopen(fn.c_str(), "wb")) {
+            const int hdr[2] = {nblk, reps};
+            std::fwrite(hdr, sizeof(int), 2, f);
+            std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+            std::fclose(f);
+        }
+    }
+    (void)hipFree(stamps);
+#endif
     *avg_ms_out = ms / reps;
     if (flops_per_launch_out) *flops_per_launch_out = 2.0 * h->B * 4.0 * md.H * md.H;
     return check_launch();

@@ -205,4 +205,5 @@ class HipPlanner:
         return float(self.lib.pl_flops_per_iteration(self._h))
 
     def synchronize(self):
-        self._stream.synchronize()
+        """Waits for the engine's stream; raises if a device-side bounded wait timed out."""
+        self._call(self.lib.pl_synchronize)

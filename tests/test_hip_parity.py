@@ -195,6 +195,40 @@ def test_bf16_against_oracle(HipPlanner, golden_small, name):
     np.testing.assert_allclose(_n(eng.get_cp()), g[f"{name}/cp_after_20"], atol=0.05 * 0.01 * 20, rtol=0)
 
 
+def test_bf16_sweep_equals_per_step_kernels(golden_small, monkeypatch):
+    """The persistent LSTM sweeps (one launch per layer, in-launch exchange) and the launch-per-step kernels run the
+    same arithmetic (MFMA shape and k order differ: 32x32x16 vs 16x16x32), so they agree to f32 accumulation noise;
+    and no bounded wait times out."""
+    from paule_amd.engine import HipPlanner
+    g = golden_small
+    outs = []
+    for no_sweep in ("0", "1"):
+        monkeypatch.setenv("PAULE_HIP_NO_SWEEP", no_sweep)
+        eng = _engine(HipPlanner, g, "acoustic_semvec", dtype="bf16")
+        loss = _n(eng.step(5))
+        eng.synchronize()
+        outs.append((loss, _n(eng.get_cp())))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("shape", [dict(B=40, T=30, set="B"), dict(B=70, T=24, set="A")])
+def test_bf16_sweep_ragged_groups_vs_oracle(HipPlanner, shape):
+    """Persistent sweeps with batch groups that are not full (B % 32 != 0), several groups, the stacked class-default
+    models (set B: 4 x H180 -> 6 workgroups per group) and Paule's default H = 720 (23 workgroups per group)."""
+    wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=shape["B"], n_frames=shape["T"], objective="acoustic_semvec",
+                     dtype="bf16")
+    for pl in (orc, eng):
+        pl.set_targets(wl.target_mel, wl.target_semvec)
+        pl.set_cp(wl.cp0)
+    lo, lh = _n(orc.step(4)), _n(eng.step(4))
+    eng.synchronize()
+    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_BF16, atol=1e-4)
+
+
 def test_bf16_model_gradients_in_isolation(HipPlanner, golden_small):
     g = golden_small
     for term, key, obj in (("w_mel", "terms/mel_grad", "acoustic"), ("w_sem", "terms/sem_grad", "semvec")):
@@ -232,3 +266,4 @@ def test_full_size_properties_bf16(HipPlanner):
     eng.set_cp(wl.cp0)
     eng.reset_optimizer()
     np.testing.assert_array_equal(_n(eng.step(6)), loss)
+    eng.synchronize()
