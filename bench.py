@@ -145,19 +145,30 @@ def main():
         progress(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
         it_s = world * args.steps / elapsed
         flops_it = eng.flops_per_iteration
-        # dominant kernel: the LSTM backward step (one launch per time step per layer); hipEvents on the engine stream
+        # dominant kernel: the LSTM backward sweep of the predictive model (one launch = T steps; bf16) or, on the
+        # f32 path, the launch-per-step backward kernel.  Timed with hipEvents on the engine's own stream.
+        swept = cfg["dtype"] == "bf16"
+        names = ("bwd_sweep", "fwd_sweep") if swept else ("bwd", "fwd")
         roof = {}
-        for name in ("bwd", "fwd"):
-            ms, fl = eng.bench_kernel(name, "pred", reps=min(298, T - 2) * 2)
-            roof[name] = (ms, fl)
-        ms, fl = roof["bwd"]
+        for name in names:
+            try:
+                roof[name] = eng.bench_kernel(name, "pred", reps=5 if swept else min(298, T - 2) * 2)
+            except ValueError:
+                swept, names = False, ("bwd", "fwd")
+                break
+        if not swept:
+            roof = {name: eng.bench_kernel(name, "pred", reps=min(298, T - 2) * 2) for name in names}
+        eng.synchronize()
+        ms, fl = roof[names[0]]
+        ms_f, fl_f = roof[names[1]]
+        kname = "lstm_bwd_sweep_kernel" if swept else "lstm_bwd_step_kernel"
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC pass (rocprofv3 --pmc), see profiles/README.md
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get("lstm_bwd_step_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(args.config, {}).get(kname + "_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -175,11 +186,12 @@ def main():
             "whole_iteration_mfma_frac": (flops_it * it_s / world) / (peak * 1e12),
             "finite": finite, "final_loss_mean": float(loss[-1, :, 0].mean().item()),
             "device_bytes": eng.device_bytes,
-            "roofline": {"bound": "mfma", "kernel": "lstm_bwd_step_kernel", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_us": ms * 1e3, "flops_per_launch": fl,
-                         "fwd_step_avg_launch_us": roof["fwd"][0] * 1e3,
-                         "fwd_step_achieved": roof["fwd"][1] / (roof["fwd"][0] * 1e-3) / 1e12},
+                         "us_per_time_step": ms * 1e3 / (T - 1) if swept else ms * 1e3,
+                         "fwd_kernel_avg_launch_us": ms_f * 1e3,
+                         "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12},
         }
         if gather_ms is not None:
             out["final_cp_all_gather_ms"] = gather_ms

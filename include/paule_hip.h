@@ -130,7 +130,9 @@ int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems,
  * on the handle's stream with real operands (cycling over the time steps of layer 0 of `model_id`), bracketed
  * by hipEvents on that stream, and returns the average launch-to-launch time (ms, inter-launch gap included)
  * and the algorithmic FLOPs of one launch (2 * B * 4H * H).  Clobbers only scratch that every pl_step rebuilds. */
-enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1 };
+enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1,
+       /* persistent sweeps: one launch = all T steps of layer 0 (+ its ~5 us counter-zeroing launch); FLOPs = 2*B*4H*H*(T-1) */
+       PL_KERNEL_LSTM_FWD_SWEEP = 2, PL_KERNEL_LSTM_BWD_SWEEP = 3 };
 int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg_ms_out /* host */,
                     double *flops_per_launch_out /* host */);
 

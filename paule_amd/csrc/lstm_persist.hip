@@ -27,6 +27,8 @@
 // Every spin is bounded (s_memrealtime); on timeout a status word is set and every workgroup leaves.
 // Results do not depend on placement or dispatch order; same-XCD placement of a group (blockIdx % groups)
 // is a speed choice only.
+#include <type_traits>
+
 #include "kernels.h"
 #include "pl_types.h"
 
@@ -110,8 +112,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
     constexpr int Hp = 16 * KS;
     constexpr int ROWB = Hp * 2;                 // bytes of one h row
     constexpr int RS = ROWB + 16;                // LDS row stride: odd number of 16-byte chunks -> conflict-free b128 reads
-    constexpr int CPR = Hp / 8;                  // 16-byte chunks per row
-    constexpr int NLD = (32 * CPR + 255) / 256;  // loads per thread per step
+    constexpr int KSH = KS / 2;                  // k-steps per K half
+    constexpr int CH = Hp / 16;                  // 16-byte chunks per row half
+    constexpr int NLH = (32 * CH + 255) / 256;   // loads per thread per half
+    constexpr int PF = 6;                        // B-fragment read-ahead
+    static_assert(KS % 2 == 0, "Hp is a multiple of 32");
     __shared__ __attribute__((aligned(16))) unsigned char himg[32 * RS];
     __shared__ int lds_flag;
 
@@ -161,30 +166,44 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
             if (t > 0) {
                 if (!wait_arrivals(cnt + (t - 1), P, a.status, &lds_flag, a.spin_ticks)) return;
                 PL_ST(1);   // waiting for the group's arrivals
-                // h_{t-1} of the group's 32 batch rows -> LDS (sc1 loads: handed-off bytes)
+                // h_{t-1} of the group's 32 batch rows -> LDS (sc1 loads: handed-off bytes), in two K halves: all
+                // loads are issued at once, the second half is still in flight while the first half multiplies
                 const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t - 1) * slabH, (unsigned)(slabH * 2));
-                uint4 v[NLD];
+                uint4 v[2][NLH];
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) {
-                    const int q = tid + 256 * i;
-                    const int row = q / CPR, c = q % CPR;
-                    int rb = 32 * g + row;
-                    rb = rb < Bp ? rb : Bp - 1;
-                    v[i] = (q < 32 * CPR) ? ld16_sc1(rh, (unsigned)(rb * ROWB + c * 16)) : make_uint4(0, 0, 0, 0);
-                }
+                for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) {
-                    const int q = tid + 256 * i;
-                    if (q < 32 * CPR) *reinterpret_cast<uint4*>(himg + (q / CPR) * RS + (q % CPR) * 16) = v[i];
-                }
-                __syncthreads();
-                PL_ST(2);   // h tile: sc1 loads + LDS image
+                    for (int i = 0; i < NLH; ++i) {
+                        const int q = tid + 256 * i;
+                        const int row = q / CH, c = q % CH + hf * CH;
+                        int rb = 32 * g + row;
+                        rb = rb < Bp ? rb : Bp - 1;
+                        v[hf][i] = (q < 32 * CH) ? ld16_sc1(rh, (unsigned)(rb * ROWB + c * 16)) : make_uint4(0, 0, 0, 0);
+                    }
                 const unsigned char* bsrc = himg + bl * RS + hh * 16;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const uint4 bv = *reinterpret_cast<const uint4*>(bsrc + ks * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks]),
-                                                                  __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                    for (int i = 0; i < NLH; ++i) {
+                        const int q = tid + 256 * i;
+                        if (q < 32 * CH) *reinterpret_cast<uint4*>(himg + (q / CH) * RS + (q % CH + hf * CH) * 16) = v[hf][i];
+                    }
+                    __syncthreads();
+                    if (hf == 0) PL_ST(2);   // first half of the h tile landed
+                    // B fragments are read PF k-steps ahead of the MFMA that consumes them; sched_barrier pins that order
+                    // (left alone, the scheduler serialises ds_read -> wait -> MFMA on one register)
+                    uint4 bq[PF];
+#pragma unroll
+                    for (int i = 0; i < PF; ++i)
+                        if (i < KSH) bq[i] = *reinterpret_cast<const uint4*>(bsrc + (hf * KSH + i) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[hf * KSH + ks]),
+                                                                      __builtin_bit_cast(bf16x8, bq[ks % PF]), acc, 0, 0, 0);
+                        if (ks + PF < KSH) bq[ks % PF] = *reinterpret_cast<const uint4*>(bsrc + (hf * KSH + ks + PF) * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
 
@@ -233,15 +252,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
 template <int KS>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
-    constexpr int KSH = KS / 2;                  // k-steps per half of a gate block
-    constexpr int HB = Hp;                       // bytes of half a gate block of one row (Hp / 2 bf16)
-    constexpr int RS = HB + 16;                  // LDS row stride (odd chunk count)
-    constexpr int BLK = 32 * RS;                 // one wave's image
-    constexpr int CH = HB / 16;                  // chunks per row-half
-    constexpr int NLD = (4 * 32 * CH) / 256;     // loads per thread per half  (= Hp / 32, exact)
-    static_assert((4 * 32 * CH) % 256 == 0, "half image splits evenly");
+    constexpr int NPART = KS >= 8 ? 4 : 2;       // K parts of a gate block (k-step ranges KS*i/NPART)
+    constexpr int KPM = (KS + NPART - 1) / NPART;   // k-steps of the largest part = sc1 loads per thread per part
+    constexpr int RS = KPM * 32 + 16;            // LDS row stride (odd chunk count -> conflict-free b128 reads)
+    constexpr int BLK = 32 * RS;                 // one gate block (= one wave's operand) of a part
+    constexpr int IMG = 4 * BLK;                 // one image buffer
+    constexpr int PF = 4;                        // B-fragment read-ahead
     constexpr int LDR = 33;
-    __shared__ __attribute__((aligned(16))) unsigned char img[4 * BLK];
+    __shared__ __attribute__((aligned(16))) unsigned char img[2 * IMG];
     __shared__ float red[4 * 32 * LDR];
     __shared__ int lds_flag;
 
@@ -301,34 +319,54 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                // dA_{t+1} (32 batch rows x 4 gate blocks) streams through a double-buffered LDS image in NPART K parts:
+                // the sc1 loads of part i+2 are issued before the MFMAs of part i, so two parts are always in flight.
+                uint4 v[2][KPM];
+                auto issue_part = [&](auto pi_c) {
+                    constexpr int pi = decltype(pi_c)::value;
+                    constexpr int k0 = KS * pi / NPART, kc = KS * (pi + 1) / NPART - k0;
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    // dA_{t+1}: this half of every gate block, 32 batch rows -> LDS (sc1 loads: handed-off bytes)
-                    uint4 v[NLD];
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i) {
+                    for (int i = 0; i < kc; ++i) {
                         const int q = tid + 256 * i;
-                        const int blk = q / (32 * CH), rem = q % (32 * CH);
-                        const int row = rem / CH, c = rem % CH;
+                        const int c = q % (2 * kc), row = (q / (2 * kc)) % 32, blk = q / (64 * kc);
                         int rb = 32 * g + row;
                         rb = rb < Bp ? rb : Bp - 1;
-                        v[i] = ld16_sc1(rg, (unsigned)((rb * G4 + blk * Hp + hf * (Hp / 2)) * 2 + c * 16));
+                        v[pi % 2][i] = ld16_sc1(rg, (unsigned)((rb * G4 + blk * Hp + 16 * k0) * 2 + c * 16));
                     }
-                    if (hf) __syncthreads();   // the first half's MFMA reads are done before the image is overwritten
+                };
+                auto run_part = [&](auto pi_c) {
+                    constexpr int pi = decltype(pi_c)::value;
+                    constexpr int k0 = KS * pi / NPART, kc = KS * (pi + 1) / NPART - k0;
+                    unsigned char* buf = img + (pi % 2) * IMG;
 #pragma unroll
-                    for (int i = 0; i < NLD; ++i) {
+                    for (int i = 0; i < kc; ++i) {
                         const int q = tid + 256 * i;
-                        const int blk = q / (32 * CH), rem = q % (32 * CH);
-                        *reinterpret_cast<uint4*>(img + blk * BLK + (rem / CH) * RS + (rem % CH) * 16) = v[i];
+                        const int c = q % (2 * kc), row = (q / (2 * kc)) % 32, blk = q / (64 * kc);
+                        *reinterpret_cast<uint4*>(buf + blk * BLK + row * RS + c * 16) = v[pi % 2][i];
                     }
                     __syncthreads();
-                    const unsigned char* bsrc = img + wave * BLK + (lane & 31) * RS + (lane >> 5) * 16;
+                    if constexpr (pi + 2 < NPART) issue_part(std::integral_constant<int, pi + 2>{});
+                    const unsigned char* bsrc = buf + wave * BLK + (lane & 31) * RS + (lane >> 5) * 16;
+                    uint4 bq[PF];
 #pragma unroll
-                    for (int ks = 0; ks < KSH; ++ks) {
-                        const uint4 bv = *reinterpret_cast<const uint4*>(bsrc + ks * 32);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[hf * KSH + ks]),
-                                                                      __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                    for (int i = 0; i < PF; ++i)
+                        if (i < kc) bq[i] = *reinterpret_cast<const uint4*>(bsrc + i * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < kc; ++ks) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[k0 + ks]),
+                                                                      __builtin_bit_cast(bf16x8, bq[ks % PF]), acc, 0, 0, 0);
+                        if (ks + PF < kc) bq[ks % PF] = *reinterpret_cast<const uint4*>(bsrc + (ks + PF) * 32);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                };
+                issue_part(std::integral_constant<int, 0>{});
+                issue_part(std::integral_constant<int, 1>{});
+                run_part(std::integral_constant<int, 0>{});
+                run_part(std::integral_constant<int, 1>{});
+                if constexpr (NPART == 4) {
+                    run_part(std::integral_constant<int, 2>{});
+                    run_part(std::integral_constant<int, 3>{});
                 }
                 PL_ST(2);   // both halves: sc1 loads + LDS image + MFMA
                 // reduce the four gate-block partials: acc[r] = out[row (r&3) + 8 (r>>2) + 4 (lane>>5)][col lane & 31]

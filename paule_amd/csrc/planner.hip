@@ -718,13 +718,39 @@ int pl_embed_mel(pl_handle* h, const float* mel, const int32_t* lens, float* sem
 
 int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg_ms_out, double* flops_per_launch_out) {
     if (!h || !avg_ms_out || reps < 1) return fail(PL_ERR_INVALID, "pl_bench_kernel: bad argument");
-    if (kernel != PL_KERNEL_LSTM_FWD_STEP && kernel != PL_KERNEL_LSTM_BWD_STEP) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
+    if (kernel < PL_KERNEL_LSTM_FWD_STEP || kernel > PL_KERNEL_LSTM_BWD_SWEEP) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
     Model& md = model_id == PL_MODEL_EMBED ? h->emb : h->pred;
     if (md.L == 0 || !md.ready()) return fail(PL_ERR_STATE, "pl_bench_kernel: model weights are not set");
     DeviceGuard guard(h->cfg.device);
     LstmLayer& ly = md.layers[0];
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
     const size_t a = h->act;
+    if (kernel >= PL_KERNEL_LSTM_FWD_SWEEP) {
+        const int grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        if (grid <= 0) return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: the persistent sweep is not used for this dtype / shape");
+        const bool bwd = kernel == PL_KERNEL_LSTM_BWD_SWEEP;
+        LstmSweepArgs s{};
+        s.Bp = Bp; s.T = Tl; s.G = ly.G; s.W = bwd ? ly.WhhT : ly.Whh; s.h = ly.h; s.c = ly.c;
+        s.dh_ext = bwd ? md.dh_ext : nullptr;
+        s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks;
+        hipEvent_t e0, e1;
+        PL_HIP(hipEventCreate(&e0));
+        PL_HIP(hipEventCreate(&e1));
+        PL_HIP(hipEventRecord(e0, h->stream));
+        for (int i = 0; i < reps; ++i) {
+            zero_sweep_counters(h, h->stream);
+            launch_lstm_sweep(h->stream, bwd, Hp, grid, s);
+        }
+        PL_HIP(hipEventRecord(e1, h->stream));
+        PL_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms_out = ms / reps;
+        if (flops_per_launch_out) *flops_per_launch_out = 2.0 * h->B * 4.0 * md.H * md.H * (Tl - 1);
+        return check_launch();
+    }
 #ifdef PL_STAMPS
     // diagnostic build: every launch writes [block][8] s_memrealtime stamps; dumped raw to $PL_STAMP_FILE
     const int nblk = kernel == PL_KERNEL_LSTM_FWD_STEP ? (Hp / 16) * ((Bp + 63) / 64) : (Hp / 32) * ((Bp + 31) / 32);

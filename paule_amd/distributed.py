@@ -1,0 +1,48 @@
+"""Batch sharding of the planning path across the GPUs of one node.
+
+Utterances are independent (per-utterance losses), so rank r plans the contiguous block
+``[r * B / G, (r + 1) * B / G)`` with replicated weights and NO collective inside the loop; the only
+exchange is one ``all_gather`` of the final CP trajectories (RCCL over xGMI with backend "nccl", gloo in the
+CPU tests), after the last iteration.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_utterances: int, rank: int, world: int):
+    """Contiguous, balanced blocks: the first (n % world) ranks hold one utterance more."""
+    base, extra = divmod(n_utterances, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_final_cp(cp_local: torch.Tensor, n_utterances: int):
+    """all_gather of the per-rank CP blocks (B_r, T, C) -> (B, T, C) on every rank.  Blocks may differ by one row,
+    so they are padded to the largest block for the collective and trimmed afterwards."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return cp_local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_bounds(n_utterances, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((bmax,) + tuple(cp_local.shape[1:]), dtype=cp_local.dtype, device=cp_local.device)
+    pad[: cp_local.shape[0]] = cp_local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0)
+
+
+def plan_sharded(make_planner, cp0, target_mel, target_semvec, n_iters: int):
+    """Plans this rank's block with ``make_planner(batch=...)`` (a HipPlanner factory on the GPU; tests inject the
+    CPU oracle) and returns (final CP of ALL utterances, this rank's loss log)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = cp0.shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    planner = make_planner(batch=hi - lo)
+    planner.set_targets(target_mel[lo:hi], None if target_semvec is None else target_semvec[lo:hi])
+    planner.set_cp(cp0[lo:hi])
+    loss = planner.step(n_iters)
+    cp = planner.get_cp()
+    return gather_final_cp(cp if isinstance(cp, torch.Tensor) else torch.as_tensor(cp), n), loss

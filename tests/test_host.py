@@ -1,0 +1,141 @@
+"""Host logic on the CPU: Paule.plan_resynth validation / result contract (with the oracle engine injected as
+test infrastructure) and the multi-process batch sharding over gloo (world size 2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import state_dict_from
+from oracle_engine import OracleEngine
+from paule_amd import paule as pp
+from paule_amd import synthetic
+from paule_amd.distributed import gather_final_cp, plan_sharded, shard_bounds
+
+
+def _factory(pred_model, embedder, **kw):
+    return OracleEngine(pred_model, embedder, **kw)
+
+
+@pytest.fixture(scope="module")
+def small():
+    return synthetic.make_workload(2, 24, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                   emb=dict(num_lstm_layers=1, hidden_size=10))
+
+
+@pytest.fixture()
+def model(small):
+    return pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory,
+                    device=torch.device("cpu"))
+
+
+def test_exceptions(model, small):
+    """The ValueErrors pinned by the reference's tests/test_paule.py:31-62, same messages."""
+    mel = small.target_mel[0].numpy()
+    cp_11 = np.zeros((11, 30))
+    with pytest.raises(ValueError, match="Either target_acoustic or target_semvec"):
+        model.plan_resynth(target_acoustic=None, target_semvec=None)
+    with pytest.raises(ValueError, match="results can only be logged"):
+        model.plan_resynth(target_acoustic=mel, target_semvec=None, n_inner=5, log_ii=10)
+    with pytest.raises(ValueError, match="if target_acoustic is None you need"):
+        model.plan_resynth(target_acoustic=None, target_semvec=np.zeros(300))
+    with pytest.raises(ValueError, match="initialize_from has to be either"):
+        model.plan_resynth(target_acoustic=mel, initialize_from="ERROR")
+    with pytest.raises(ValueError, match="one of initial_cp and initialize_from has to be None"):
+        model.plan_resynth(target_acoustic=mel, initial_cp=cp_11, initialize_from="ERROR")
+    with pytest.raises(ValueError, match="one of initial_cp and initialize_from has to be None"):
+        model.plan_resynth(target_acoustic=mel, initial_cp=cp_11)
+    with pytest.raises(ValueError, match="past_cp have to be None or the sequence length"):
+        model.plan_resynth(target_acoustic=mel, past_cp=cp_11)
+    with pytest.raises(ValueError, match="objective has to be one of"):
+        model.plan_resynth(target_acoustic=mel, initial_cp=small.cp0[0].numpy(), initialize_from=None, objective="ERROR")
+    with pytest.raises(ValueError, match="initial_cp 11, target_mel 24"):
+        model.plan_resynth(target_acoustic=mel, initial_cp=cp_11, initialize_from=None)
+    with pytest.raises(NotImplementedError):
+        pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, use_somatosensory_feedback=True,
+                 use_speech_classifier=True)
+
+
+def test_plan_resynth_contract(model, small):
+    """33-field PlanningResults, log-step bookkeeping (pre-step CP at log steps, post-step planned_cp), and the
+    values of the loop equal a direct oracle run."""
+    n_outer, n_inner, log_ii = 2, 6, 3
+    res = model.plan_resynth(target_acoustic=small.target_mel[0].numpy(), target_semvec=small.target_semvec[0].numpy(),
+                             initial_cp=small.cp0[0].numpy(), initialize_from=None, objective="acoustic_semvec",
+                             n_outer=n_outer, n_inner=n_inner, log_ii=log_ii, continue_learning=False, log_cps=True,
+                             log_gradients=True, verbose=False)
+    assert len(res) == 33 and res._fields[0] == "planned_cp" and res._fields[-1] == "inv_model_loss"
+    assert res.planned_cp.shape == (24, 30) and res.pred_mel.shape == (12, 60) and res.pred_semvec.shape == (300,)
+    n_logs = n_outer * (n_inner // log_ii)
+    assert len(res.planned_loss_steps) == n_logs == len(res.vel_loss_steps) == len(res.pred_semvec_loss_steps)
+    assert len(res.cp_steps) == n_outer and len(res.cp_steps[0]) == n_inner // log_ii
+    assert len(res.grad_steps) == n_outer * n_inner
+    assert res.prod_mel is None and res.prod_loss_steps == []          # no synthesizer injected
+    eng = OracleEngine(small.pred_sd, small.emb_sd, batch=1, n_frames=24, objective="acoustic_semvec")
+    eng.set_targets(small.target_mel[0:1], small.target_semvec[0:1])
+    eng.set_cp(small.cp0[0:1])
+    log = eng.step(n_outer * n_inner).numpy()
+    np.testing.assert_allclose(res.planned_cp, eng.get_cp()[0].numpy(), atol=1e-12)
+    np.testing.assert_allclose(res.planned_loss_steps, log[log_ii - 1::log_ii, 0, 0], rtol=1e-12)
+    pre = OracleEngine(small.pred_sd, small.emb_sd, batch=1, n_frames=24, objective="acoustic_semvec")
+    pre.set_targets(small.target_mel[0:1], small.target_semvec[0:1])
+    pre.set_cp(small.cp0[0:1])
+    pre.step(log_ii - 1)                                                # CP handed out at a log step = PRE-step CP
+    np.testing.assert_allclose(res.cp_steps[0][0], pre.get_cp()[0].numpy(), atol=1e-12)
+
+
+def test_batched_targets_and_hooks(small):
+    calls = []
+
+    def synth(cp):
+        calls.append(cp.shape)
+        return np.zeros(100), 44100
+
+    def melx(sig, sr):
+        return np.full((12, 60), 0.25)
+
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory,
+                     device=torch.device("cpu"), synthesizer=synth, mel_extractor=melx, smiling=True)
+    res = model.plan_resynth(target_acoustic=small.target_mel.numpy(), initial_cp=small.cp0.numpy(), initialize_from=None,
+                             objective="acoustic", n_outer=1, n_inner=4, log_ii=2, continue_learning=False, verbose=False)
+    assert res.planned_cp.shape == (2, 24, 30)
+    assert np.all(res.planned_cp[:, :, 4] == -1.0) and np.all(res.planned_cp[:, :, 1] == 1.0)   # smiling
+    assert res.prod_mel.shape == (2, 12, 60) and len(res.prod_loss_steps) == 2
+    assert len(calls) == 2 * (1 + 2)                                    # initial + two log steps, per utterance
+    assert model.best_synthesis_acoustic.mel_loss < np.inf
+
+
+def test_shard_bounds():
+    assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_bounds(2048, r, 8) for r in range(8)][-1] == (1792, 2048)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    wl = synthetic.make_workload(5, 24, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                 emb=dict(num_lstm_layers=1, hidden_size=10))
+    mk = lambda batch: OracleEngine(wl.pred_sd, wl.emb_sd, batch=batch, n_frames=24, objective="acoustic_semvec")
+    cp_all, loss = plan_sharded(mk, wl.cp0, wl.target_mel, wl.target_semvec, 4)
+    if rank == 0:
+        torch.save(cp_all, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_planning_world2_gloo(tmp_path):
+    """N > 1 path: two ranks plan 3 + 2 utterances, one all_gather; equals the single-process batch of 5."""
+    out = str(tmp_path / "cp.pt")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    cp_all = torch.load(out)
+    wl = synthetic.make_workload(5, 24, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                 emb=dict(num_lstm_layers=1, hidden_size=10))
+    eng = OracleEngine(wl.pred_sd, wl.emb_sd, batch=5, n_frames=24, objective="acoustic_semvec")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    eng.step(4)
+    np.testing.assert_allclose(cp_all.numpy(), eng.get_cp().numpy(), atol=1e-13)

@@ -27,6 +27,10 @@ for s in $STEPS; do
     rocprof) rm -rf gpurun_out/prof
              step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline
              find gpurun_out/prof -name "*stats*" | head ;;
+    pmc) rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+         step pmc_fetch 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+         step pmc_write 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+         python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg3 gpurun_out/traffic.json | tee gpurun_out/pmc_summary.log ;;
     *) echo "unknown step $s" ;;
   esac
 done

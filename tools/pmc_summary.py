@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs as the MI355X
+guide prescribes: FETCH_SIZE takes 3 of the 4 TCC slots) into HBM bytes per launch for the dominant kernels.
+gfx950 corrections (MI355X_MICROARCH.md, HBM): counters are in KiB; FETCH_SIZE reads exactly 1/2 of the bytes of a
+wide (16 B / lane) coalesced stream -> doubled; WRITE_SIZE is exact.
+usage: pmc_summary.py <dir_fetch> <dir_write> <config> [out.json]"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(dirname, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    dfetch, dwrite, config = sys.argv[1], sys.argv[2], sys.argv[3]
+    out_path = sys.argv[4] if len(sys.argv) > 4 else None
+    fetch, write = per_kernel(dfetch, "FETCH_SIZE"), per_kernel(dwrite, "WRITE_SIZE")
+    res = {}
+    for kname, key in (("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"), ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
+                       ("lstm_bwd_step_kernel", "lstm_bwd_step_kernel"), ("lstm_fwd_step_kernel", "lstm_fwd_step_kernel"),
+                       ("gemm_nt_kernel", "gemm_nt_kernel")):
+        fv = [v for k, vs in fetch.items() if kname in k for v in vs]
+        wv = [v for k, vs in write.items() if kname in k for v in vs]
+        if not fv and not wv:
+            continue
+        # the predictive model's sweep (T = 300) is the longest launch of its kind: take the upper half by value
+        fv.sort()
+        wv.sort()
+        fbig = fv[len(fv) * 2 // 3:] if "sweep" in kname else fv
+        wbig = wv[len(wv) * 2 // 3:] if "sweep" in kname else wv
+        fb = 2.0 * 1024.0 * (sum(fbig) / max(1, len(fbig)))
+        wb = 1024.0 * (sum(wbig) / max(1, len(wbig)))
+        res[key + "_bytes_per_launch"] = fb + wb
+        res[key + "_fetch_bytes"] = fb
+        res[key + "_write_bytes"] = wb
+        res[key + "_launches"] = len(fv)
+        print(f"{kname:26s} launches {len(fv):5d}  fetch {fb / 1e6:10.2f} MB  write {wb / 1e6:10.2f} MB per launch")
+    if out_path:
+        data = {}
+        if os.path.exists(out_path):
+            data = json.load(open(out_path))
+        data[config] = res
+        json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
