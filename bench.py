@@ -139,6 +139,7 @@ def main():
         dist.all_gather(outs, cp)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+    eng.synchronize()   # surfaces device-side failures (bounded in-kernel waits) -- outside the timed region
     finite = bool(torch.isfinite(loss).all().item() and torch.isfinite(cp).all().item())
 
     if rank == 0:

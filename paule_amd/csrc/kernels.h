@@ -49,11 +49,15 @@ struct LstmSweepArgs {
     int* status;           // set to 1 when a bounded spin timed out (the sweep is then abandoned)
     unsigned long long spin_ticks;   // bound of every in-kernel wait, in 100 MHz s_memrealtime ticks
     unsigned long long* stamps;      // diagnostic builds (-DPL_STAMPS) only: [block][8] accumulated phase ticks
+    void* xchg;            // reduce-scatter backward only: partial-tile exchange [2 slots][groups][P][32 rows][Hp]
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit
 int lstm_sweep_grid(int Hp, int Bp, int n_cu);
 void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
+// backward sweep in reduce-scatter form (lstm_persist_rs.hip): same arguments + a.xchg of lstm_rs_exchange_bytes()
+size_t lstm_rs_exchange_bytes(int Hp, int Bp);
+void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a);
 // zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
 void launch_zero_counters(hipStream_t stream, int* p, int n);
 

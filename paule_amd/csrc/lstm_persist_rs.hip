@@ -1,0 +1,213 @@
+// Backward LSTM sweep, "reduce-scatter" form (bf16).
+//
+// The all-gather form (lstm_persist.hip) makes every workgroup of a batch group read the group's whole
+// dA_{t+1} (32 rows x 4*Hp bf16 = 188 KB per workgroup per step at H = 720): 3.3 of its 5.4 us per step.
+// Here each workgroup multiplies only the dA it produced itself (its 32 hidden units x 4 gates = 128 gate
+// rows, straight from LDS) with the matching 128 rows of W_hh, i.e. its PARTIAL contribution to dh_t of ALL
+// hidden units, and hands the partials over; a workgroup then sums the P partial 32 x 32 tiles that belong to
+// its own hidden units.  Per workgroup and step: 47 KB written + 47 KB read instead of 188 KB read.
+//
+//   partial_p[b][n] = sum_{k in gate rows of slice p} dA_t[b][k] * W_hh[k][n]        (MFMA, K = 128, N = Hp)
+//   dh_{t-1}[b][j]  = dh_ext_{t-1}[b][j] + sum_p partial_p[b][j]                      (j in own slice)
+//
+// Price: the partials cross the exchange rounded to bf16 (each is a 128-term f32 sum; 23 of them are then added
+// in f32) -- the same order of rounding as dA itself being bf16; covered by the bf16 parity tests.
+// W_hh^T rows stay in registers (wave w owns N tiles w, w+4, ...: 6 x 8 k-steps x 4 VGPRs = 192), the running dc
+// never leaves registers.  Exchange protocol, bounded waits, zeroing: as in lstm_persist.hip.
+#include "sweep_common.h"
+
+namespace pl {
+
+template <int KS>   // KS = Hp / 16
+__global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int P = Hp / 32;                   // slices = N tiles of 32 hidden units
+    constexpr int NT = (P + 3) / 4;              // N tiles per wave (wave w: tiles w, w + 4, ...)
+    constexpr int DRS = 128 * 2 + 16;            // dA^T image: [32 batch rows][128 local gate rows] bf16, odd chunk stride
+    constexpr int ORS = Hp * 2 + 16;             // partial image: [32 batch rows][Hp] bf16
+    constexpr int NST = (P * 128 + 255) / 256;   // hand-off stores (16 B) per thread per step
+    __shared__ __attribute__((aligned(16))) unsigned char da_img[32 * DRS];
+    __shared__ __attribute__((aligned(16))) unsigned char out_img[32 * ORS];
+    __shared__ int lds_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_res = gridDim.x / P;
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int n_groups = (Bp + 31) / 32;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);   // Whh^T packed [Hp][4*Hp]
+
+    // weights -> registers: tile nt = wave + 4 i covers hidden columns n = 32 nt + (lane & 31); local k = 16 ks + 8 (lane >> 5) + jj
+    // maps to gate row (ks / 2) * Hp + 32 p + 16 (ks % 2) + 8 (lane >> 5) + jj of this slice
+    uint4 wreg[NT][8];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nt = wave + 4 * i;
+        const int n = 32 * (nt < P ? nt : 0) + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            wreg[i][ks] = *reinterpret_cast<const uint4*>(WT + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
+    }
+
+    // cell ownership: thread -> batch row (tid >> 3), hidden units 32p + 4 (tid & 7) .. +3
+    const int erow = tid >> 3, jq = tid & 7;
+    const int j = 32 * p + 4 * jq;
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(a.G);
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(a.c);
+    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(a.dh_ext);
+    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(a.dh_last);
+    // exchange layout [2 slots][groups][P destinations][P sources][32 rows][32 columns]: a destination reads ONE contiguous
+    // 2 KB x P block (a wave instruction = 512 contiguous bytes), a source writes P contiguous 2-KB tiles
+    bf16_t* __restrict__ X = static_cast<bf16_t*>(a.xchg);
+    constexpr size_t TILE = 32 * 32;                                  // elements of one (destination, source) tile
+    const size_t grp_stride = (size_t)P * P * TILE;
+    const size_t slot_stride = (size_t)n_groups * grp_stride;
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = 32 * g + erow;
+        const bool ok = b < Bp;
+        const int bc = ok ? b : Bp - 1;
+        float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+        int* cnt = a.counters + (size_t)g * T;
+
+        for (int t = T - 1; t >= 0; --t) {
+            // stash operands of this step (written by the forward launch): plain loads, issued before the wait
+            const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
+            uint2 sg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+            const uint2 sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+            uint2 scp = make_uint2(0u, 0u);
+            if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
+            uint2 sdh = make_uint2(0u, 0u);
+            if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
+            else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
+
+            float dh[4];
+            unpack_bf16x4(sdh, dh);
+            PL_ST(0);
+            if (t + 1 < T) {
+                if (!wait_arrivals(cnt + (t + 1), P, a.status, &lds_flag, a.spin_ticks)) return;
+                PL_ST(1);
+                // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)
+                const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+                const unsigned o0 = (unsigned)((erow * 32 + 4 * jq) * 2);
+                u32x2 pv[P];
+#pragma unroll
+                for (int s = 0; s < P; ++s)
+                    pv[s] = __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    float f[4];
+                    unpack_bf16x4(make_uint2(pv[s][0], pv[s][1]), f);
+                    dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+                }
+            }
+            PL_ST(2);   // partial ingest
+
+            float gi[4], gf[4], gg[4], go[4], c[4], cp[4];
+            unpack_bf16x4(sg[0], gi);
+            unpack_bf16x4(sg[1], gf);
+            unpack_bf16x4(sg[2], gg);
+            unpack_bf16x4(sg[3], go);
+            unpack_bf16x4(sc, c);
+            unpack_bf16x4(scp, cp);
+            float dai[4], daf[4], dag[4], dao[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float tc = tanh_fast(c[u]);
+                const float dc = dc_next[u] + dh[u] * go[u] * (1.f - tc * tc);
+                dai[u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
+                daf[u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
+                dag[u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
+                dao[u] = dh[u] * tc * go[u] * (1.f - go[u]);
+                dc_next[u] = dc * gf[u];
+            }
+            const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
+            const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
+            if (ok) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                *reinterpret_cast<uint2*>(go_) = pi;
+                *reinterpret_cast<uint2*>(go_ + Hp) = pf;
+                *reinterpret_cast<uint2*>(go_ + 2 * Hp) = pg;
+                *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
+            }
+            if (t == 0) break;   // nobody consumes the partials of step 0
+
+            // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
+            {
+                unsigned char* drow = da_img + erow * DRS + jq * 8;
+                *reinterpret_cast<uint2*>(drow) = pi;
+                *reinterpret_cast<uint2*>(drow + 64) = pf;
+                *reinterpret_cast<uint2*>(drow + 128) = pg;
+                *reinterpret_cast<uint2*>(drow + 192) = po;
+            }
+            __syncthreads();
+            PL_ST(3);   // cell + stash stores + dA image
+            uint4 bfr[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                bfr[ks] = *reinterpret_cast<const uint4*>(da_img + (lane & 31) * DRS + ks * 32 + (lane >> 5) * 16);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int nt = wave + 4 * i;
+                if (nt >= P) break;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+                // acc[r] = partial[n = 32 nt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31] -> bf16 image [batch][n]
+                unsigned char* orow = out_img + (lane & 31) * ORS + (32 * nt + 4 * (lane >> 5)) * 2;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<uint2*>(orow + rg * 16) = pack_bf16x4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+            }
+            __syncthreads();
+            PL_ST(4);   // MFMA + partial image
+            {   // hand-off: this workgroup's partial tile rows, whole 16-byte chunks, write-through
+                bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+#pragma unroll
+                for (int i = 0; i < NST; ++i) {
+                    const int e = tid + 256 * i;      // 16-byte chunk: destination e / 128, row (e % 128) / 4, quarter e % 4
+                    if (e < P * 128) {
+                        const int dst = e >> 7, r = (e & 127) >> 2, c4 = e & 3;
+                        const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (32 * dst + 8 * c4) * 2);
+                        u32x4 d;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        __builtin_amdgcn_raw_buffer_store_b128(d, ro, (unsigned)(((size_t)dst * P * TILE + (e & 127) * 8) * 2), 0, kAuxSc1);
+                    }
+                }
+            }
+            PL_ST(5);   // hand-off store issue
+            publish<0>(cnt + t);
+            PL_ST(6);   // drain + barrier + arrival add
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+#define PL_SWEEP_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
+
+size_t lstm_rs_exchange_bytes(int Hp, int Bp) {
+    const size_t groups = (Bp + 31) / 32, P = Hp / 32;
+    return 2 * groups * P * P * 32 * 32 * 2;
+}
+
+void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a) {
+#define PL_CASE(K)                                                                                   \
+    if (Hp == 16 * K) {                                                                              \
+        hipLaunchKernelGGL(lstm_bwd_rs_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);        \
+        return;                                                                                      \
+    }
+    PL_SWEEP_KS_LIST(PL_CASE)
+#undef PL_CASE
+}
+
+}  // namespace pl

@@ -102,6 +102,8 @@ struct pl_handle {
     int n_cu = 0;
     bool use_sweep = true;
     int zero_mode = 0;          // 0: own sc1 zeroing kernel, 1: hipMemsetAsync (experiments)
+    int bwd_mode = 0;           // backward sweep: 0 all-gather of dA (default), 1 reduce-scatter of partial dh tiles (A/B variant)
+    void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
     unsigned long long spin_ticks = 200000000ull;   // 2 s
     double* past = nullptr;
@@ -249,8 +251,12 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
+            s.xchg = h->sweep_xchg;
             zero_sweep_counters(h, st);
-            launch_lstm_sweep(st, true, Hp, sweep_grid, s);
+            if (h->bwd_mode == 1 && h->sweep_xchg)
+                launch_lstm_bwd_rs_sweep(st, Hp, sweep_grid, s);
+            else
+                launch_lstm_sweep(st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
             LstmStepArgs s{};
@@ -495,6 +501,15 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         const char* env = std::getenv("PAULE_HIP_NO_SWEEP");
         h->use_sweep = !(env && env[0] == '1');
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
+        if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1) {
+            size_t xb = lstm_sweep_supported(h->dt, h->pred.Hp) ? lstm_rs_exchange_bytes(h->pred.Hp, h->Bp) : 0;
+            if (cfg->emb_layers > 0 && lstm_sweep_supported(h->dt, h->emb.Hp)) {
+                const size_t xe = lstm_rs_exchange_bytes(h->emb.Hp, h->Bp);
+                xb = xb > xe ? xb : xe;
+            }
+            if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
+        }
         if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
         const size_t n = (size_t)((Bp + 31) / 32) * T;
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
@@ -737,9 +752,13 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         PL_HIP(hipEventCreate(&e0));
         PL_HIP(hipEventCreate(&e1));
         PL_HIP(hipEventRecord(e0, h->stream));
+        s.xchg = h->sweep_xchg;
         for (int i = 0; i < reps; ++i) {
             zero_sweep_counters(h, h->stream);
-            launch_lstm_sweep(h->stream, bwd, Hp, grid, s);
+            if (bwd && h->bwd_mode == 1 && h->sweep_xchg)
+                launch_lstm_bwd_rs_sweep(h->stream, Hp, grid, s);
+            else
+                launch_lstm_sweep(h->stream, bwd, Hp, grid, s);
         }
         PL_HIP(hipEventRecord(e1, h->stream));
         PL_HIP(hipEventSynchronize(e1));

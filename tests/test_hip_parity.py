@@ -212,10 +212,13 @@ def test_bf16_sweep_equals_per_step_kernels(golden_small, monkeypatch):
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("bwd_mode", ["0", "1"])
 @pytest.mark.parametrize("shape", [dict(B=40, T=30, set="B"), dict(B=70, T=24, set="A")])
-def test_bf16_sweep_ragged_groups_vs_oracle(HipPlanner, shape):
+def test_bf16_sweep_ragged_groups_vs_oracle(HipPlanner, shape, bwd_mode, monkeypatch):
     """Persistent sweeps with batch groups that are not full (B % 32 != 0), several groups, the stacked class-default
-    models (set B: 4 x H180 -> 6 workgroups per group) and Paule's default H = 720 (23 workgroups per group)."""
+    models (set B: 4 x H180 -> 6 workgroups per group) and Paule's default H = 720 (23 workgroups per group); both backward
+    exchange forms (0: all-gather of dA, the default; 1: reduce-scatter of partial dh tiles)."""
+    monkeypatch.setenv("PAULE_HIP_BWD_MODE", bwd_mode)
     wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
     orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
                            objective="acoustic_semvec")
