@@ -39,13 +39,17 @@ void launch_lstm_bwd_step(hipStream_t stream, int dt, const LstmStepArgs& a);
 // One launch = all T steps of one layer (bf16, register-resident W_hh, in-launch exchange).
 struct LstmSweepArgs {
     int Bp, T;
+    int group_rows;        // batch rows per group (8..32, multiple of 8): lstm_sweep_group_rows()
     void* G;               // [T][Bp][4*Hp]: forward: W_ih x + b in, activated gates out; backward: gates in, dA out
     const void* W;         // forward: Whh [4*Hp][Hp]; backward: Whh^T [Hp][4*Hp]
     void* h;               // forward: h stash [T][Bp][Hp] (written; h_{t-1} is read back by the whole group)
     void* c;               // c stash [T][Bp][Hp] (forward writes, backward reads)
     const void* dh_ext;    // backward: dL/dh from above [T][Bp][Hp], or null
     const void* dh_last;   // backward: [Bp][Hp] applied at t = T-1 only (when dh_ext is null), or null
-    int* counters;         // [groups][T] arrival counters, zeroed before the launch
+    int* counters;         // arrival flags [groups][T][flag_stride], zeroed before the launch
+    int flag_stride;       // >= Hp / 32 (workgroups per group), multiple of 16
+    int* xcc_tab;          // [groups][64] XCD ids (+1) of the group's workgroups, zeroed with the counters
+    int xcd_fast;          // 1: groups that find themselves on one XCD hand off with plain stores (speed only)
     int* status;           // set to 1 when a bounded spin timed out (the sweep is then abandoned)
     unsigned long long spin_ticks;   // bound of every in-kernel wait, in 100 MHz s_memrealtime ticks
     unsigned long long* stamps;      // diagnostic builds (-DPL_STAMPS) only: [block][8] accumulated phase ticks
@@ -54,6 +58,7 @@ struct LstmSweepArgs {
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit
 int lstm_sweep_grid(int Hp, int Bp, int n_cu);
+int lstm_sweep_group_rows(int Hp, int Bp, int n_cu);
 void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
 // backward sweep in reduce-scatter form (lstm_persist_rs.hip): same arguments + a.xchg of lstm_rs_exchange_bytes()
 size_t lstm_rs_exchange_bytes(int Hp, int Bp);

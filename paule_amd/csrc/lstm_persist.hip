@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
     const int n_res = gridDim.x / P;             // resident groups
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
-    const int n_groups = (Bp + 31) / 32;
+    const int gs = a.group_rows;                 // batch rows per group (<= 32; the MFMA tile stays 32 wide)
+    const int n_groups = (Bp + gs - 1) / gs;
     const bf16_t* __restrict__ W = static_cast<const bf16_t*>(a.W);
 
     // weights -> registers: A-operand row (lane & 31) = gate (row >> 3), unit 32p + 8 wave + (row & 7)
@@ -73,11 +74,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
     bf16_t* __restrict__ Cs = static_cast<bf16_t*>(a.c);
 
     for (int g = g_first; g < n_groups; g += n_res) {
-        const int b = 32 * g + bl;
-        const bool ok = b < Bp;
+        const int b = gs * g + bl;
+        const bool ok = bl < gs && b < Bp;
         const int bc = ok ? b : Bp - 1;
         float c_state[4] = {0.f, 0.f, 0.f, 0.f};
-        int* cnt = a.counters + (size_t)g * T;
+        int* cnt = a.counters + (size_t)g * T * a.flag_stride;   // flags [group][step][flag_stride]
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
 
         for (int t = 0; t < T; ++t) {
             // input projection of this step (written by the preceding GEMM launch): plain loads, issued before the wait
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             PL_ST(0);   // top of step (prefetch issue)
             if (t > 0) {
-                if (!wait_arrivals(cnt + (t - 1), P, a.status, &lds_flag, a.spin_ticks)) return;
+                if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
+                if (t == 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);   // waiting for the group's arrivals
                 // h_{t-1} of the group's 32 batch rows -> LDS (sc1 loads: handed-off bytes), in two K halves: all
                 // loads are issued at once, the second half is still in flight while the first half multiplies
@@ -103,9 +107,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
                     for (int i = 0; i < NLH; ++i) {
                         const int q = tid + 256 * i;
                         const int row = q / CH, c = q % CH + hf * CH;
-                        int rb = 32 * g + row;
+                        int rb = gs * g + row;
                         rb = rb < Bp ? rb : Bp - 1;
-                        v[hf][i] = (q < 32 * CH) ? ld16_sc1(rh, (unsigned)(rb * ROWB + c * 16)) : make_uint4(0, 0, 0, 0);
+                        // rows beyond the group are never used (their MFMA columns are discarded): skip their traffic
+                        v[hf][i] = (q < 32 * CH && row < gs) ? ld16_handoff(rh, (unsigned)(rb * ROWB + c * 16), plain_handoff) : make_uint4(0, 0, 0, 0);
                     }
                 const unsigned char* bsrc = himg + bl * RS + hh * 16;
 #pragma unroll
@@ -152,9 +157,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
                 vc[u] = c_state[u];
                 vh[u] = vo[u] * tanh_fast(vc[u]);
             }
+            if (t == 0 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ok) {
                 const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
-                st8_sc1(ro, (unsigned)((b * Hp + j) * 2), pack_bf16x4(vh[0], vh[1], vh[2], vh[3]));   // hand-off first
+                st8_handoff(ro, (unsigned)((b * Hp + j) * 2), pack_bf16x4(vh[0], vh[1], vh[2], vh[3]), plain_handoff);   // hand-off first
                 asm volatile("" ::: "memory");   // keep the five stash stores behind it
                 bf16_t* go = G + (size_t)t * slabG + (size_t)b * G4 + j;
                 *reinterpret_cast<uint2*>(go) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
             PL_ST(4);   // cell update + store issue
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             PL_ST(5);   // hand-off store drain (the five stash stores stay in flight)
-            publish<5>(cnt + t);   // also orders this step's LDS reads before the next step's LDS writes
+            publish<5>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);   // also orders this step's LDS reads before the next step's LDS writes
             PL_ST(6);   // barrier + arrival add
         }
     }
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
-    const int n_groups = (Bp + 31) / 32;
+    const int gs = a.group_rows;
+    const int n_groups = (Bp + gs - 1) / gs;
     const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);
 
     // weights -> registers: wave = gate block; A-operand row = hidden unit 32p + (lane & 31); k inside the gate block
@@ -217,11 +224,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
     const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(a.dh_last);
 
     for (int g = g_first; g < n_groups; g += n_res) {
-        const int b = 32 * g + erow;
-        const bool ok = b < Bp;
+        const int b = gs * g + erow;
+        const bool ok = erow < gs && b < Bp;
         const int bc = ok ? b : Bp - 1;
         float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
-        int* cnt = a.counters + (size_t)g * T;
+        int* cnt = a.counters + (size_t)g * T * a.flag_stride;   // flags [group][step][flag_stride]
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
 
         for (int t = T - 1; t >= 0; --t) {
             // stash operands of this step (written by the forward launch): plain loads before the wait
@@ -240,7 +249,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
             unpack_bf16x4(sdh, dh);
             PL_ST(0);
             if (t + 1 < T) {
-                if (!wait_arrivals(cnt + (t + 1), P, a.status, &lds_flag, a.spin_ticks)) return;
+                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
+                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)(t + 1) * slabG, (unsigned)(slabG * 2));
                 f32x16 acc;
@@ -256,9 +266,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
                     for (int i = 0; i < kc; ++i) {
                         const int q = tid + 256 * i;
                         const int c = q % (2 * kc), row = (q / (2 * kc)) % 32, blk = q / (64 * kc);
-                        int rb = 32 * g + row;
+                        int rb = gs * g + row;
                         rb = rb < Bp ? rb : Bp - 1;
-                        v[pi % 2][i] = ld16_sc1(rg, (unsigned)((rb * G4 + blk * Hp + 16 * k0) * 2 + c * 16));
+                        v[pi % 2][i] = row < gs ? ld16_handoff(rg, (unsigned)((rb * G4 + blk * Hp + 16 * k0) * 2 + c * 16), plain_handoff)
+                                                : make_uint4(0, 0, 0, 0);
                     }
                 };
                 auto run_part = [&](auto pi_c) {
@@ -326,18 +337,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
                 dao[u] = dh[u] * tc * go[u] * (1.f - go[u]);
                 dc_next[u] = dc * gf[u];
             }
+            if (t == T - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ok) {   // dA_t overwrites the gate stash in place: the hand-off of the next (earlier) step
                 const __amdgpu_buffer_rsrc_t ro = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
                 const unsigned o = (unsigned)((b * G4 + j) * 2);
-                st8_sc1(ro, o, pack_bf16x4(dai[0], dai[1], dai[2], dai[3]));
-                st8_sc1(ro, o + Hp * 2, pack_bf16x4(daf[0], daf[1], daf[2], daf[3]));
-                st8_sc1(ro, o + 2 * Hp * 2, pack_bf16x4(dag[0], dag[1], dag[2], dag[3]));
-                st8_sc1(ro, o + 3 * Hp * 2, pack_bf16x4(dao[0], dao[1], dao[2], dao[3]));
+                st8_handoff(ro, o, pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), plain_handoff);
+                st8_handoff(ro, o + Hp * 2, pack_bf16x4(daf[0], daf[1], daf[2], daf[3]), plain_handoff);
+                st8_handoff(ro, o + 2 * Hp * 2, pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), plain_handoff);
+                st8_handoff(ro, o + 3 * Hp * 2, pack_bf16x4(dao[0], dao[1], dao[2], dao[3]), plain_handoff);
             }
             PL_ST(4);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PL_ST(5);
-            publish<0>(cnt + t);
+            publish<0>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
         }
     }
@@ -364,8 +376,18 @@ bool lstm_sweep_supported(int dt, int Hp) {
     return false;
 }
 
+// Rows per batch group: 32 (the MFMA tile width).  Smaller groups on more CUs were measured (24 rows x 11 groups = 253
+// workgroups at B = 256): the backward ingest got SLOWER (3.3 -> 3.8 us): what bounds it is the chip-wide rate of the
+// write-through hand-off traffic (P x B x 4Hp x 2 bytes per step whatever the grouping), not the per-CU rate.
+int lstm_sweep_group_rows(int Hp, int Bp, int n_cu) {
+    if (n_cu < Hp / 32) return 0;
+    return Bp < 32 ? (Bp + 7) / 8 * 8 : 32;
+}
+
 int lstm_sweep_grid(int Hp, int Bp, int n_cu) {
-    const int P = Hp / 32, groups = (Bp + 31) / 32;
+    const int P = Hp / 32, gs = lstm_sweep_group_rows(Hp, Bp, n_cu);
+    if (gs == 0) return 0;
+    const int groups = (Bp + gs - 1) / gs;
     int res = n_cu / P;
     if (res > groups) res = groups;
     if (res >= 8) res = res / 8 * 8;   // a multiple of the XCD count keeps a group's workgroups on one XCD (speed only)

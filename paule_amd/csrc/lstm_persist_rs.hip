@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
-    const int n_groups = (Bp + 31) / 32;
+    const int gs = a.group_rows;
+    const int n_groups = (Bp + gs - 1) / gs;
     const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);   // Whh^T packed [Hp][4*Hp]
 
     // weights -> registers: tile nt = wave + 4 i covers hidden columns n = 32 nt + (lane & 31); local k = 16 ks + 8 (lane >> 5) + jj
@@ -66,11 +67,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
     const size_t slot_stride = (size_t)n_groups * grp_stride;
 
     for (int g = g_first; g < n_groups; g += n_res) {
-        const int b = 32 * g + erow;
-        const bool ok = b < Bp;
+        const int b = gs * g + erow;
+        const bool ok = erow < gs && b < Bp;
         const int bc = ok ? b : Bp - 1;
         float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
-        int* cnt = a.counters + (size_t)g * T;
+        const bool plain_handoff = false;   // this variant always hands off write-through
+        int* cnt = a.counters + (size_t)g * T * a.flag_stride;   // flags [group][step][flag_stride]
 
         for (int t = T - 1; t >= 0; --t) {
             // stash operands of this step (written by the forward launch): plain loads, issued before the wait
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
             unpack_bf16x4(sdh, dh);
             PL_ST(0);
             if (t + 1 < T) {
-                if (!wait_arrivals(cnt + (t + 1), P, a.status, &lds_flag, a.spin_ticks)) return;
+                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
                 PL_ST(1);
                 // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)
                 const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 }
             }
             PL_ST(5);   // hand-off store issue
-            publish<0>(cnt + t);
+            publish<0>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);   // drain + barrier + arrival add
         }
     }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
 #define PL_SWEEP_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
 
 size_t lstm_rs_exchange_bytes(int Hp, int Bp) {
-    const size_t groups = (Bp + 31) / 32, P = Hp / 32;
+    const size_t groups = (Bp + 7) / 8, P = Hp / 32;   // upper bound on the group count (groups hold >= 8 rows)
     return 2 * groups * P * P * 32 * 32 * 2;
 }
 

@@ -100,8 +100,10 @@ struct pl_handle {
     size_t sweep_cnt_bytes = 0;
     int* sweep_status = nullptr;
     int n_cu = 0;
+    int flag_stride = 16;
     bool use_sweep = true;
     int zero_mode = 0;          // 0: own sc1 zeroing kernel, 1: hipMemsetAsync (experiments)
+    int xcd_fast = 1;           // same-XCD groups hand off with plain stores (verified at run time)
     int bwd_mode = 0;           // backward sweep: 0 all-gather of dA (default), 1 reduce-scatter of partial dh tiles (A/B variant)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
@@ -198,11 +200,15 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
             LstmSweepArgs s{};
             s.Bp = Bp;
             s.T = Tl;
+            s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
             s.G = ly.G;
             s.W = ly.Whh;
             s.h = ly.h;
             s.c = ly.c;
             s.counters = h->sweep_cnt;
+            s.flag_stride = h->flag_stride;
+            s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
+            s.xcd_fast = h->xcd_fast;
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks;
             s.stamps = h->sweep_stamps;
@@ -242,12 +248,16 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             LstmSweepArgs s{};
             s.Bp = Bp;
             s.T = Tl;
+            s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
             s.G = ly.G;
             s.W = ly.WhhT;
             s.c = ly.c;
             s.dh_ext = sparse_top ? nullptr : md.dh_ext;
             s.dh_last = sparse_top ? dh_last : nullptr;
             s.counters = h->sweep_cnt;
+            s.flag_stride = h->flag_stride;
+            s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
+            s.xcd_fast = h->xcd_fast;
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
@@ -502,6 +512,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->use_sweep = !(env && env[0] == '1');
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
         if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1) {
             size_t xb = lstm_sweep_supported(h->dt, h->pred.Hp) ? lstm_rs_exchange_bytes(h->pred.Hp, h->Bp) : 0;
             if (cfg->emb_layers > 0 && lstm_sweep_supported(h->dt, h->emb.Hp)) {
@@ -511,7 +522,11 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
         }
         if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
-        const size_t n = (size_t)((Bp + 31) / 32) * T;
+        const size_t n_groups_max = (Bp + 7) / 8;   // groups hold >= 8 rows
+        int pmax = h->pred.Hp / 32;
+        if (cfg->emb_layers > 0 && h->emb.Hp / 32 > pmax) pmax = h->emb.Hp / 32;
+        h->flag_stride = (pmax + 15) / 16 * 16;
+        const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
         if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int)))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
@@ -746,8 +761,11 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         const bool bwd = kernel == PL_KERNEL_LSTM_BWD_SWEEP;
         LstmSweepArgs s{};
         s.Bp = Bp; s.T = Tl; s.G = ly.G; s.W = bwd ? ly.WhhT : ly.Whh; s.h = ly.h; s.c = ly.c;
+        s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
         s.dh_ext = bwd ? md.dh_ext : nullptr;
         s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks;
+        s.flag_stride = h->flag_stride;
+        s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride; s.xcd_fast = h->xcd_fast;
         hipEvent_t e0, e1;
         PL_HIP(hipEventCreate(&e0));
         PL_HIP(hipEventCreate(&e1));
