@@ -162,7 +162,8 @@ def main():
         eng.synchronize()
         ms, fl = roof[names[0]]
         ms_f, fl_f = roof[names[1]]
-        kname = "lstm_bwd_sweep_kernel" if swept else "lstm_bwd_step_kernel"
+        rs = os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1"   # reduce-scatter form is the library default
+        kname = ("lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel") if swept else "lstm_bwd_step_kernel"
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
         traffic = None

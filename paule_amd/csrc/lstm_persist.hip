@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
     constexpr int NLH = (32 * CH + 255) / 256;   // loads per thread per half
     constexpr int PF = 6;                        // B-fragment read-ahead
     static_assert(KS % 2 == 0, "Hp is a multiple of 32");
+    constexpr int HRS = 64 + 16;                 // row stride of the outgoing h tile [32 rows][32 units] bf16
     __shared__ __attribute__((aligned(16))) unsigned char himg[32 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char hst[32 * HRS];
     __shared__ int lds_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,10 +160,26 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
                 vh[u] = vo[u] * tanh_fast(vc[u]);
             }
             if (t == 0 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // hand-off first: the workgroup's h tile (32 rows x 32 units) goes through LDS so that each row's 64 bytes
+            // leave as ONE instruction's contiguous piece (4 lanes x 16 B): whole sectors, which the consumers' reads
+            // of the shared L2 need (16-byte pieces from four different waves read back at half the rate)
+            *reinterpret_cast<uint2*>(hst + bl * HRS + (8 * wave + 4 * hh) * 2) = pack_bf16x4(vh[0], vh[1], vh[2], vh[3]);
+            __syncthreads();
+            if (tid < 128) {
+                const int row = tid >> 2, qt = tid & 3;
+                const int rb = gs * g + row;
+                if (row < gs && rb < Bp) {
+                    const uint4 hv = *reinterpret_cast<const uint4*>(hst + row * HRS + qt * 16);
+                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                    u32x4 d;
+                    d[0] = hv.x; d[1] = hv.y; d[2] = hv.z; d[3] = hv.w;
+                    const unsigned off = (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2);
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                }
+            }
+            asm volatile("" ::: "memory");   // keep the five stash stores behind it
             if (ok) {
-                const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
-                st8_handoff(ro, (unsigned)((b * Hp + j) * 2), pack_bf16x4(vh[0], vh[1], vh[2], vh[3]), plain_handoff);   // hand-off first
-                asm volatile("" ::: "memory");   // keep the five stash stores behind it
                 bf16_t* go = G + (size_t)t * slabG + (size_t)b * G4 + j;
                 *reinterpret_cast<uint2*>(go) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);
                 *reinterpret_cast<uint2*>(go + Hp) = pack_bf16x4(vf[0], vf[1], vf[2], vf[3]);

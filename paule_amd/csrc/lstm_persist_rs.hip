@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
         const bool ok = erow < gs && b < Bp;
         const int bc = ok ? b : Bp - 1;
         float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool plain_handoff = false;   // this variant always hands off write-through
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
         int* cnt = a.counters + (size_t)g * T * a.flag_stride;   // flags [group][step][flag_stride]
 
         for (int t = T - 1; t >= 0; --t) {
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
             PL_ST(0);
             if (t + 1 < T) {
                 if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
+                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)
                 const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 u32x2 pv[P];
 #pragma unroll
                 for (int s = 0; s < P; ++s)
-                    pv[s] = __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
+                    pv[s] = plain_handoff ? __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxNt)
+                                          : __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
 #pragma unroll
                 for (int s = 0; s < P; ++s) {
                     float f[4];
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
             }
             if (t == 0) break;   // nobody consumes the partials of step 0
+            if (t == T - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
             // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
             {
@@ -183,7 +187,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                         const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (32 * dst + 8 * c4) * 2);
                         u32x4 d;
                         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                        __builtin_amdgcn_raw_buffer_store_b128(d, ro, (unsigned)(((size_t)dst * P * TILE + (e & 127) * 8) * 2), 0, kAuxSc1);
+                        const unsigned off = (unsigned)(((size_t)dst * P * TILE + (e & 127) * 8) * 2);
+                        if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
                     }
                 }
             }

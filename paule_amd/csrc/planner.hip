@@ -103,8 +103,11 @@ struct pl_handle {
     int flag_stride = 16;
     bool use_sweep = true;
     int zero_mode = 0;          // 0: own sc1 zeroing kernel, 1: hipMemsetAsync (experiments)
-    int xcd_fast = 1;           // same-XCD groups hand off with plain stores (verified at run time)
-    int bwd_mode = 0;           // backward sweep: 0 all-gather of dA (default), 1 reduce-scatter of partial dh tiles (A/B variant)
+    int xcd_fast = 2;           // same-XCD groups hand off through the shared L2 (verified at run time): bit 0 forward, bit 1 backward
+                                // sweeps.  Default backward only: its hand-off is whole 128-byte lines (-4 % iteration time); the forward
+                                // hand-off is half lines per workgroup and reads back slower from L2 than from the memory side (+1 %)
+    int bwd_mode = 1;           // backward sweep: 1 reduce-scatter of partial dh tiles (default: 8.5 % faster iteration with the
+                                // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
     unsigned long long spin_ticks = 200000000ull;   // 2 s
@@ -208,7 +211,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
             s.counters = h->sweep_cnt;
             s.flag_stride = h->flag_stride;
             s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
-            s.xcd_fast = h->xcd_fast;
+            s.xcd_fast = h->xcd_fast & 1;
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks;
             s.stamps = h->sweep_stamps;
@@ -257,7 +260,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.counters = h->sweep_cnt;
             s.flag_stride = h->flag_stride;
             s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
-            s.xcd_fast = h->xcd_fast;
+            s.xcd_fast = (h->xcd_fast >> 1) & 1;
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
@@ -765,7 +768,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         s.dh_ext = bwd ? md.dh_ext : nullptr;
         s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks;
         s.flag_stride = h->flag_stride;
-        s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride; s.xcd_fast = h->xcd_fast;
+        s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride; s.xcd_fast = bwd ? (h->xcd_fast >> 1) & 1 : h->xcd_fast & 1;
         hipEvent_t e0, e1;
         PL_HIP(hipEventCreate(&e0));
         PL_HIP(hipEventCreate(&e1));

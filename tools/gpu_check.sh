@@ -3,6 +3,7 @@
 # Stops after a timed-out / killed step (never start another GPU step after that).
 set -o pipefail
 mkdir -p gpurun_out
+rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write   # stale profiles of earlier calls
 export TMPDIR=/tmp
 STEPS=${@:-pytest smoke bench bench_cfg2 rocprof}
 step() {  # name, timeout, command...

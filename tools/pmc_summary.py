@@ -26,7 +26,8 @@ def main():
     out_path = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, write = per_kernel(dfetch, "FETCH_SIZE"), per_kernel(dwrite, "WRITE_SIZE")
     res = {}
-    for kname, key in (("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"), ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
+    for kname, key in (("lstm_bwd_rs_sweep_kernel", "lstm_bwd_rs_sweep_kernel"), ("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"),
+                       ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
                        ("lstm_bwd_step_kernel", "lstm_bwd_step_kernel"), ("lstm_fwd_step_kernel", "lstm_fwd_step_kernel"),
                        ("gemm_nt_kernel", "gemm_nt_kernel")):
         fv = [v for k, vs in fetch.items() if kname in k for v in vs]

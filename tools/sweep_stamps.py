@@ -24,9 +24,9 @@ raw = np.fromfile(os.environ["PL_STAMP_FILE"] + ".sweep", dtype=np.uint64).resha
 for d, name, steps, labels in (
         (0, "forward sweep (embedder layer 1, 150 steps)", 150,
          ["step top/prefetch", "wait arrivals", "h tile sc1 loads+LDS", "MFMA chain", "cell+store issue", "store drain", "barrier+add"]),
-        (1, "backward sweep (pred model, 300 steps), mode " + os.environ.get("PAULE_HIP_BWD_MODE", "0"), 300,
+        (1, "backward sweep (pred model, 300 steps), mode " + os.environ.get("PAULE_HIP_BWD_MODE", "1"), 300,
          ["step top/prefetch", "wait arrivals", "partial ingest", "cell+stash+dA image", "MFMA+partial image", "hand-off store issue",
-          "drain+barrier+add"] if os.environ.get("PAULE_HIP_BWD_MODE", "0") == "1" else
+          "drain+barrier+add"] if os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1" else
          ["step top/prefetch", "wait arrivals", "dA loads+LDS+MFMA", "partial reduce", "cell+store issue", "store drain", "barrier+add"])):
     blk = raw[d]
     used = blk[blk.sum(axis=1) > 0]
