@@ -52,7 +52,8 @@ enum { PL_MODEL_PRED = 0 /* ForwardModel, paule/models.py:326 */,
 
 /* columns of one loss_log row (weighted sub-losses as logged at paule/paule.py:942-945, :988-992) */
 enum { PL_LOSS_TOTAL = 0, PL_LOSS_MEL = 1, PL_LOSS_SEMVEC = 2, PL_LOSS_VEL = 3, PL_LOSS_JERK = 4,
-       PL_LOSS_LOCAL_LINEAR = 5, PL_LOSS_COLS = 6 };
+       PL_LOSS_LOCAL_LINEAR = 5, PL_LOSS_SPEECH_CLASSIFIER = 6 /* 0 unless pl_set_speech_classifier */, PL_LOSS_RESERVED = 7,
+       PL_LOSS_COLS = 8 };
 
 typedef struct pl_handle pl_handle;
 
@@ -93,6 +94,12 @@ int pl_set_lstm_weights(pl_handle *h, int model_id, int layer, const float *w_ih
 /* post_linear [mel_dim, H] (paule/models.py:345) for PL_MODEL_PRED;
  * linear_mapping [sem_dim, H] (paule/models.py:437) for PL_MODEL_EMBED. */
 int pl_set_linear(pl_handle *h, int model_id, const float *w, const float *b);
+
+/* Optional speech-classifier term (use_speech_classifier=True; paule/models.py:887-910 LinearClassifier(60 -> 1),
+ * paule/paule.py:604-622, :914-915): z = mean_t(w . mel_t + b), loss += weight * BCEWithLogits(z, 0) = weight * softplus(z).
+ * w [mel_dim], b [1] device pointers (linear.weight / linear.bias); weight = 0.1 in the reference (paule/paule.py:596).
+ * w = NULL switches the term off. */
+int pl_set_speech_classifier(pl_handle *h, const float *w, const float *b, float weight);
 
 /* target_mel [B, T/2, mel_dim]; target_semvec [B, sem_dim] or NULL (paule/paule.py:531-540). */
 int pl_set_targets(pl_handle *h, const float *target_mel, const float *target_semvec);

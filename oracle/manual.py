@@ -173,8 +173,9 @@ class ManualModels:
         return d
 
 
-def loss_and_grad(models, objective, x, target_mel, target_semvec=None):
-    """One evaluation of the criterion and dL/dCP.  Returns (sub (B,6), grad (B,T,30), parts dict)."""
+def loss_and_grad(models, objective, x, target_mel, target_semvec=None, classifier=None):
+    """One evaluation of the criterion and dL/dCP.  Returns (sub (B,8), grad (B,T,30), parts dict).
+    classifier = (w (M,), b, weight) or None: + weight * softplus(mean_t(w . mel_t + b)) (paule/paule.py:604-622)."""
     assert objective in OBJECTIVES
     B, T, _ = x.shape
     mel, st_p = models.pred_forward(x)
@@ -192,6 +193,12 @@ def loss_and_grad(models, objective, x, target_mel, target_semvec=None):
         dmel_e = models.emb_backward(dsem, st_e, Tp)
         dmel += dmel_e
         parts.update(pred_semvec=sem, dmel_from_embedder=dmel_e)
+    cls_l = np.zeros(B)
+    if classifier is not None:
+        w, b, weight = classifier
+        z = (mel @ w + b).mean(axis=1)
+        cls_l = weight * (np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z))))
+        dmel += (weight * sigmoid(z))[:, None, None] * w[None, None, :] / Tp
     g_model = models.pred_backward(dmel, st_p, T)
     grad = g_model + g_smooth
     if objective == "acoustic":
@@ -200,7 +207,8 @@ def loss_and_grad(models, objective, x, target_mel, target_semvec=None):
         total = mel_l + vel_l + jerk_l + sem_l + ll_l
     else:
         total = vel_l + jerk_l + sem_l + ll_l
-    sub = np.stack([total, mel_l, sem_l, vel_l, jerk_l, ll_l], axis=1)
+    total = total + cls_l
+    sub = np.stack([total, mel_l, sem_l, vel_l, jerk_l, ll_l, cls_l, np.zeros(B)], axis=1)
     parts.update(grad_model=g_model, grad_smooth=g_smooth, dmel=dmel)
     return sub, grad, parts
 
@@ -237,6 +245,14 @@ class ManualPlanner:
         self.k = 0
         self.past_cp = None
         self.last_grad = None
+        self.classifier = None
+
+    def set_speech_classifier(self, classifier=None, weight=0.1):
+        if classifier is None:
+            self.classifier = None
+            return
+        sd = _np(classifier.state_dict() if hasattr(classifier, "state_dict") else classifier)
+        self.classifier = (sd["linear.weight"].reshape(-1), float(sd["linear.bias"].reshape(-1)[0]), weight)
 
     def set_targets(self, target_mel, target_semvec=None):
         self.target_mel = np.asarray(target_mel, dtype=np.float64)
@@ -258,7 +274,7 @@ class ManualPlanner:
     def step(self, n_iters=1):
         log = []
         for _ in range(n_iters):
-            sub, grad, _ = loss_and_grad(self.models, self.objective, self.x, self.target_mel, self.target_semvec)
+            sub, grad, _ = loss_and_grad(self.models, self.objective, self.x, self.target_mel, self.target_semvec, self.classifier)
             self.last_grad = grad
             log.append(sub)
             self.k += 1

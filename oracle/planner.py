@@ -24,10 +24,11 @@ VELOCITY_WEIGHT = 80.0
 JERK_WEIGHT = 400.0
 SEMANTIC_WEIGHT = 10.0
 LOCAL_LINEAR_WEIGHT = 100_000.0
+SPEECH_CLASSIFIER_WEIGHT = 0.1
 
 OBJECTIVES = ("acoustic", "acoustic_semvec", "semvec")
 # loss_log columns (weighted sub-losses, as logged at paule/paule.py:942-945, :988-992)
-LOSS_COLUMNS = ("total", "mel", "semvec", "velocity", "jerk", "local_linear")
+LOSS_COLUMNS = ("total", "mel", "semvec", "velocity", "jerk", "local_linear", "speech_classifier", "reserved")
 
 
 # --------------------------------------------------------------------------------------
@@ -116,11 +117,17 @@ def _rmse_per_utt(yhat, y):
     return torch.sqrt((d * d).flatten(1).mean(dim=1))
 
 
-def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_semvec=None):
-    """Weighted per-utterance losses -> (loss_b (B,), sub (B, 6)) (paule/paule.py:647-662, :705-717, :760-773).
+def speech_classifier_logit(pred_mel, w, b):
+    """LinearClassifier(60 -> 1).forward without src_lens (paule/models.py:899-908): mean over time of w . mel_t + b."""
+    return (pred_mel @ w + b).mean(dim=1)
+
+
+def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_semvec=None, classifier=None):
+    """Weighted per-utterance losses -> (loss_b (B,), sub (B, 8)) (paule/paule.py:647-662, :705-717, :760-773; with the
+    speech classifier :604-622, :666-683, :723-738).
 
     In the 'semvec' objective the mel loss is evaluated for logging only
-    (paule/paule.py:1021) and does not enter the objective.
+    (paule/paule.py:1021) and does not enter the objective.  classifier = (w (M,), b (), weight) or None.
     """
     vel, _, jerk = vel_acc_jerk(cps)                       # paule/paule.py:75-88 with loss=mse_loss
     vel_l = VELOCITY_WEIGHT * _mse_per_utt(vel)
@@ -139,7 +146,13 @@ def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_sem
         loss = vel_l + jerk_l + sem_l + ll_l
     else:
         raise ValueError("objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'")
-    sub = torch.stack([loss, mel_l, sem_l, vel_l, jerk_l, ll_l], dim=1)
+    cls_l = torch.zeros_like(mel_l)
+    if classifier is not None:
+        w, b, weight = classifier
+        # bce_loss(logit, zeros) (paule/paule.py:610-612) = softplus(logit), per utterance
+        cls_l = weight * torch.nn.functional.softplus(speech_classifier_logit(pred_mel, w, b))
+        loss = loss + cls_l
+    sub = torch.stack([loss, mel_l, sem_l, vel_l, jerk_l, ll_l, cls_l, torch.zeros_like(mel_l)], dim=1)
     return loss, sub
 
 
@@ -173,6 +186,17 @@ class OraclePlanner:
         self.target_mel = None
         self.target_semvec = None
         self.last_grad = None
+        self.classifier = None
+
+    def set_speech_classifier(self, classifier=None, weight=SPEECH_CLASSIFIER_WEIGHT):
+        """classifier: module / state dict with linear.weight [1, M], linear.bias [1]; None = off."""
+        if classifier is None:
+            self.classifier = None
+            return
+        sd = classifier.state_dict() if hasattr(classifier, "state_dict") else classifier
+        w = torch.as_tensor(sd["linear.weight"]).to(self.dtype).reshape(-1)
+        b = torch.as_tensor(sd["linear.bias"]).to(self.dtype).reshape(())
+        self.classifier = (w, b, weight)
 
     # -- state ------------------------------------------------------------------------
     def set_targets(self, target_mel, target_semvec=None):
@@ -219,13 +243,13 @@ class OraclePlanner:
 
     # -- iterations ---------------------------------------------------------------------
     def step(self, n_iters=1):
-        """Runs n inner iterations; returns loss_log (n_iters, B, 6) evaluated at the PRE-step CP."""
+        """Runs n inner iterations; returns loss_log (n_iters, B, 8) evaluated at the PRE-step CP."""
         log = []
         for _ in range(n_iters):
             self.optimizer.zero_grad()                                   # paule.py:911
             pred_mel, pred_semvec = self._predict(self.xx)               # :913, :921-925
             loss_b, sub = criterion(self.objective, self.xx, pred_mel, self.target_mel,
-                                    pred_semvec, self.target_semvec)     # :939 / :986 / :1020
+                                    pred_semvec, self.target_semvec, self.classifier)     # :939 / :986 / :1020
             loss_b.sum().backward()                                      # :1052
             self.last_grad = self.xx.grad.detach().clone()
             log.append(sub.detach().clone())

@@ -16,12 +16,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaule_hip.so")
 PL_F32, PL_BF16 = 0, 1
 PL_OBJ = {"acoustic": 0, "acoustic_semvec": 1, "semvec": 2}
 PL_MODEL_PRED, PL_MODEL_EMBED = 0, 1
-PL_LOSS_COLS = 6
+PL_LOSS_COLS = 8
 
 # every symbol include/paule_hip.h declares
 EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
-    "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
+    "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
     "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_last_error", "pl_version",
 )
@@ -71,6 +71,7 @@ def load_library(path: str | None = None):
     lib.pl_destroy.argtypes = [vp]
     lib.pl_set_lstm_weights.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     lib.pl_set_linear.argtypes = [vp, C.c_int, fp, fp]
+    lib.pl_set_speech_classifier.argtypes = [vp, fp, fp, C.c_float]
     lib.pl_set_targets.argtypes = [vp, fp, fp]
     lib.pl_set_cp.argtypes = [vp, fp]
     lib.pl_set_past_cp.argtypes = [vp, fp, C.c_int, C.c_int]
@@ -86,7 +87,7 @@ def load_library(path: str | None = None):
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double
     lib.pl_flops_per_iteration.argtypes = [vp]
-    for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
+    for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
                  "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize"):
         getattr(lib, name).restype = C.c_int

@@ -210,6 +210,16 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
     s = block_sum(s, sh);
     if (tid == 0) sc[0] = sqrt(s / nm);
 
+    // speech classifier logit: mean over time of Linear(60 -> 1) (paule/models.py:899-908)
+    if (a.cls_wb) {
+        s = 0.0;
+        for (int e = tid; e < nm; e += nt) s += (double)a.cls_wb[e % a.M] * (double)mel[e];
+        s = block_sum(s, sh);
+        if (tid == 0) sc[5] = s / a.Tp + (double)a.cls_wb[a.M];
+    } else if (tid == 0) {
+        sc[5] = 0.0;
+    }
+
     if (a.sem) {
         s = 0.0;
         for (int e = tid; e < a.S; e += nt) {
@@ -244,16 +254,21 @@ __global__ void loss_finalize_kernel(LossArgs a) {
     const double* sc = a.scal + (size_t)b * 8;
     const double mel = a.w_mel * sc[0], sem = a.sem ? a.w_sem * sc[1] : 0.0;
     const double vel = a.w_vel * sc[2], jerk = a.w_jerk * sc[3], ll = a.w_ll * sc[4];
-    double total = vel + jerk + ll;
+    // BCEWithLogits(z, 0) = softplus(z) (paule/paule.py:610-612), numerically stable form
+    const double z = sc[5];
+    const double cls = a.cls_wb ? a.w_cls * (fmax(z, 0.0) + log1p(exp(-fabs(z)))) : 0.0;
+    double total = vel + jerk + ll + cls;
     if (a.use_mel) total += mel;
     if (a.use_sem) total += sem;
-    float* row = a.loss_rows + ((size_t)(*a.iter_slot) * a.B + b) * 6;
+    float* row = a.loss_rows + ((size_t)(*a.iter_slot) * a.B + b) * 8;
     row[0] = (float)total;
     row[1] = (float)mel;
     row[2] = (float)sem;
     row[3] = (float)vel;
     row[4] = (float)jerk;
     row[5] = (float)ll;
+    row[6] = (float)cls;
+    row[7] = 0.f;
 }
 
 void launch_loss_finalize(hipStream_t stream, const LossArgs& a) {
@@ -304,6 +319,10 @@ __global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __re
             if (rm > 0.0) g = (double)a.w_mel * ((double)a.mel[e] - (double)a.target_mel[e]) / ((double)a.Tp * a.M * rm);
         }
         if (dmel_e) g += (double)dmel_e[((size_t)tp * a.Bp + b) * a.Mp + m];
+        if (a.cls_wb) {   // d(w_cls softplus(z))/d mel = w_cls sigmoid(z) w[m] / T'
+            const double z = a.scal[(size_t)b * 8 + 5];
+            g += (double)a.w_cls / (1.0 + exp(-z)) * (double)a.cls_wb[m] / (double)a.Tp;
+        }
         v = (float)(0.5 * g);
     }
     dY[idx] = from_f32<AT>(v);

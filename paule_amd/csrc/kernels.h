@@ -96,13 +96,15 @@ struct LossArgs {
     const float* sem;                // pred semvec f32 [Bp][Sp] (null if not evaluated)
     const float* target_sem;         // [B][S]
     double* dwork;                   // [B][3][T][C] velocity / jerk / local-linear correlations (kept for the gradient)
-    double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse
-    float* loss_rows;                // [cap][B][6] internal log
+    double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse, 5 classifier logit
+    const float* cls_wb;             // speech classifier: [M] weights then bias, or null (term off)
+    float w_cls;                     // its loss weight (0.1)
+    float* loss_rows;                // [cap][B][8] internal log
     const int* iter_slot;            // device counter: row of loss_rows written by this iteration
 };
 // per-utterance reductions (deterministic, no atomics) -> scal
 void launch_loss_reduce(hipStream_t stream, const LossArgs& a);
-// writes loss_rows[*iter_slot][b][0..5]
+// writes loss_rows[*iter_slot][b][0..7]
 void launch_loss_finalize(hipStream_t stream, const LossArgs& a);
 // dsem activation [Bp][Sp] = w_sem * (sem - target) / (S * rmse_sem)   (zero rows for b >= B, zero pad)
 void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem);

@@ -91,6 +91,9 @@ struct pl_handle {
     float* dX = nullptr;
     double *x = nullptr, *m = nullptr, *v = nullptr, *grad = nullptr, *dwork = nullptr;
     float *target_mel = nullptr, *target_sem = nullptr;
+    float* cls_wb = nullptr;    // speech classifier weights + bias
+    bool cls_on = false;
+    float w_cls = 0.1f;
     float* out_tmp = nullptr;   // [B][max(S, ...)] staging for unpadded outputs
     double* scal = nullptr;
     float* loss_rows = nullptr;
@@ -321,6 +324,7 @@ LossArgs loss_args(pl_handle* h, bool with_sem) {
     a.sem = with_sem ? h->sem : nullptr;
     a.target_sem = h->target_sem;
     a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1; a.dwork = h->dwork;
+    a.cls_wb = h->cls_on ? h->cls_wb : nullptr; a.w_cls = h->w_cls;
     return a;
 }
 
@@ -503,6 +507,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if ((rc = dev_alloc(h, &h->grad, B * T * h->C))) return bail(rc);
     if ((rc = dev_alloc(h, &h->dwork, 3 * B * T * h->C))) return bail(rc);
     if ((rc = dev_alloc(h, &h->target_mel, B * Tp * h->M))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->cls_wb, h->M + 1))) return bail(rc);
     if ((rc = dev_alloc(h, &h->scal, B * 8))) return bail(rc);
     if ((rc = dev_alloc(h, &h->loss_rows, (size_t)h->loss_cap * B * PL_LOSS_COLS))) return bail(rc);
     if ((rc = dev_alloc(h, &h->counters, 4))) return bail(rc);
@@ -590,6 +595,22 @@ int pl_set_linear(pl_handle* h, int model_id, const float* w, const float* b) {
     int rc = check_launch();
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(st));
+    return PL_OK;
+}
+
+int pl_set_speech_classifier(pl_handle* h, const float* w, const float* b, float weight) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_set_speech_classifier: NULL handle");
+    const bool on = w != nullptr;
+    if (on && !b) return fail(PL_ERR_INVALID, "pl_set_speech_classifier: bias is NULL");
+    DeviceGuard guard(h->cfg.device);
+    if (on) {
+        PL_HIP(hipMemcpyAsync(h->cls_wb, w, sizeof(float) * h->M, hipMemcpyDeviceToDevice, h->stream));
+        PL_HIP(hipMemcpyAsync(h->cls_wb + h->M, b, sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        PL_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (on != h->cls_on || weight != h->w_cls) drop_graph(h);   // kernel arguments change
+    h->cls_on = on;
+    h->w_cls = weight;
     return PL_OK;
 }
 

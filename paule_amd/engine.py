@@ -122,6 +122,19 @@ class HipPlanner:
             w, b = self._dev(sd[f"{lin}.weight"]), self._dev(sd[f"{lin}.bias"])
             self._call(self.lib.pl_set_linear, model_id, w.data_ptr(), b.data_ptr())
 
+    def set_speech_classifier(self, classifier=None, weight=0.1):
+        """LinearClassifier(mel_dim -> 1) term (paule/models.py:887-910; ``use_speech_classifier=True``): module or state
+        dict with ``linear.weight`` [1, mel_dim] and ``linear.bias`` [1]; ``None`` switches the term off."""
+        sd = _state_dict(classifier)
+        if sd is None:
+            self._call(self.lib.pl_set_speech_classifier, None, None, C.c_float(weight))
+            return
+        w = self._dev(sd["linear.weight"]).reshape(-1)
+        b = self._dev(sd["linear.bias"]).reshape(-1)
+        if w.numel() != self.M or b.numel() != 1:
+            raise ValueError("speech classifier has to be Linear(mel_dim -> 1)")
+        self._call(self.lib.pl_set_speech_classifier, w.data_ptr(), b.data_ptr(), C.c_float(weight))
+
     # ---- state --------------------------------------------------------------------------------
     def set_targets(self, target_mel, target_semvec=None):
         tm = self._dev(target_mel, (self.B, self.Tp, self.M))
@@ -147,8 +160,8 @@ class HipPlanner:
 
     # ---- the hot path -------------------------------------------------------------------------
     def step(self, n_iters=1, *, return_loss=True, return_grad=False):
-        """n inner iterations.  Returns loss_log (n_iters, B, 6) [total, mel, semvec, vel, jerk, local_linear]
-        at the pre-step CP (device tensor, stream-asynchronous) and optionally the last gradient."""
+        """n inner iterations.  Returns loss_log (n_iters, B, 8) [total, mel, semvec, vel, jerk, local_linear,
+        speech_classifier, 0] at the pre-step CP (device tensor, stream-asynchronous) and optionally the last gradient."""
         loss = torch.empty((n_iters, self.B, _capi.PL_LOSS_COLS), dtype=torch.float32, device=self.device) \
             if return_loss else None
         grad = torch.empty((self.B, self.T, self.C), dtype=torch.float32, device=self.device) if return_grad else None

@@ -38,6 +38,15 @@ PlanningResults = namedtuple(
     "pred_semvec_loss_steps, prod_semvec_loss_steps, cp_steps, pred_semvec_steps, prod_semvec_steps, grad_steps, "
     "sig_steps, prod_mel_steps, pred_mel_steps, pred_model_loss, inv_model_loss")
 
+PlanningResultsWithSpeechClassifier = namedtuple(
+    "PlanningResultsWithSpeechClassifier",
+    "planned_cp, initial_cp, initial_sig, initial_sr, initial_prod_mel, initial_pred_mel, target_sig, target_sr, "
+    "target_mel, prod_sig, prod_sr, prod_mel, pred_mel, initial_prod_semvec, initial_pred_semvec, prod_semvec, "
+    "pred_semvec, prod_loss_steps, planned_loss_steps, planned_mel_loss_steps, vel_loss_steps, jerk_loss_steps, "
+    "pred_semvec_loss_steps, prod_semvec_loss_steps, pred_speech_classifier_loss_steps, "
+    "prod_speech_classifier_loss_steps, cp_steps, pred_semvec_steps, prod_semvec_steps, grad_steps, sig_steps, "
+    "prod_mel_steps, pred_mel_steps, pred_model_loss, inv_model_loss")   # paule/paule.py:58
+
 BestSynthesisAcoustic = namedtuple("BestSynthesisAcoustic", "mel_loss, planned_cp, prod_sig, prod_mel, pred_mel")
 BestSynthesisSemantic = namedtuple("BestSynthesisSemantic", "semvec_loss, planned_cp, prod_sig, prod_semvec, pred_semvec")
 
@@ -46,9 +55,10 @@ MEL_WEIGHT = 5.0
 VELOCITY_WEIGHT = 80.0
 JERK_WEIGHT = 400.0
 SEMANTIC_WEIGHT = 10.0
+SPEECH_CLASSIFIER_WEIGHT = 0.1
 LOCAL_LINEAR_WEIGHT = 100_000
 
-_COL = dict(total=0, mel=1, semvec=2, vel=3, jerk=4, ll=5)
+_COL = dict(total=0, mel=1, semvec=2, vel=3, jerk=4, ll=5, cls=6)
 
 
 def _default_planner_factory(pred_model, embedder, **kw):
@@ -89,10 +99,13 @@ class Paule():
             raise NotImplementedError("at the moment you have to choose either to use `use_somatosenrosry_feedback=True` OR to use `use_speech_classifier=True` or none")
         if use_somatosensory_feedback:
             raise NotImplementedError("use_somatosensory_feedback is not on the MI355X planning path (SURVEY.md 8f rank 4)")
-        if use_speech_classifier:
-            raise NotImplementedError("use_speech_classifier is not on the MI355X planning path yet (SURVEY.md 8f rank 1)")
         self.use_somatosensory_feedback = False
-        self.use_speech_classifier = False
+        self.use_speech_classifier = use_speech_classifier
+        self.speech_classifier = speech_classifier
+        if use_speech_classifier and speech_classifier is None:
+            # the reference loads pretrained_models/speech_classifier/linear_model_rec_as_nonspeech.pt (paule/paule.py:215-222)
+            raise FileNotFoundError("pretrained weights are not bundled: pass speech_classifier= (a Linear(60 -> 1) module "
+                                    "or state dict with linear.weight / linear.bias, paule/models.py:887-910)")
         if pred_model is None or embedder is None:
             # the reference loads paule/pretrained_models/*.pt here (paule/paule.py:121-175); that 200 MB download
             # (paule/util.py:936-955) does not exist offline, so the models have to be handed in.
@@ -280,6 +293,11 @@ class Paule():
         self.planner = planner
         planner.set_cp(initial_cp)
         planner.reset_optimizer()                       # a fresh Adam per call (paule/paule.py:797)
+        cls_w = cls_b = None
+        if self.use_speech_classifier:                  # paule/paule.py:604-622, :914-915
+            planner.set_speech_classifier(self.speech_classifier, SPEECH_CLASSIFIER_WEIGHT)
+            sd = self.speech_classifier.state_dict() if hasattr(self.speech_classifier, "state_dict") else self.speech_classifier
+            cls_w, cls_b = _np(sd["linear.weight"]).reshape(-1).astype(np.float64), float(_np(sd["linear.bias"]).reshape(-1)[0])
         if past_cp is not None:
             planner.set_past_cp(past_cp)
 
@@ -317,6 +335,7 @@ class Paule():
         vel_loss_steps, jerk_loss_steps, pred_semvec_loss_steps, prod_semvec_loss_steps = [], [], [], []
         cp_steps, pred_semvec_steps, prod_semvec_steps, grad_steps, sig_steps = [], [], [], [], []
         pred_mel_steps, prod_mel_steps, pred_model_loss, inv_model_loss = [], [], [], []
+        pred_speech_classifier_loss_steps, prod_speech_classifier_loss_steps = [], []
         sig = sr = prod_mel = None
         pred_mel = initial_pred_mel
         squeeze = (lambda a: a[-1]) if B == 1 else (lambda a: a)
@@ -333,6 +352,8 @@ class Paule():
                 print("Local Linear Loss: ", _scalar_or_vec(row[:, _COL["ll"]]))
                 if objective != "acoustic":
                     print("Semvec Loss: ", _scalar_or_vec(row[:, _COL["semvec"]]))
+                if self.use_speech_classifier:
+                    print("Speech Classifier Loss: ", _scalar_or_vec(row[:, _COL["cls"]]))
 
         def run(n, first_ii):
             """n plain iterations (no log step inside)"""
@@ -374,6 +395,8 @@ class Paule():
                 planned_mel_loss_steps.append(_scalar_or_vec(row[:, _COL["mel"]]))
                 vel_loss_steps.append(_scalar_or_vec(row[:, _COL["vel"]]))
                 jerk_loss_steps.append(_scalar_or_vec(row[:, _COL["jerk"]]))
+                if self.use_speech_classifier:
+                    pred_speech_classifier_loss_steps.append(_scalar_or_vec(row[:, _COL["cls"]]))
                 if objective != "acoustic":
                     pred_semvec_loss_steps.append(_scalar_or_vec(row[:, _COL["semvec"]]))
                 elif log_semantics and pred_semvec is not None:
@@ -390,6 +413,10 @@ class Paule():
                     prod_mel_steps_ii.append(squeeze(prod_mel))
                     prod_loss = MEL_WEIGHT * _rmse_rows(prod_mel, target_mel)
                     prod_loss_steps.append(_scalar_or_vec(prod_loss))
+                    if self.use_speech_classifier:      # paule/paule.py:1114-1122, on the host (log steps only)
+                        z = (prod_mel @ cls_w + cls_b).mean(axis=1)
+                        prod_speech_classifier_loss_steps.append(_scalar_or_vec(
+                            SPEECH_CLASSIFIER_WEIGHT * (np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z))))))
                     if verbose:
                         print("Produced Mel Loss: ", _scalar_or_vec(prod_loss))
                     new_ac = BestSynthesisAcoustic(float(prod_loss.mean()), xx_pre, sig, prod_mel, pred_mel)
@@ -437,6 +464,15 @@ class Paule():
         prod_semvec = _np(planner.embed_mel(prod_mel)) if prod_mel is not None else None
         sq = (lambda a: None if a is None else a[-1]) if B == 1 else (lambda a: a)
         sqs = (lambda s: None if s is None else s[0]) if B == 1 else (lambda s: s)
+        if self.use_speech_classifier:
+            return PlanningResultsWithSpeechClassifier(
+                sq(planned_cp), sq(initial_cp), sqs(initial_sig), initial_sr, sq(initial_prod_mel), sq(initial_pred_mel),
+                target_sig, target_sr, sq(target_mel), sqs(sig), sr, sq(prod_mel), sq(pred_mel),
+                sq(initial_prod_semvec), sq(initial_pred_semvec), sq(prod_semvec), sq(pred_semvec),
+                prod_loss_steps, planned_loss_steps, planned_mel_loss_steps, vel_loss_steps, jerk_loss_steps,
+                pred_semvec_loss_steps, prod_semvec_loss_steps, pred_speech_classifier_loss_steps,
+                prod_speech_classifier_loss_steps, cp_steps, pred_semvec_steps, prod_semvec_steps,
+                grad_steps, sig_steps, prod_mel_steps, pred_mel_steps, pred_model_loss, inv_model_loss)
         return PlanningResults(
             sq(planned_cp), sq(initial_cp), sqs(initial_sig), initial_sr, sq(initial_prod_mel), sq(initial_pred_mel),
             target_sig, target_sr, sq(target_mel), sqs(sig), sr, sq(prod_mel), sq(pred_mel),

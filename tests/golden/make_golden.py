@@ -58,8 +58,13 @@ def load_reference():
 MEL_WEIGHT, VELOCITY_WEIGHT, JERK_WEIGHT, SEMANTIC_WEIGHT, LOCAL_LINEAR_WEIGHT = 5.0, 80.0, 400.0, 10.0, 100_000
 
 
-def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, cps):
-    """The plain criterion closures (paule/paule.py:647-662, :705-717, :760-773) on ONE utterance."""
+SPEECH_CLASSIFIER_WEIGHT = 0.1
+bce_loss = torch.nn.BCEWithLogitsLoss()   # paule/paule.py:71
+
+
+def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, cps, pred_speech_classifier=None):
+    """The criterion closures (paule/paule.py:647-662, :705-717, :760-773; with the speech classifier :604-622,
+    :666-683) on ONE utterance."""
     rmse_loss, mse_loss = ns["rmse_loss"], ns["mse_loss"]
     velocity_loss, jerk_loss = ns["velocity_jerk_loss"](cps, loss=mse_loss)
     ll = ns["local_linear"](cps)
@@ -77,11 +82,17 @@ def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semve
         loss = mel_loss + velocity_loss + jerk_loss + semvec_loss + local_linear_loss
     else:
         loss = velocity_loss + jerk_loss + semvec_loss + local_linear_loss
-    return loss, torch.stack([loss, mel_loss, semvec_loss, velocity_loss, jerk_loss, local_linear_loss])
+    speech_classifier_loss = torch.zeros((), dtype=cps.dtype)
+    if pred_speech_classifier is not None:                                # paule/paule.py:610-612, :619, :621
+        speech_classifier_loss = SPEECH_CLASSIFIER_WEIGHT * bce_loss(
+            pred_speech_classifier, torch.zeros_like(pred_speech_classifier, dtype=pred_speech_classifier.dtype))
+        loss = loss + speech_classifier_loss
+    return loss, torch.stack([loss, mel_loss, semvec_loss, velocity_loss, jerk_loss, local_linear_loss,
+                              speech_classifier_loss, torch.zeros((), dtype=cps.dtype)])
 
 
 def ref_plan_one(ns, pred_model, embedder, objective, cp0, target_mel, target_semvec, n_iters, lr=0.01,
-                 smiling=False, past_cp=None, snapshots=()):
+                 smiling=False, past_cp=None, snapshots=(), speech_classifier=None):
     """Inner loop for ONE utterance exactly as the reference runs it (batch 1, paule/paule.py:585-588)."""
     xx_new = cp0.clone().view(1, *cp0.shape).requires_grad_()          # :585-590
     target_mel = target_mel.view(1, *target_mel.shape)
@@ -96,7 +107,9 @@ def ref_plan_one(ns, pred_model, embedder, objective, cp0, target_mel, target_se
             seq_length = pred_mel.shape[1]
             embedder = embedder.train()
             pred_semvec = embedder(pred_mel, (torch.tensor(seq_length),))
-        discrepancy, sub = ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, xx_new)
+        pred_speech_classifier = speech_classifier(pred_mel) if speech_classifier is not None else None   # :914-915
+        discrepancy, sub = ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, xx_new,
+                                         pred_speech_classifier)
         log.append(sub.detach().clone())
         discrepancy.backward()                                          # :1052
         if ii + 1 in snapshots:
@@ -157,9 +170,17 @@ def main():
         out["fwd/embed_lens"] = np.array([20, 13, 7])
         out["fwd/embed_semvec_lens"] = em(wl.target_mel, [torch.tensor(20), torch.tensor(13), torch.tensor(7)]).numpy()
     past = wl.cp0[0, :6].clone() * 0.5
+    torch.manual_seed(synthetic.SEED + 7)
+    clf = ref_models.LinearClassifier(input_dim=60, output_dim=1).double()   # paule/paule.py:215 architecture, random init
+    with torch.no_grad():
+        clf.linear.weight.mul_(3.0)                                          # a logit far enough from 0 to matter
+        clf.linear.bias.fill_(0.4)
+    out["clf/linear.weight"] = clf.linear.weight.detach().numpy()
+    out["clf/linear.bias"] = clf.linear.bias.detach().numpy()
     cases = {"acoustic": dict(objective="acoustic"), "acoustic_semvec": dict(objective="acoustic_semvec"),
              "semvec": dict(objective="semvec"), "smiling": dict(objective="acoustic_semvec", smiling=True),
-             "past_cp": dict(objective="acoustic", past_cp=past)}
+             "past_cp": dict(objective="acoustic", past_cp=past),
+             "classifier": dict(objective="acoustic_semvec", speech_classifier=clf)}
     out["past_cp"] = past.numpy()
     for name, kw in cases.items():   # level (iv): trajectories, one reference run per utterance
         logs, cps, grads = [], {k: [] for k in SNAP}, {k: [] for k in SNAP}
@@ -167,7 +188,8 @@ def main():
         for b in range(B):
             log, snaps, gr, fmel, fsem = ref_plan_one(ns, pm, em, kw["objective"], wl.cp0[b], wl.target_mel[b],
                                                       wl.target_semvec[b], 20, smiling=kw.get("smiling", False),
-                                                      past_cp=kw.get("past_cp"), snapshots=SNAP)
+                                                      past_cp=kw.get("past_cp"), snapshots=SNAP,
+                                                      speech_classifier=kw.get("speech_classifier"))
             logs.append(log)
             fm.append(fmel)
             fs.append(fsem)

@@ -25,6 +25,7 @@ class OracleEngine:
         if old is not None:
             self.p.xx, self.p.optimizer = old.xx, old.optimizer
             self.p.target_mel, self.p.target_semvec, self.p.past_cp = old.target_mel, old.target_semvec, old.past_cp
+            self.p.classifier = old.classifier
 
     def set_weights(self, pred_model=None, embedder=None):
         sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
@@ -39,6 +40,9 @@ class OracleEngine:
 
     def set_cp(self, cp):
         self.p.set_cp(np.asarray(cp))
+
+    def set_speech_classifier(self, classifier=None, weight=0.1):
+        self.p.set_speech_classifier(classifier, weight)
 
     def set_past_cp(self, past):
         self.p.set_past_cp(past)

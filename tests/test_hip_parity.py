@@ -19,7 +19,7 @@ CP_ATOL_F32, LOSS_RTOL_F32, FWD_ATOL_F32 = 1e-5, 1e-5, 2e-5
 LOSS_RTOL_BF16, COS_BF16 = 2e-2, 0.999
 CASES = {"acoustic": dict(objective="acoustic"), "acoustic_semvec": dict(objective="acoustic_semvec"),
          "semvec": dict(objective="semvec"), "smiling": dict(objective="acoustic_semvec", smiling=True),
-         "past_cp": dict(objective="acoustic")}
+         "past_cp": dict(objective="acoustic"), "classifier": dict(objective="acoustic_semvec")}
 
 
 @pytest.fixture(scope="module")
@@ -45,6 +45,8 @@ def _engine(HipPlanner, g, name, dtype="f32", **extra):
     eng.set_cp(g["cp0"])
     if name == "past_cp":
         eng.set_past_cp(g["past_cp"])
+    if name == "classifier":
+        eng.set_speech_classifier(state_dict_from(g, "clf"))
     return eng
 
 

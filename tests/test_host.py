@@ -107,6 +107,22 @@ def test_batched_targets_and_hooks(small):
     assert model.best_synthesis_acoustic.mel_loss < np.inf
 
 
+def test_speech_classifier_config(small):
+    """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
+    clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}
+    with pytest.raises(FileNotFoundError):
+        pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, use_speech_classifier=True)
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory, device=torch.device("cpu"),
+                     use_speech_classifier=True, speech_classifier=clf)
+    res = model.plan_resynth(target_acoustic=small.target_mel[0].numpy(), initial_cp=small.cp0[0].numpy(),
+                             initialize_from=None, objective="acoustic_semvec", n_outer=1, n_inner=4, log_ii=2,
+                             continue_learning=False, verbose=False)
+    assert type(res).__name__ == "PlanningResultsWithSpeechClassifier" and len(res) == 35
+    assert len(res.pred_speech_classifier_loss_steps) == 2 and all(v > 0 for v in res.pred_speech_classifier_loss_steps)
+    ref = model.plan_resynth   # the logged total contains the classifier term
+    assert res.planned_loss_steps[0] > res.planned_mel_loss_steps[0] + res.pred_speech_classifier_loss_steps[0]
+
+
 def test_shard_bounds():
     assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert [shard_bounds(2048, r, 8) for r in range(8)][-1] == (1792, 2048)

@@ -12,7 +12,7 @@ from paule_amd import synthetic
 TOL = 1e-12
 CASES = {"acoustic": dict(objective="acoustic"), "acoustic_semvec": dict(objective="acoustic_semvec"),
          "semvec": dict(objective="semvec"), "smiling": dict(objective="acoustic_semvec", smiling=True),
-         "past_cp": dict(objective="acoustic")}
+         "past_cp": dict(objective="acoustic"), "classifier": dict(objective="acoustic_semvec")}
 
 
 def _close(a, b, tol=TOL):
@@ -32,6 +32,8 @@ def _planners(g, name):
         pl.set_targets(g["target_mel"], g["target_semvec"])
         pl.set_cp(g["cp0"])
         pl.set_past_cp(past)
+        if name == "classifier":
+            pl.set_speech_classifier(state_dict_from(g, "clf"))
     return P, M
 
 
