@@ -215,11 +215,13 @@ def test_bf16_sweep_equals_per_step_kernels(golden_small, monkeypatch):
 
 
 @pytest.mark.parametrize("bwd_mode", ["0", "1"])
-@pytest.mark.parametrize("shape", [dict(B=40, T=30, set="B"), dict(B=70, T=24, set="A")])
+@pytest.mark.parametrize("shape", [dict(B=40, T=30, set="B"), dict(B=70, T=24, set="A"), dict(B=270, T=17, set="A")])
 def test_bf16_sweep_ragged_groups_vs_oracle(HipPlanner, shape, bwd_mode, monkeypatch):
     """Persistent sweeps with batch groups that are not full (B % 32 != 0), several groups, the stacked class-default
-    models (set B: 4 x H180 -> 6 workgroups per group) and Paule's default H = 720 (23 workgroups per group); both backward
-    exchange forms (0: all-gather of dA, the default; 1: reduce-scatter of partial dh tiles)."""
+    models (set B: 4 x H180 -> 6 workgroups per group) and Paule's default H = 720 (23 workgroups per group); more groups
+    than fit on the chip at once (B = 270 -> 9 groups, 8 resident: the ninth is swept by the same workgroups afterwards),
+    odd T (last frame dropped); both backward exchange forms (1: reduce-scatter of partial dh tiles, the default;
+    0: all-gather of dA)."""
     monkeypatch.setenv("PAULE_HIP_BWD_MODE", bwd_mode)
     wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
     orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
@@ -231,7 +233,11 @@ def test_bf16_sweep_ragged_groups_vs_oracle(HipPlanner, shape, bwd_mode, monkeyp
         pl.set_cp(wl.cp0)
     lo, lh = _n(orc.step(4)), _n(eng.step(4))
     eng.synchronize()
-    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_BF16, atol=1e-4)
+    # small weighted terms (velocity ~0.05) carry bf16 noise of the same absolute size as the large ones
+    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
+    # Adam is sign-like where the gradient is bf16 noise: single coordinates may flip (bounded by lr per step), the bulk agrees
+    dcp = np.abs(_n(eng.get_cp()) - _n(orc.get_cp()))
+    assert dcp.max() <= 0.5 * 0.01 * 4 and dcp.mean() <= 1e-4, (dcp.max(), dcp.mean())
 
 
 def test_bf16_model_gradients_in_isolation(HipPlanner, golden_small):
