@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const AT* __restrict__ A, 
                                                       const float* __restrict__ bias, OT* __restrict__ C, int ldc, int M,
                                                       int N, int K, int n_blocks_n) {
     using TG = TileGemm<AT, BM, BN, WM, WN>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TG::LDS_BYTES];
+    constexpr int EPI_BYTES = (sizeof(OT) == 2 && WM == 64 && WN == 64) ? 4 * 64 * (64 * 2 + 16) : 0;   // transposed-epilogue tiles
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TG::LDS_BYTES > EPI_BYTES ? TG::LDS_BYTES : EPI_BYTES];
     const int bid = blockIdx.x;
     const int m0 = (bid / n_blocks_n) * BM;
     const int n0 = (bid % n_blocks_n) * BN;
@@ -29,6 +30,36 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const AT* __restrict__ A, 
     TG::run(arow, wrow, K, acc, lds);
 
     const auto cd = TG::coord();
+    if constexpr (sizeof(OT) == 2 && WM == 64 && WN == 64) {
+        // bf16 output: the MFMA C layout gives a lane one column x 4 rows per tile (2-byte stores, 32-byte segments: the
+        // output-heavy projections ran at 2 TB/s).  Transpose each wave's 64 x 64 tile through LDS (free after the main
+        // loop) and store whole 128-byte rows as 16-byte pieces.
+        constexpr int RS = 64 * 2 + 16;   // row stride: odd number of 16-byte chunks
+        static_assert(4 * 64 * RS <= EPI_BYTES, "epilogue tiles fit the LDS array");
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        unsigned char* tile = lds + wave * 64 * RS;
+#pragma unroll
+        for (int j = 0; j < TG::TN; ++j) {
+            const int n = n0 + cd.n(j);
+            const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TG::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<OT*>(tile + (i * 16 + cd.kq * 4 + r) * RS + (j * 16 + cd.lr) * 2) =
+                        from_f32<OT>(acc[i][j][r] + bv);
+        }
+        __syncthreads();
+        const int mw = m0 + cd.wm * WM, nw = n0 + cd.wn * WN;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cid = lane + 64 * q, row = cid >> 3, c8 = cid & 7;
+            const int m = mw + row, n = nw + c8 * 8;
+            if (m < M && n < N)   // N is a multiple of 16: a chunk is whole or absent
+                *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = *reinterpret_cast<const uint4*>(tile + row * RS + c8 * 16);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TG::TN; ++j) {
         const int n = n0 + cd.n(j);
@@ -59,7 +90,7 @@ static void launch_typed(hipStream_t stream, const void* A, int lda, const void*
     if (N <= 32)
         launch_cfg<AT, OT, 256, 32, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
     else if (N <= 64)
-        launch_cfg<AT, OT, 256, 64, 64, 64>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        launch_cfg<AT, OT, 128, 64, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);   // 2 x 2 waves of 64 x 32
     else
         launch_cfg<AT, OT, 128, 128, 64, 64>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
 }

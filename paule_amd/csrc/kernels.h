@@ -52,6 +52,7 @@ struct LstmSweepArgs {
     int xcd_fast;          // 1: groups that find themselves on one XCD hand off with plain stores (speed only)
     int* status;           // set to 1 when a bounded spin timed out (the sweep is then abandoned)
     unsigned long long spin_ticks;   // bound of every in-kernel wait, in 100 MHz s_memrealtime ticks
+    unsigned poll_mask;              // the abort / timeout check runs on polls with (n & poll_mask) == 0
     unsigned long long* stamps;      // diagnostic builds (-DPL_STAMPS) only: [block][8] accumulated phase ticks
     void* xchg;            // reduce-scatter backward only: partial-tile exchange [2 slots][groups][P][32 rows][Hp]
 };

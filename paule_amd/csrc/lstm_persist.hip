@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             PL_ST(0);   // top of step (prefetch issue)
             if (t > 0) {
-                if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
+                if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
                 if (t == 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);   // waiting for the group's arrivals
                 // h_{t-1} of the group's 32 batch rows -> LDS (sc1 loads: handed-off bytes), in two K halves: all
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_kernel(LstmSweepArgs a)
             unpack_bf16x4(sdh, dh);
             PL_ST(0);
             if (t + 1 < T) {
-                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
+                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
                 if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)(t + 1) * slabG, (unsigned)(slabG * 2));

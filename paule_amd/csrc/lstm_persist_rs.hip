@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
             unpack_bf16x4(sdh, dh);
             PL_ST(0);
             if (t + 1 < T) {
-                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks)) return;
+                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
                 if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)

@@ -114,6 +114,7 @@ struct pl_handle {
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
     unsigned long long spin_ticks = 200000000ull;   // 2 s
+    unsigned poll_mask = 63u;
     double* past = nullptr;
     int past_len = 0, past_per_utt = 0;
     hipGraph_t graph = nullptr;
@@ -216,7 +217,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
             s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
             s.xcd_fast = h->xcd_fast & 1;
             s.status = h->sweep_status;
-            s.spin_ticks = h->spin_ticks;
+            s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps;
             zero_sweep_counters(h, st);
             launch_lstm_sweep(st, false, Hp, sweep_grid, s);
@@ -265,7 +266,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
             s.xcd_fast = (h->xcd_fast >> 1) & 1;
             s.status = h->sweep_status;
-            s.spin_ticks = h->spin_ticks;
+            s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
             s.xchg = h->sweep_xchg;
             zero_sweep_counters(h, st);
@@ -521,6 +522,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1) {
             size_t xb = lstm_sweep_supported(h->dt, h->pred.Hp) ? lstm_rs_exchange_bytes(h->pred.Hp, h->Bp) : 0;
             if (cfg->emb_layers > 0 && lstm_sweep_supported(h->dt, h->emb.Hp)) {
@@ -787,7 +789,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         s.Bp = Bp; s.T = Tl; s.G = ly.G; s.W = bwd ? ly.WhhT : ly.Whh; s.h = ly.h; s.c = ly.c;
         s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
         s.dh_ext = bwd ? md.dh_ext : nullptr;
-        s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks;
+        s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
         s.flag_stride = h->flag_stride;
         s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride; s.xcd_fast = bwd ? (h->xcd_fast >> 1) & 1 : h->xcd_fast & 1;
         hipEvent_t e0, e1;

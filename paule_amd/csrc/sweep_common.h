@@ -87,22 +87,22 @@ __device__ __forceinline__ void st8_handoff(__amdgpu_buffer_rsrc_t r, unsigned o
 // (an L2 round trip instead of two memory-side ones: the wait drops from ~1.2 to ~0.5 us per step).
 // Bounded: on a timeout the status word is set and every workgroup leaves.  Ends with a barrier.
 __device__ __forceinline__ bool wait_arrivals(const int* flags, int P, bool same_xcd, int* status, int* lds_flag,
-                                              unsigned long long spin_ticks) {
+                                              unsigned long long spin_ticks, unsigned poll_mask = 63u) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(flags, (unsigned)(P * 4));
         int ok = 1;
-        for (;;) {
+        for (unsigned spin = 1;; ++spin) {
             int v = 1;
-            if (lane < P) {
-                const __amdgpu_buffer_rsrc_t rf = make_rsrc(flags, (unsigned)(P * 4));
+            if (lane < P)
                 v = same_xcd ? (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, 2 /* nt */)
                              : (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
-            }
             if (__all(v != 0)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                __builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+            // the abort / timeout check costs a second memory round trip: only every 64th poll
+            if ((spin & poll_mask) == 0 &&
+                (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                 __builtin_amdgcn_s_memrealtime() - t0 > spin_ticks)) {
                 ok = 0;
                 break;
             }
