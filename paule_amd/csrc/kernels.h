@@ -55,6 +55,11 @@ struct LstmSweepArgs {
     unsigned poll_mask;              // the abort / timeout check runs on polls with (n & poll_mask) == 0
     unsigned long long* stamps;      // diagnostic builds (-DPL_STAMPS) only: [block][8] accumulated phase ticks
     void* xchg;            // reduce-scatter backward only: partial-tile exchange [2 slots][groups][P][32 rows][Hp]
+    // forward, fused input projection (narrow inputs, in_p = 32 / 64): null x_in = G holds the precomputed projection
+    const void* x_in;      // layer input, time-major [T][Bp][in_p]
+    const void* Wih;       // packed [4*Hp][in_p]
+    const float* bias;     // b_ih + b_hh, [4*Hp]
+    int in_p;
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit

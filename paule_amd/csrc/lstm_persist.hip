@@ -34,9 +34,13 @@ namespace pl {
 // ---------------------------------------------------------------------------------------------------
 // forward sweep
 // ---------------------------------------------------------------------------------------------------
-template <int KS>   // KS = Hp / 16 MFMA k-steps
+// KSX > 0: the input projection W_ih x_t + b is fused (layers with a narrow input: CP 32, mel 64 columns): the group's
+// x_t tile rides along as KSX extra k-steps, the bias initialises the accumulator, and the batched projection GEMM
+// with its [T][Bp][4Hp] write + read-back disappears.  KSX = 0: G holds the precomputed projection.
+template <int KS, int KSX>   // KS = Hp / 16, KSX = in_p / 16 MFMA k-steps
 __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
+    constexpr int XRS = KSX * 32 + 16;           // row stride of the x_t image [32 rows][in_p] bf16
     constexpr int ROWB = Hp * 2;                 // bytes of one h row
     constexpr int RS = ROWB + 16;                // LDS row stride: odd number of 16-byte chunks -> conflict-free b128 reads
     constexpr int KSH = KS / 2;                  // k-steps per K half
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
     constexpr int HRS = 64 + 16;                 // row stride of the outgoing h tile [32 rows][32 units] bf16
     __shared__ __attribute__((aligned(16))) unsigned char himg[32 * RS];
     __shared__ __attribute__((aligned(16))) unsigned char hst[32 * HRS];
+    __shared__ __attribute__((aligned(16))) unsigned char ximg[KSX ? 32 * XRS : 16];
     __shared__ int lds_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,8 +71,19 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wreg[ks] = *reinterpret_cast<const uint4*>(wrow + 16 * ks);
     }
-
     const int bl = lane & 31, hh = lane >> 5;
+    uint4 wx[KSX ? KSX : 1];
+    float bias_r[16];
+    if constexpr (KSX > 0) {
+        constexpr int INP = 16 * KSX;
+        const int ar = lane & 31;
+        const bf16_t* xrow = static_cast<const bf16_t*>(a.Wih) + (size_t)((ar >> 3) * Hp + 32 * p + 8 * wave + (ar & 7)) * INP + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) wx[ks] = *reinterpret_cast<const uint4*>(xrow + 16 * ks);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[(r >> 2) * Hp + 32 * p + 8 * wave + 4 * hh + (r & 3)];
+    }
+
     const int j = 32 * p + 8 * wave + 4 * hh;     // this lane's 4 hidden units
     PL_ST_DECL
     const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
@@ -85,15 +101,30 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
         bool plain_handoff = false;
 
         for (int t = 0; t < T; ++t) {
-            // input projection of this step (written by the preceding GEMM launch): plain loads, issued before the wait
-            const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
-            uint2 gx[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gx[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
-
+            // input projection of this step: either precomputed (G, written by the preceding GEMM launch) or fused: both are
+            // plain loads of data from earlier launches, issued before the wait
+            uint2 gx[4] = {};
             f32x16 acc;
+            if constexpr (KSX > 0) {
+                constexpr int INP = 16 * KSX, XC = INP / 8;     // 16-byte chunks per x row
+                if (tid < 32 * XC) {
+                    const int row = tid / XC, c = tid % XC;
+                    int rb = gs * g + row;
+                    rb = rb < Bp ? rb : Bp - 1;
+                    const uint4 xv = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x_in) +
+                                                                     ((size_t)t * Bp + rb) * INP + c * 8);
+                    *reinterpret_cast<uint4*>(ximg + row * XRS + c * 16) = xv;
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+                if (t == 0) __syncthreads();   // later steps: the barrier of the arrival wait publishes the x image
+            } else {
+                const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gx[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
             PL_ST(0);   // top of step (prefetch issue)
             if (t > 0) {
                 if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
@@ -141,6 +172,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
                 }
             }
 
+            if constexpr (KSX > 0) {
+#pragma unroll
+                for (int ks = 0; ks < KSX; ++ks) {
+                    const uint4 xb = *reinterpret_cast<const uint4*>(ximg + bl * XRS + ks * 32 + hh * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wx[ks]),
+                                                                  __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+                }
+            }
             PL_ST(3);   // MFMA chain
             // cell update: acc[4 * gate + unit]
             float gxi[4], gxf[4], gxg[4], gxo[4];
@@ -413,11 +452,14 @@ int lstm_sweep_grid(int Hp, int Bp, int n_cu) {
 }
 
 void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a) {
-#define PL_CASE(K)                                                                                          \
-    if (Hp == 16 * K) {                                                                                     \
-        if (backward) hipLaunchKernelGGL(lstm_bwd_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);    \
-        else hipLaunchKernelGGL(lstm_fwd_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);             \
-        return;                                                                                             \
+    const int ksx = (!backward && a.x_in) ? a.in_p / 16 : 0;   // fused input projection (in_p = 32 or 64)
+#define PL_CASE(K)                                                                                               \
+    if (Hp == 16 * K) {                                                                                          \
+        if (backward) hipLaunchKernelGGL(lstm_bwd_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);         \
+        else if (ksx == 2) hipLaunchKernelGGL((lstm_fwd_sweep_kernel<K, 2>), dim3(grid), dim3(256), 0, stream, a); \
+        else if (ksx == 4) hipLaunchKernelGGL((lstm_fwd_sweep_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a); \
+        else hipLaunchKernelGGL((lstm_fwd_sweep_kernel<K, 0>), dim3(grid), dim3(256), 0, stream, a);             \
+        return;                                                                                                  \
     }
     PL_SWEEP_KS_LIST(PL_CASE)
 #undef PL_CASE

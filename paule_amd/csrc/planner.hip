@@ -104,6 +104,7 @@ struct pl_handle {
     int* sweep_status = nullptr;
     int n_cu = 0;
     int flag_stride = 16;
+    bool fuse_input = true;     // fuse narrow input projections into the forward sweeps
     bool use_sweep = true;
     int zero_mode = 0;          // 0: own sc1 zeroing kernel, 1: hipMemsetAsync (experiments)
     int xcd_fast = 2;           // same-XCD groups hand off through the shared L2 (verified at run time): bit 0 forward, bit 1 backward
@@ -200,9 +201,12 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
     const void* cur_in = in_act;
     for (int l = 0; l < md.L; ++l) {
         LstmLayer& ly = md.layers[l];
-        // input projection for every time step at once: G = in * Wih^T + (b_ih + b_hh)
-        launch_gemm_nt(st, h->dt, false, cur_in, ly.in_p, ly.Wih, ly.in_p, ly.bias, ly.G, 4 * Hp, Tl * Bp, 4 * Hp, ly.in_p);
         const int sweep_grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        // narrow inputs (CP, mel): the persistent sweep computes W_ih x_t + b itself; otherwise one batched GEMM for all
+        // time steps: G = in * Wih^T + (b_ih + b_hh)
+        const bool fuse_in = sweep_grid > 0 && h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
+        if (!fuse_in)
+            launch_gemm_nt(st, h->dt, false, cur_in, ly.in_p, ly.Wih, ly.in_p, ly.bias, ly.G, 4 * Hp, Tl * Bp, 4 * Hp, ly.in_p);
         if (sweep_grid > 0) {
             LstmSweepArgs s{};
             s.Bp = Bp;
@@ -212,6 +216,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
             s.W = ly.Whh;
             s.h = ly.h;
             s.c = ly.c;
+            if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
             s.counters = h->sweep_cnt;
             s.flag_stride = h->flag_stride;
             s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
@@ -523,6 +528,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
         if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1) {
             size_t xb = lstm_sweep_supported(h->dt, h->pred.Hp) ? lstm_rs_exchange_bytes(h->pred.Hp, h->Bp) : 0;
             if (cfg->emb_layers > 0 && lstm_sweep_supported(h->dt, h->emb.Hp)) {
