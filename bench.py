@@ -146,9 +146,9 @@ def main():
         progress(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
         it_s = world * args.steps / elapsed
         flops_it = eng.flops_per_iteration
-        # dominant kernel: the LSTM backward sweep of the predictive model (one launch = T steps; bf16) or, on the
-        # f32 path, the launch-per-step backward kernel.  Timed with hipEvents on the engine's own stream.
-        swept = cfg["dtype"] == "bf16"
+        # dominant kernel: the LSTM backward sweep of the predictive model (one launch = T steps), or the launch-per-step
+        # backward kernel when the sweeps are switched off / unsupported.  Timed with hipEvents on the engine's stream.
+        swept = True
         names = ("bwd_sweep", "fwd_sweep") if swept else ("bwd", "fwd")
         roof = {}
         for name in names:
@@ -163,7 +163,12 @@ def main():
         ms, fl = roof[names[0]]
         ms_f, fl_f = roof[names[1]]
         rs = os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1"   # reduce-scatter form is the library default
-        kname = ("lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel") if swept else "lstm_bwd_step_kernel"
+        if not swept:
+            kname = "lstm_bwd_step_kernel"
+        elif cfg["dtype"] == "f32":
+            kname = "lstm_bwd_sweep_f32_kernel"
+        else:
+            kname = "lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel"
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
         traffic = None

@@ -69,6 +69,11 @@ void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, cons
 // backward sweep in reduce-scatter form (lstm_persist_rs.hip): same arguments + a.xchg of lstm_rs_exchange_bytes()
 size_t lstm_rs_exchange_bytes(int Hp, int Bp);
 void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a);
+// f32 sweeps (lstm_persist_f32.hip): groups of 16 rows, Hp / 16 workgroups per group, backward in reduce-scatter form
+bool lstm_sweep_f32_supported(int Hp);
+int lstm_sweep_f32_grid(int Hp, int Bp, int n_cu);
+size_t lstm_f32_exchange_bytes(int Hp, int Bp);
+void launch_lstm_sweep_f32(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
 // zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
 void launch_zero_counters(hipStream_t stream, int* p, int n);
 

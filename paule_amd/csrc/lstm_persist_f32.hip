@@ -1,0 +1,360 @@
+// Persistent LSTM layer sweeps, f32 (exact `v_mfma_f32_16x16x4_f32`): ONE launch runs all T time steps of one layer.
+//
+// Same idea as the bf16 sweeps (lstm_persist.hip / lstm_persist_rs.hip): W_hh never leaves registers, only the
+// recurrent operand moves, in-launch exchange with arrival flags (sweep_common.h).  f32 MFMA is 16x slower than
+// bf16, so the work is cut finer to spread it over the chip: groups of 16 batch rows, one workgroup per 16 hidden
+// units (P = Hp / 16 workgroups per group: 46 at H = 720; B = 64 fills 184 CUs).
+//   forward : wave w owns 4 hidden units x 4 gates = 16 gate rows, ordered [unit slot q (4)][gate (4)] so that the
+//             C layout (row = 4 (lane >> 4) + reg, col = lane & 15) leaves a lane with the four gates of ONE unit of
+//             one batch row.  A / B fragments are 16-byte (4 k) pieces feeding 4 consecutive MFMAs with the same
+//             permuted k order on both operands.  184 weight VGPRs per lane at H = 720.
+//   backward: reduce-scatter form: a workgroup multiplies the dA it produced itself (64 gate rows, from LDS) with its
+//             64 rows of W_hh -> its f32 partial of dh for all Hp units, 46 tiles of 16 x 16, stored straight from
+//             the accumulators (a lane's 4 registers = 16 contiguous bytes of a tile row); a workgroup then sums the
+//             46 partial tiles of its own units.  Partials stay f32: the only rounding difference to the
+//             launch-per-step kernels is the summation order.
+#include "sweep_common.h"
+
+namespace pl {
+
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ uint4 ld16_ho(__amdgpu_buffer_rsrc_t r, unsigned off, bool same_xcd) { return ld16_handoff(r, off, same_xcd); }
+
+__device__ __forceinline__ void st16_handoff(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v, bool plain) {
+    u32x4 d;
+    d[0] = __builtin_bit_cast(unsigned, v.x);
+    d[1] = __builtin_bit_cast(unsigned, v.y);
+    d[2] = __builtin_bit_cast(unsigned, v.z);
+    d[3] = __builtin_bit_cast(unsigned, v.w);
+    if (plain) __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, kAuxSc1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward sweep (all-gather of h); KSX > 0: input projection fused (in_p = 16 * KSX = 32 / 64)
+// ---------------------------------------------------------------------------------------------------
+template <int KS, int KSX>   // KS = Hp / 16
+__global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int ROWB = Hp * 4;                 // bytes of one h row
+    constexpr int RS = ROWB + 16;                // LDS row stride: Hp / 4 + 1 chunks (odd): conflict-free b128 reads
+    constexpr int CPR = Hp / 4;                  // 16-byte chunks per row
+    constexpr int NLD = (16 * CPR + 255) / 256;  // loads per thread per step
+    constexpr int PF = 4;                        // B-fragment read-ahead (16-k chunks)
+    constexpr int HRS = 64 + 16;                 // outgoing h tile [16 rows][16 units] f32
+    constexpr int XRS = KSX * 64 + 16;           // x_t image [16 rows][in_p] f32
+    __shared__ __attribute__((aligned(16))) unsigned char himg[16 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char hst[16 * HRS];
+    __shared__ __attribute__((aligned(16))) unsigned char ximg[KSX ? 16 * XRS : 16];
+    __shared__ int lds_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int P = KS;                        // workgroups per group
+    const int n_res = gridDim.x / P;
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int n_groups = (Bp + 15) / 16;         // Bp is a multiple of 16: groups are whole
+    const float* __restrict__ W = static_cast<const float*>(a.W);
+    const int kq = lane >> 4;
+
+    // weights -> registers: A row r (= lane & 15): unit slot r >> 2, gate r & 3
+    float4 wreg[KS];
+    {
+        const int r = lane & 15;
+        const float* wrow = W + (size_t)((r & 3) * Hp + 16 * p + 4 * wave + (r >> 2)) * Hp + 4 * kq;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wreg[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
+    }
+    // epilogue ownership (C layout): batch column lane & 15, unit 16p + 4 wave + (lane >> 4), gate = accumulator register
+    const int bl = lane & 15;
+    const int j = 16 * p + 4 * wave + kq;
+    float4 wx[KSX ? KSX : 1];
+    f32x4 bias_r = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KSX > 0) {
+        constexpr int INP = 16 * KSX;
+        const int r = lane & 15;
+        const float* xrow = static_cast<const float*>(a.Wih) + (size_t)((r & 3) * Hp + 16 * p + 4 * wave + (r >> 2)) * INP + 4 * kq;
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) wx[s] = *reinterpret_cast<const float4*>(xrow + 16 * s);
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) bias_r[gate] = a.bias[gate * Hp + j];
+    }
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    float* __restrict__ G = static_cast<float*>(a.G);
+    float* __restrict__ Hs = static_cast<float*>(a.h);
+    float* __restrict__ Cs = static_cast<float*>(a.c);
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = 16 * g + bl;
+        float c_state = 0.f;
+        int* cnt = a.counters + (size_t)g * T * a.flag_stride;
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
+
+        for (int t = 0; t < T; ++t) {
+            float gx[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc;
+            if constexpr (KSX > 0) {
+                constexpr int INP = 16 * KSX, XC = INP / 4;
+                if (tid < 16 * XC) {
+                    const int row = tid / XC, c = tid % XC;
+                    const uint4 xv = *reinterpret_cast<const uint4*>(static_cast<const float*>(a.x_in) +
+                                                                     ((size_t)t * Bp + 16 * g + row) * INP + c * 4);
+                    *reinterpret_cast<uint4*>(ximg + row * XRS + c * 16) = xv;
+                }
+                acc = bias_r;
+                if (t == 0) __syncthreads();
+            } else {
+                const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) gx[gate] = g_row[gate * Hp];
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            PL_ST(0);
+            if (t > 0) {
+                if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
+                if (t == 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+                PL_ST(1);
+                const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t - 1) * slabH, (unsigned)(slabH * 4));
+                uint4 v[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int e = tid + 256 * i;
+                    v[i] = (e < 16 * CPR) ? ld16_ho(rh, (unsigned)((16 * g + e / CPR) * ROWB + (e % CPR) * 16), plain_handoff)
+                                          : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int e = tid + 256 * i;
+                    if (e < 16 * CPR) *reinterpret_cast<uint4*>(himg + (e / CPR) * RS + (e % CPR) * 16) = v[i];
+                }
+                __syncthreads();
+                PL_ST(2);
+                const unsigned char* bsrc = himg + bl * RS + kq * 16;
+                float4 bq[PF];
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (i < KS) bq[i] = *reinterpret_cast<const float4*>(bsrc + i * 64);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc = mfma4(wreg[s], bq[s % PF], acc);
+                    if (s + PF < KS) bq[s % PF] = *reinterpret_cast<const float4*>(bsrc + (s + PF) * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (KSX > 0) {
+#pragma unroll
+                for (int s = 0; s < KSX; ++s)
+                    acc = mfma4(wx[s], *reinterpret_cast<const float4*>(ximg + bl * XRS + s * 64 + kq * 16), acc);
+            }
+            PL_ST(3);
+
+            // cell (libm forms: the f32 path carries the 1e-5 parity bar)
+            const float vi = sigmoid_f(acc[0] + gx[0]), vf = sigmoid_f(acc[1] + gx[1]);
+            const float vg = tanhf(acc[2] + gx[2]), vo = sigmoid_f(acc[3] + gx[3]);
+            c_state = vf * c_state + vi * vg;
+            const float vh = vo * tanhf(c_state);
+            if (t == 0 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // hand-off first: the workgroup's h tile (16 rows x 16 units) leaves as whole 64-byte row pieces
+            *reinterpret_cast<float*>(hst + bl * HRS + (4 * wave + kq) * 4) = vh;
+            __syncthreads();
+            if (tid < 64) {
+                const int row = tid >> 2, qt = tid & 3;
+                const float4 hv = *reinterpret_cast<const float4*>(hst + row * HRS + qt * 16);
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 4));
+                st16_handoff(ro, (unsigned)(((16 * g + row) * Hp + 16 * p + 4 * qt) * 4), hv, plain_handoff);
+            }
+            asm volatile("" ::: "memory");   // keep the five stash stores behind it
+            {
+                float* go = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                go[0] = vi;
+                go[Hp] = vf;
+                go[2 * Hp] = vg;
+                go[3 * Hp] = vo;
+                Cs[(size_t)t * slabH + (size_t)b * Hp + j] = c_state;
+            }
+            PL_ST(4);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            PL_ST(5);
+            publish<5>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
+            PL_ST(6);
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward sweep, reduce-scatter of f32 partial dh tiles (backward-DATA only)
+// ---------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int P = KS;                        // workgroups per group = N tiles of 16 hidden units
+    constexpr int NT = (P + 3) / 4;              // N tiles per wave (wave w: tiles w, w + 4, ...)
+    constexpr int DRS = 64 * 4 + 16;             // dA^T image [16 batch rows][64 local gate rows] f32
+    __shared__ __attribute__((aligned(16))) unsigned char da_img[16 * DRS];
+    __shared__ int lds_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_res = gridDim.x / P;
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int n_groups = (Bp + 15) / 16;
+    const float* __restrict__ WT = static_cast<const float*>(a.W);   // Whh^T packed [Hp][4*Hp]
+    const int kq = lane >> 4;
+
+    // weights -> registers: tile nt = wave + 4 i: A row = hidden column n = 16 nt + (lane & 15); chunk c = gate c:
+    // k = 4 kq + e  <->  gate row c * Hp + 16 p + 4 kq + e
+    float4 wreg[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nt = wave + 4 * i;
+        const int n = 16 * (nt < P ? nt : 0) + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wreg[i][c] = *reinterpret_cast<const float4*>(WT + (size_t)n * G4 + c * Hp + 16 * p + 4 * kq);
+    }
+
+    // cell ownership: thread -> batch row tid >> 4, unit 16p + (tid & 15)
+    const int erow = tid >> 4, eu = tid & 15;
+    const int j = 16 * p + eu;
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    float* __restrict__ G = static_cast<float*>(a.G);
+    const float* __restrict__ Cs = static_cast<const float*>(a.c);
+    const float* __restrict__ dhe = static_cast<const float*>(a.dh_ext);
+    const float* __restrict__ dhl = static_cast<const float*>(a.dh_last);
+    // exchange [2 slots][groups][P destinations][P sources][16 rows][16 columns] f32 (1-KB tiles)
+    float* __restrict__ X = static_cast<float*>(a.xchg);
+    constexpr size_t TILE = 16 * 16;
+    const size_t grp_stride = (size_t)P * P * TILE;
+    const size_t slot_stride = (size_t)n_groups * grp_stride;
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = 16 * g + erow;
+        float dc_next = 0.f;
+        int* cnt = a.counters + (size_t)g * T * a.flag_stride;
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
+
+        for (int t = T - 1; t >= 0; --t) {
+            const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
+            const float gi = g_row[0], gf = g_row[Hp], gg = g_row[2 * Hp], go = g_row[3 * Hp];
+            const float c = Cs[(size_t)t * slabH + (size_t)b * Hp + j];
+            const float cp = t > 0 ? Cs[(size_t)(t - 1) * slabH + (size_t)b * Hp + j] : 0.f;
+            float dh = 0.f;
+            if (dhe) dh = dhe[(size_t)t * slabH + (size_t)b * Hp + j];
+            else if (dhl && t == T - 1) dh = dhl[(size_t)b * Hp + j];
+            PL_ST(0);
+            if (t + 1 < T) {
+                if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
+                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+                PL_ST(1);
+                const float* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 4));
+                const unsigned o0 = (unsigned)((erow * 16 + eu) * 4);
+                unsigned pv[P];
+#pragma unroll
+                for (int s = 0; s < P; ++s)
+                    pv[s] = plain_handoff ? __builtin_amdgcn_raw_buffer_load_b32(rx, o0 + (unsigned)(s * TILE * 4), 0, kAuxNt)
+                                          : __builtin_amdgcn_raw_buffer_load_b32(rx, o0 + (unsigned)(s * TILE * 4), 0, kAuxSc1);
+#pragma unroll
+                for (int s = 0; s < P; ++s) dh += __builtin_bit_cast(float, pv[s]);
+            }
+            PL_ST(2);
+
+            const float tc = tanhf(c);
+            const float dc = dc_next + dh * go * (1.f - tc * tc);
+            const float dai = dc * gg * gi * (1.f - gi);
+            const float daf = dc * cp * gf * (1.f - gf);
+            const float dag = dc * gi * (1.f - gg * gg);
+            const float dao = dh * tc * go * (1.f - go);
+            dc_next = dc * gf;
+            {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                float* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                go_[0] = dai;
+                go_[Hp] = daf;
+                go_[2 * Hp] = dag;
+                go_[3 * Hp] = dao;
+            }
+            if (t == 0) break;   // nobody consumes the partials of step 0
+            if (t == T - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 16 + unit]
+                float* drow = reinterpret_cast<float*>(da_img + erow * DRS) + eu;
+                drow[0] = dai;
+                drow[16] = daf;
+                drow[32] = dag;
+                drow[48] = dao;
+            }
+            __syncthreads();
+            PL_ST(3);
+            float4 bfr[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) bfr[c4] = *reinterpret_cast<const float4*>(da_img + (lane & 15) * DRS + c4 * 64 + kq * 16);
+            float* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 4));
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int nt = wave + 4 * i;
+                if (nt >= P) break;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) acc = mfma4(wreg[i][c4], bfr[c4], acc);
+                // acc[r] = partial[n = 16 nt + 4 kq + r][batch lane & 15]: a lane's 4 registers are 16 contiguous bytes of tile row b
+                st16_handoff(ro, (unsigned)(((size_t)nt * P * TILE + (lane & 15) * 16 + 4 * kq) * 4),
+                             make_float4(acc[0], acc[1], acc[2], acc[3]), plain_handoff);
+            }
+            PL_ST(4);
+            publish<0>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
+            PL_ST(6);
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define PL_SWEEP_F32_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
+
+bool lstm_sweep_f32_supported(int Hp) {
+#define PL_CASE(K) if (Hp == 16 * K) return true;
+    PL_SWEEP_F32_KS_LIST(PL_CASE)
+#undef PL_CASE
+    return false;
+}
+
+int lstm_sweep_f32_grid(int Hp, int Bp, int n_cu) {
+    const int P = Hp / 16, groups = (Bp + 15) / 16;
+    int res = n_cu / P;
+    if (res > groups) res = groups;
+    if (res >= 8) res = res / 8 * 8;
+    return res < 1 ? 0 : res * P;
+}
+
+size_t lstm_f32_exchange_bytes(int Hp, int Bp) {
+    const size_t groups = (Bp + 15) / 16, P = Hp / 16;
+    return 2 * groups * P * P * 16 * 16 * 4;
+}
+
+void launch_lstm_sweep_f32(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a) {
+    const int ksx = (!backward && a.x_in) ? a.in_p / 16 : 0;
+#define PL_CASE(K)                                                                                                      \
+    if (Hp == 16 * K) {                                                                                                 \
+        if (backward) hipLaunchKernelGGL(lstm_bwd_sweep_f32_kernel<K>, dim3(grid), dim3(256), 0, stream, a);            \
+        else if (ksx == 2) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 2>), dim3(grid), dim3(256), 0, stream, a);  \
+        else if (ksx == 4) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a);  \
+        else hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 0>), dim3(grid), dim3(256), 0, stream, a);                \
+        return;                                                                                                         \
+    }
+    PL_SWEEP_F32_KS_LIST(PL_CASE)
+#undef PL_CASE
+}
+
+}  // namespace pl

@@ -113,6 +113,7 @@ struct pl_handle {
     int bwd_mode = 1;           // backward sweep: 1 reduce-scatter of partial dh tiles (default: 8.5 % faster iteration with the
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
+    bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
     unsigned long long spin_ticks = 200000000ull;   // 2 s
     unsigned poll_mask = 63u;
@@ -194,6 +195,22 @@ void zero_sweep_counters(pl_handle* h, hipStream_t st) {
         launch_zero_counters(st, h->sweep_cnt, (int)(h->sweep_cnt_bytes / sizeof(int)));
 }
 
+// persistent-sweep dispatch by arithmetic type: grid 0 = launch-per-step kernels
+int sweep_grid_for(pl_handle* h, int Hp) {
+    if (!h->use_sweep) return 0;
+    if (h->dt == F32) return (h->f32_sweep && lstm_sweep_f32_supported(Hp)) ? lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu) : 0;
+    return lstm_sweep_supported(h->dt, Hp) ? lstm_sweep_grid(Hp, h->Bp, h->n_cu) : 0;
+}
+int sweep_group_rows_for(pl_handle* h, int Hp) { return h->dt == F32 ? 16 : lstm_sweep_group_rows(Hp, h->Bp, h->n_cu); }
+void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, const LstmSweepArgs& s) {
+    if (h->dt == F32)
+        launch_lstm_sweep_f32(st, bwd, Hp, grid, s);
+    else if (bwd && h->bwd_mode == 1 && h->sweep_xchg)
+        launch_lstm_bwd_rs_sweep(st, Hp, grid, s);
+    else
+        launch_lstm_sweep(st, bwd, Hp, grid, s);
+}
+
 // stacked LSTM forward over all Tl steps; in_act = time-major [Tl][Bp][in_p]
 void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) {
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
@@ -201,7 +218,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
     const void* cur_in = in_act;
     for (int l = 0; l < md.L; ++l) {
         LstmLayer& ly = md.layers[l];
-        const int sweep_grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        const int sweep_grid = sweep_grid_for(h, Hp);
         // narrow inputs (CP, mel): the persistent sweep computes W_ih x_t + b itself; otherwise one batched GEMM for all
         // time steps: G = in * Wih^T + (b_ih + b_hh)
         const bool fuse_in = sweep_grid > 0 && h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
@@ -211,7 +228,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
             LstmSweepArgs s{};
             s.Bp = Bp;
             s.T = Tl;
-            s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
+            s.group_rows = sweep_group_rows_for(h, Hp);
             s.G = ly.G;
             s.W = ly.Whh;
             s.h = ly.h;
@@ -225,7 +242,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps;
             zero_sweep_counters(h, st);
-            launch_lstm_sweep(st, false, Hp, sweep_grid, s);
+            launch_sweep(h, st, false, Hp, sweep_grid, s);
             cur_in = ly.h;
             continue;
         }
@@ -255,12 +272,12 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
     for (int l = md.L - 1; l >= 0; --l) {
         LstmLayer& ly = md.layers[l];
         const bool sparse_top = (l == md.L - 1) && dh_last;
-        const int sweep_grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        const int sweep_grid = sweep_grid_for(h, Hp);
         if (sweep_grid > 0) {
             LstmSweepArgs s{};
             s.Bp = Bp;
             s.T = Tl;
-            s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
+            s.group_rows = sweep_group_rows_for(h, Hp);
             s.G = ly.G;
             s.W = ly.WhhT;
             s.c = ly.c;
@@ -275,10 +292,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
             s.xchg = h->sweep_xchg;
             zero_sweep_counters(h, st);
-            if (h->bwd_mode == 1 && h->sweep_xchg)
-                launch_lstm_bwd_rs_sweep(st, Hp, sweep_grid, s);
-            else
-                launch_lstm_sweep(st, true, Hp, sweep_grid, s);
+            launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
             LstmStepArgs s{};
@@ -529,6 +543,15 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
+        if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
+            size_t xb = lstm_sweep_f32_supported(h->pred.Hp) ? lstm_f32_exchange_bytes(h->pred.Hp, h->Bp) : 0;
+            if (cfg->emb_layers > 0 && lstm_sweep_f32_supported(h->emb.Hp)) {
+                const size_t xe = lstm_f32_exchange_bytes(h->emb.Hp, h->Bp);
+                xb = xb > xe ? xb : xe;
+            }
+            if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
+        }
         if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1) {
             size_t xb = lstm_sweep_supported(h->dt, h->pred.Hp) ? lstm_rs_exchange_bytes(h->pred.Hp, h->Bp) : 0;
             if (cfg->emb_layers > 0 && lstm_sweep_supported(h->dt, h->emb.Hp)) {
@@ -539,8 +562,9 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         }
         if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
         const size_t n_groups_max = (Bp + 7) / 8;   // groups hold >= 8 rows
-        int pmax = h->pred.Hp / 32;
-        if (cfg->emb_layers > 0 && h->emb.Hp / 32 > pmax) pmax = h->emb.Hp / 32;
+        const int slice = h->dt == F32 ? 16 : 32;   // hidden units per workgroup
+        int pmax = h->pred.Hp / slice;
+        if (cfg->emb_layers > 0 && h->emb.Hp / slice > pmax) pmax = h->emb.Hp / slice;
         h->flag_stride = (pmax + 15) / 16 * 16;
         const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
@@ -788,12 +812,12 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
     const size_t a = h->act;
     if (kernel >= PL_KERNEL_LSTM_FWD_SWEEP) {
-        const int grid = (h->use_sweep && lstm_sweep_supported(h->dt, Hp)) ? lstm_sweep_grid(Hp, Bp, h->n_cu) : 0;
+        const int grid = sweep_grid_for(h, Hp);
         if (grid <= 0) return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: the persistent sweep is not used for this dtype / shape");
         const bool bwd = kernel == PL_KERNEL_LSTM_BWD_SWEEP;
         LstmSweepArgs s{};
         s.Bp = Bp; s.T = Tl; s.G = ly.G; s.W = bwd ? ly.WhhT : ly.Whh; s.h = ly.h; s.c = ly.c;
-        s.group_rows = lstm_sweep_group_rows(Hp, Bp, h->n_cu);
+        s.group_rows = sweep_group_rows_for(h, Hp);
         s.dh_ext = bwd ? md.dh_ext : nullptr;
         s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
         s.flag_stride = h->flag_stride;
@@ -805,10 +829,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         s.xchg = h->sweep_xchg;
         for (int i = 0; i < reps; ++i) {
             zero_sweep_counters(h, h->stream);
-            if (bwd && h->bwd_mode == 1 && h->sweep_xchg)
-                launch_lstm_bwd_rs_sweep(h->stream, Hp, grid, s);
-            else
-                launch_lstm_sweep(h->stream, bwd, Hp, grid, s);
+            launch_sweep(h, h->stream, bwd, Hp, grid, s);
         }
         PL_HIP(hipEventRecord(e1, h->stream));
         PL_HIP(hipEventSynchronize(e1));

@@ -157,6 +157,32 @@ def test_ragged_shapes_vs_oracle_f32(HipPlanner, shape):
     np.testing.assert_allclose(_n(eng.get_cp()), _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
 
 
+@pytest.mark.parametrize("shape", [dict(B=100, T=21, set="A"), dict(B=37, T=26, set="B")])
+def test_f32_sweep_many_groups_vs_oracle_and_per_step(shape, monkeypatch):
+    """f32 persistent sweeps (groups of 16 rows, Hp / 16 workgroups per group: 46 at H = 720, so 5 groups are resident
+    on 256 CUs and B = 100 -> 7 groups makes the same workgroups sweep a second group), against the oracle at the f32
+    bar, and against the launch-per-step kernels (PAULE_HIP_F32_SWEEP=0; only the dh summation order differs)."""
+    from paule_amd.engine import HipPlanner
+    wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    orc.set_targets(wl.target_mel, wl.target_semvec)
+    orc.set_cp(wl.cp0)
+    lo, co = _n(orc.step(6)), _n(orc.get_cp())
+    outs = []
+    for sweep in ("1", "0"):
+        monkeypatch.setenv("PAULE_HIP_F32_SWEEP", sweep)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=shape["B"], n_frames=shape["T"], objective="acoustic_semvec")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        lh = _n(eng.step(6))
+        eng.synchronize()
+        np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7, err_msg=f"sweep={sweep}")
+        np.testing.assert_allclose(_n(eng.get_cp()), co, atol=CP_ATOL_F32, rtol=0, err_msg=f"sweep={sweep}")
+        outs.append(lh)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=LOSS_RTOL_F32, atol=1e-7)
+
+
 def test_optimizer_state_persists_and_resets(HipPlanner, golden_small):
     """Adam state continues across pl_step calls (= outer iterations, paule/paule.py:797) and resets on request."""
     g = golden_small

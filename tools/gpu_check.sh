@@ -20,6 +20,7 @@ step() {  # name, timeout, command...
 for s in $STEPS; do
   case $s in
     pytest) step pytest_gpu 900 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider ;;
+    pytest_k) step pytest_k 600 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider -k "${PYTEST_K:-f32}" ;;
     smoke) step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) step bench 400 python bench.py --steps 10 --warmup 2 ;;
     bench_cfg2) step bench_cfg2 300 python bench.py --config cfg2 --steps 10 --warmup 2 --no-cpu-baseline ;;
