@@ -150,4 +150,23 @@ void launch_act_to_f32(hipStream_t stream, int dt, const void* src, float* dst, 
 // strip padding: src f32 [Bp][Sp] -> dst [B][S]
 void launch_unpad_rows(hipStream_t stream, const float* src, int B, int S, int Sp, float* dst);
 
+// ---- continued learning of the predictive model (train.hip) ------------------------------------------------------
+// C[M][N] (f32) = sum over t < Tk, b < nb of A[(tA0 + t) * Bp + b][m] * B[(tB0 + t) * Bp + b][n]; nb multiple of 16, M, N of 8
+void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
+                    int Bp, int nb, int Tk, int tA0, int tB0);
+// out[c] = sum over the same rows of A[.][c]
+void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* out);
+// scal[0] = sqrt(mean((pred - target)^2)) over n elements (f64), scal[1] = the sum of squares; loss_out (device f32) optional
+void launch_train_rmse(hipStream_t stream, const float* pred, const float* target, int64_t n, double* scal, float* loss_out);
+void launch_train_dy(hipStream_t stream, int dt, const float* pred, const float* target, const double* scal, int n_rows, int T, int Tp,
+                     int M, int Bp, int Mp, void* dY);
+struct AdamHyper {
+    double lr, b1, b2, eps, bc1, bc2;   // bc = 1 - beta^k of the step being taken
+};
+void launch_adam_matrix(hipStream_t stream, int dt, const float* grad, int nblk, int R, int C, int Rp, int Cp, double* x, double* am,
+                        double* av, void* W, void* WT, const AdamHyper& hp);
+void launch_adam_bias(hipStream_t stream, const float* grad, int nblk, int R, int Rp, double* x0, double* am0, double* av0, double* x1,
+                      double* am1, double* av1, float* packed, const AdamHyper& hp);
+void launch_f64_to_f32_rows(hipStream_t stream, const double* src, float* dst, int64_t n);
+
 }  // namespace pl

@@ -330,12 +330,17 @@ bool lstm_sweep_f32_supported(int Hp) {
     return false;
 }
 
+// Workgroups to launch, 0 = use the launch-per-step kernels.  A workgroup sweeps its groups one after the other
+// (~7 us per step each), the launch-per-step kernels take ~24-28 us per step whatever the batch (they stream the f32
+// weights every step): measured break-even is 4 rounds (B = 256 at H = 720: 36.6 vs 34.4 ms per iteration).
 int lstm_sweep_f32_grid(int Hp, int Bp, int n_cu) {
     const int P = Hp / 16, groups = (Bp + 15) / 16;
     int res = n_cu / P;
+    if (res < 1) return 0;
     if (res > groups) res = groups;
     if (res >= 8) res = res / 8 * 8;
-    return res < 1 ? 0 : res * P;
+    if ((groups + res - 1) / res > 3) return 0;
+    return res * P;
 }
 
 size_t lstm_f32_exchange_bytes(int Hp, int Bp) {
