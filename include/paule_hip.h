@@ -129,6 +129,28 @@ int pl_get_pred(pl_handle *h, float *pred_mel_out, float *pred_semvec_out);
  * lens [B] int32 device pointer or NULL (= T/2 for every utterance, paule/paule.py:922-924). */
 int pl_embed_mel(pl_handle *h, const float *mel, const int32_t *lens, float *semvec_out);
 
+/* ---- continued learning of the predictive model (paule/paule.py:1353-1379) ---------------------
+ * One optimiser step of `pred_model` on a mini-batch, entirely on the device, replacing
+ *     Y_hat = self.pred_model(batch_input, lens_input_j); self.pred_optimizer.zero_grad()
+ *     pred_loss = self.pred_criterion(Y_hat, batch_output); pred_loss.backward(); self.pred_optimizer.step()
+ * (paule/paule.py:1372-1377) with pred_criterion = RMSELoss(eps=0) over the whole batch (:288) and
+ * pred_optimizer = torch.optim.Adam (:287; lr = learning_rate_learning, :473-474).
+ *   n_rows      samples of the mini-batch, 1 <= n_rows <= batch; all of length T (same_size_batching, :1356-1358)
+ *   cp          [n_rows, T, cp_dim]     batch_input  (cp_norm of produced samples)
+ *   mel_target  [n_rows, T/2, mel_dim]  batch_output (melspec_norm_synthesized)
+ *   loss_out    device float or NULL: pred_loss of this step (before the update)
+ * The handle keeps f64 masters of every parameter and the Adam moments; the packed compute copies the planner reads
+ * are refreshed by the same launch sequence, so the next pl_step / pl_get_pred uses the new weights (no re-upload,
+ * contrast paule/paule.py:1372-1377 mutating pred_model in place).  Stream-asynchronous.  Clobbers only scratch. */
+int pl_train_pred_step(pl_handle *h, int n_rows, const float *cp, const float *mel_target, float lr, float beta1,
+                       float beta2, float eps, float *loss_out);
+/* Fresh torch.optim.Adam state for the parameters (moments = 0, step count = 0). */
+int pl_reset_pred_optimizer(pl_handle *h);
+/* Current parameters in torch layout (the layouts of pl_set_lstm_weights / pl_set_linear), float32 device pointers:
+ * how the host's torch module is brought back in sync after continued learning. */
+int pl_get_lstm_weights(pl_handle *h, int model_id, int layer, float *w_ih, float *w_hh, float *b_ih, float *b_hh);
+int pl_get_linear(pl_handle *h, int model_id, float *w, float *b);
+
 /* Test / debugging aid: copies a named internal buffer, converted to float32, into out (device pointer).
  * Returns the element count through *n_out; out may be NULL to query the size only. */
 int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems, int64_t *n_out);

@@ -8,6 +8,8 @@ Follows the reference line by line in *behaviour* (not in text):
                  :617-637 (vel/acc/jerk = stencil applied 1x/2x/3x)
 * criterion    : paule/paule.py:592-597 (weights), :647-662 / :705-717 / :760-773
 * loop         : paule/paule.py:797 (Adam), :911-913, :921-925, :1052, :1199-1211
+* continued learning of the predictive model (``OracleTrainer``): paule/paule.py:287-288
+  (Adam on the parameters, RMSE criterion), :1372-1377 (one mini-batch step)
 
 Batch rule: the reference plans exactly one utterance
 (paule/paule.py:585-588).  For B > 1 every loss is reduced per utterance and the
@@ -262,3 +264,37 @@ class OraclePlanner:
                 if self.past_cp is not None:
                     self.xx.data[:, 0:self.past_cp.shape[-2], :] = self.past_cp
         return torch.stack(log)
+
+
+# --------------------------------------------------------------------------------------
+# continued learning of the predictive model
+# --------------------------------------------------------------------------------------
+class OracleTrainer:
+    """One ``pred_optimizer`` step per call on the CPU (torch autograd + torch.optim.Adam), as in the mini-batch loop of
+    paule/paule.py:1372-1377 with ``pred_optimizer = Adam(pred_model.parameters(), lr=0.001)`` (:287) and
+    ``pred_criterion = rmse_loss`` (:288; RMSELoss(eps=0) over the whole batch, paule/util.py:564-572)."""
+
+    def __init__(self, pred_model, *, lr=0.001, betas=(0.9, 0.999), eps=1e-8, dtype=torch.float64):
+        self.pred_model = pred_model.to(dtype)
+        self.dtype = dtype
+        for p in self.pred_model.parameters():
+            p.requires_grad_(True)
+        self.optimizer = torch.optim.Adam(self.pred_model.parameters(), lr=lr, betas=betas, eps=eps)
+
+    def train_pred_step(self, cp, mel_target):
+        batch_input = torch.as_tensor(cp).to(self.dtype)
+        batch_output = torch.as_tensor(mel_target).to(self.dtype)
+        if batch_input.dim() == 2:
+            batch_input, batch_output = batch_input[None], batch_output[None]
+        y_hat = self.pred_model(batch_input)                                  # :1372
+        self.optimizer.zero_grad()                                            # :1374
+        pred_loss = torch.sqrt(torch.mean((y_hat - batch_output) ** 2))       # :1375, RMSELoss(eps=0)
+        pred_loss.backward()                                                  # :1376
+        self.optimizer.step()                                                 # :1377
+        return pred_loss.detach()
+
+    def gradients(self):
+        return {k: p.grad.detach().clone() for k, p in self.pred_model.named_parameters()}
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.pred_model.state_dict().items()}

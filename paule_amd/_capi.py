@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
     "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
     "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
+    "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
     "pl_last_error", "pl_version",
 )
 
@@ -83,13 +84,18 @@ def load_library(path: str | None = None):
     lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
     lib.pl_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_int64, C.POINTER(C.c_int64)]
     lib.pl_bench_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    lib.pl_train_pred_step.argtypes = [vp, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+    lib.pl_reset_pred_optimizer.argtypes = [vp]
+    lib.pl_get_lstm_weights.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
+    lib.pl_get_linear.argtypes = [vp, C.c_int, fp, fp]
     lib.pl_device_bytes.restype = C.c_int64
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double
     lib.pl_flops_per_iteration.argtypes = [vp]
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
-                 "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize"):
+                 "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
+                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib

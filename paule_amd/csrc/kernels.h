@@ -167,6 +167,5 @@ void launch_adam_matrix(hipStream_t stream, int dt, const float* grad, int nblk,
                         double* av, void* W, void* WT, const AdamHyper& hp);
 void launch_adam_bias(hipStream_t stream, const float* grad, int nblk, int R, int Rp, double* x0, double* am0, double* av0, double* x1,
                       double* am1, double* av1, float* packed, const AdamHyper& hp);
-void launch_f64_to_f32_rows(hipStream_t stream, const double* src, float* dst, int64_t n);
 
 }  // namespace pl

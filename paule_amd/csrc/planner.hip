@@ -46,12 +46,20 @@ struct DeviceGuard {
     }
 };
 
+// one trainable parameter tensor in torch layout: f64 master + Adam moments (moments allocated with the first training step)
+struct ParamState {
+    double *x = nullptr, *m = nullptr, *v = nullptr;
+    size_t n = 0;
+};
+
 struct LstmLayer {
     int in = 0, in_p = 0;
     void *Wih = nullptr, *WihT = nullptr, *Whh = nullptr, *WhhT = nullptr;
     float* bias = nullptr;
     void *G = nullptr, *h = nullptr, *c = nullptr;   // time-major slabs [Tl][Bp][4Hp] / [Tl][Bp][Hp]
     bool set = false;
+    ParamState p_wih, p_whh, p_bih, p_bhh;           // masters (continued learning, pl_get_lstm_weights)
+    float *gWih = nullptr, *gWhh = nullptr, *gb = nullptr;   // weight gradients in the padded compute layout
 };
 
 struct Model {
@@ -61,6 +69,10 @@ struct Model {
     float* blin = nullptr;
     void* dh_ext = nullptr;                   // [Tl][Bp][Hp] dL/dh of the layer being back-propagated
     bool lin_set = false;
+    ParamState p_wlin, p_blin;
+    float *gWlin = nullptr, *gblin = nullptr;
+    bool train_ready = false;                 // moments + gradient buffers allocated
+    long long train_steps = 0;                // Adam step count of the parameter optimizer
     bool ready() const {
         if (!lin_set) return false;
         for (auto& l : layers)
@@ -177,6 +189,17 @@ int alloc_model(pl_handle* h, Model& md, int L, int H, int in, int out, int Tl) 
         if ((rc = alloc_act(h, &ly.G, (size_t)Tl * Bp * 4 * Hp))) return rc;
         if ((rc = alloc_act(h, &ly.h, (size_t)Tl * Bp * Hp))) return rc;
         if ((rc = alloc_act(h, &ly.c, (size_t)Tl * Bp * Hp))) return rc;
+        ly.p_wih.n = (size_t)4 * H * ly.in;
+        ly.p_whh.n = (size_t)4 * H * H;
+        ly.p_bih.n = ly.p_bhh.n = (size_t)4 * H;
+        for (ParamState* ps : {&ly.p_wih, &ly.p_whh, &ly.p_bih, &ly.p_bhh})
+            if ((rc = dev_alloc(h, &ps->x, ps->n))) return rc;
+    }
+    md.p_wlin.n = (size_t)out * H;
+    md.p_blin.n = (size_t)out;
+    for (ParamState* ps : {&md.p_wlin, &md.p_blin}) {
+        int rc2;
+        if ((rc2 = dev_alloc(h, &ps->x, ps->n))) return rc2;
     }
     int rc;
     if ((rc = alloc_act(h, &md.Wlin, (size_t)md.out_p * Hp))) return rc;
@@ -266,7 +289,11 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) 
 // backward-data through the stack.  Top-layer dL/dh is either dense (md.dh_ext, all steps) or, when
 // dh_last != nullptr, a single [Bp][Hp] slab applied at the last step only (EmbeddingModel: only
 // output[:, lens-1] feeds the loss, paule/models.py:442).  dIn: f32 time-major [Tl][Bp][in_p].
-void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn) {
+// train_nb > 0 (continued learning): the first train_nb batch rows carry samples; after each layer's recurrence the
+// weight gradients dW_hh = sum_t dA_t^T h_{t-1}, dW_ih = sum_t dA_t^T in_t, db = sum_t dA_t are taken from the dA stash
+// (in_act = the model's input slab), and the input gradient of layer 0 is not needed.
+void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn, int train_nb = 0,
+                    const void* in_act = nullptr) {
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
     const size_t a = h->act;
     for (int l = md.L - 1; l >= 0; --l) {
@@ -311,8 +338,16 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
                 s.dh_ext = off(md.dh_ext, (size_t)t * Bp * Hp, a);
             launch_lstm_bwd_step(st, h->dt, s);
         }
+        if (train_nb > 0) {
+            const void* lin = l == 0 ? in_act : md.layers[l - 1].h;
+            launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, ly.h, Hp, ly.gWhh, Hp, 4 * Hp, Hp, Bp, train_nb, Tl - 1, 1, 0);
+            launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, lin, ly.in_p, ly.gWih, ly.in_p, 4 * Hp, ly.in_p, Bp, train_nb, Tl, 0, 0);
+            launch_colsum(st, h->dt, ly.G, 4 * Hp, 4 * Hp, Bp, train_nb, Tl, 0, ly.gb);
+        }
         if (l > 0)   // dL/dh of the layer below = dA * Wih
             launch_gemm_nt(st, h->dt, false, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, md.dh_ext, Hp, Tl * Bp, Hp, 4 * Hp);
+        else if (train_nb > 0)
+            ;
         else
             launch_gemm_nt(st, h->dt, true, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, dIn, ly.in_p, Tl * Bp, ly.in_p, 4 * Hp);
     }
@@ -606,6 +641,10 @@ int pl_set_lstm_weights(pl_handle* h, int model_id, int layer, const float* w_ih
     launch_pack_matrix(st, h->dt, w_hh, 4, md.H, md.H, ly.Whh, md.Hp, md.Hp, false);
     launch_pack_matrix(st, h->dt, w_hh, 4, md.H, md.H, ly.WhhT, md.Hp, md.Hp, true);
     launch_pack_bias(st, b_ih, b_hh, 4, md.H, ly.bias, md.Hp);
+    launch_f32_to_f64(st, w_ih, ly.p_wih.x, (int64_t)ly.p_wih.n);
+    launch_f32_to_f64(st, w_hh, ly.p_whh.x, (int64_t)ly.p_whh.n);
+    launch_f32_to_f64(st, b_ih, ly.p_bih.x, (int64_t)ly.p_bih.n);
+    launch_f32_to_f64(st, b_hh, ly.p_bhh.x, (int64_t)ly.p_bhh.n);
     ly.set = true;
     int rc = check_launch();
     if (rc) return rc;
@@ -623,6 +662,8 @@ int pl_set_linear(pl_handle* h, int model_id, const float* w, const float* b) {
     launch_pack_matrix(st, h->dt, w, 1, md.out, md.H, md.Wlin, md.out_p, md.Hp, false);
     launch_pack_matrix(st, h->dt, w, 1, md.out, md.H, md.WlinT, md.out_p, md.Hp, true);
     launch_pack_bias(st, b, nullptr, 1, md.out, md.blin, md.out_p);
+    launch_f32_to_f64(st, w, md.p_wlin.x, (int64_t)md.p_wlin.n);
+    launch_f32_to_f64(st, b, md.p_blin.x, (int64_t)md.p_blin.n);
     md.lin_set = true;
     int rc = check_launch();
     if (rc) return rc;
@@ -802,6 +843,127 @@ int pl_embed_mel(pl_handle* h, const float* mel, const int32_t* lens, float* sem
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// continued learning of the predictive model (paule/paule.py:1353-1379)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+int ensure_train_state(pl_handle* h, Model& md) {
+    if (md.train_ready) return PL_OK;
+    int rc;
+    for (LstmLayer& ly : md.layers) {
+        for (ParamState* ps : {&ly.p_wih, &ly.p_whh, &ly.p_bih, &ly.p_bhh}) {
+            if ((rc = dev_alloc(h, &ps->m, ps->n))) return rc;
+            if ((rc = dev_alloc(h, &ps->v, ps->n))) return rc;
+        }
+        if ((rc = dev_alloc(h, &ly.gWih, (size_t)4 * md.Hp * ly.in_p))) return rc;
+        if ((rc = dev_alloc(h, &ly.gWhh, (size_t)4 * md.Hp * md.Hp))) return rc;
+        if ((rc = dev_alloc(h, &ly.gb, (size_t)4 * md.Hp))) return rc;
+    }
+    for (ParamState* ps : {&md.p_wlin, &md.p_blin}) {
+        if ((rc = dev_alloc(h, &ps->m, ps->n))) return rc;
+        if ((rc = dev_alloc(h, &ps->v, ps->n))) return rc;
+    }
+    if ((rc = dev_alloc(h, &md.gWlin, (size_t)md.out_p * md.Hp))) return rc;
+    if ((rc = dev_alloc(h, &md.gblin, (size_t)md.out_p))) return rc;
+    md.train_ready = true;
+    return PL_OK;
+}
+
+}  // namespace
+
+int pl_train_pred_step(pl_handle* h, int n_rows, const float* cp, const float* mel_target, float lr, float beta1, float beta2,
+                       float eps, float* loss_out) {
+    if (!h || !cp || !mel_target) return fail(PL_ERR_INVALID, "pl_train_pred_step: NULL argument");
+    if (n_rows < 1 || n_rows > h->B) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_rows has to be in [1, batch]");
+    if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f))
+        return fail(PL_ERR_INVALID, "pl_train_pred_step: bad optimizer hyper-parameter");
+    Model& p = h->pred;
+    if (!p.ready()) return fail(PL_ERR_STATE, "pl_train_pred_step: predictive-model weights are not set");
+    DeviceGuard guard(h->cfg.device);
+    int rc = ensure_train_state(h, p);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    const int Bp = h->Bp, T = h->T, Tp = h->Tp, nb = pad16(n_rows);
+    // forward: Y_hat = pred_model(batch_input) (paule/paule.py:1372); rows >= n_rows of every slab are zero input
+    launch_pack_mel(st, h->dt, cp, n_rows, T, h->C, h->X0, Bp, h->Cp);
+    model_forward(h, st, p, h->X0);
+    const LstmLayer& top = p.layers[p.L - 1];
+    launch_gemm_nt(st, h->dt, true, top.h, p.Hp, p.Wlin, p.Hp, p.blin, h->Y, h->Mp, T * Bp, h->Mp, p.Hp);
+    launch_pool_mel(st, h->dt, h->Y, n_rows, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm);
+    // pred_loss = rmse over the whole batch (pred_criterion = RMSELoss(eps=0), paule/paule.py:288, :1375)
+    launch_train_rmse(st, h->mel_bm, mel_target, (int64_t)n_rows * Tp * h->M, h->scal, loss_out);
+    // backward (paule/paule.py:1376): dY, post_linear gradients, then the recurrences with weight gradients
+    launch_train_dy(st, h->dt, h->mel_bm, mel_target, h->scal, n_rows, T, Tp, h->M, Bp, h->Mp, h->dY);
+    launch_gemm_tn(st, h->dt, h->dY, h->Mp, top.h, p.Hp, p.gWlin, p.Hp, h->Mp, p.Hp, Bp, nb, T, 0, 0);
+    launch_colsum(st, h->dt, h->dY, h->Mp, h->Mp, Bp, nb, T, 0, p.gblin);
+    launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, T * Bp, p.Hp, h->Mp);
+    model_backward(h, st, p, nullptr, nullptr, nb, h->X0);
+    // pred_optimizer.step() (paule/paule.py:1377; torch.optim.Adam defaults, :287) + refresh of the packed compute copies
+    p.train_steps += 1;
+    AdamHyper hp{(double)lr, (double)beta1, (double)beta2, (double)eps, 1.0 - std::pow((double)beta1, (double)p.train_steps),
+                 1.0 - std::pow((double)beta2, (double)p.train_steps)};
+    for (LstmLayer& ly : p.layers) {
+        launch_adam_matrix(st, h->dt, ly.gWih, 4, p.H, ly.in, p.Hp, ly.in_p, ly.p_wih.x, ly.p_wih.m, ly.p_wih.v, ly.Wih, ly.WihT, hp);
+        launch_adam_matrix(st, h->dt, ly.gWhh, 4, p.H, p.H, p.Hp, p.Hp, ly.p_whh.x, ly.p_whh.m, ly.p_whh.v, ly.Whh, ly.WhhT, hp);
+        launch_adam_bias(st, ly.gb, 4, p.H, p.Hp, ly.p_bih.x, ly.p_bih.m, ly.p_bih.v, ly.p_bhh.x, ly.p_bhh.m, ly.p_bhh.v, ly.bias, hp);
+    }
+    launch_adam_matrix(st, h->dt, p.gWlin, 1, p.out, p.H, p.out_p, p.Hp, p.p_wlin.x, p.p_wlin.m, p.p_wlin.v, p.Wlin, p.WlinT, hp);
+    launch_adam_bias(st, p.gblin, 1, p.out, p.out_p, p.p_blin.x, p.p_blin.m, p.p_blin.v, nullptr, nullptr, nullptr, p.blin, hp);
+    return check_launch();
+}
+
+int pl_reset_pred_optimizer(pl_handle* h) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_reset_pred_optimizer: NULL handle");
+    DeviceGuard guard(h->cfg.device);
+    Model& p = h->pred;
+    p.train_steps = 0;
+    if (!p.train_ready) return PL_OK;
+    auto zero = [&](ParamState& ps) -> int {
+        PL_HIP(hipMemsetAsync(ps.m, 0, sizeof(double) * ps.n, h->stream));
+        PL_HIP(hipMemsetAsync(ps.v, 0, sizeof(double) * ps.n, h->stream));
+        return PL_OK;
+    };
+    int rc;
+    for (LstmLayer& ly : p.layers)
+        for (ParamState* ps : {&ly.p_wih, &ly.p_whh, &ly.p_bih, &ly.p_bhh})
+            if ((rc = zero(*ps))) return rc;
+    if ((rc = zero(p.p_wlin))) return rc;
+    return zero(p.p_blin);
+}
+
+int pl_get_lstm_weights(pl_handle* h, int model_id, int layer, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
+    if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: NULL argument");
+    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (layer < 0 || layer >= md.L) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: layer out of range for this model");
+    LstmLayer& ly = md.layers[layer];
+    if (!ly.set) return fail(PL_ERR_STATE, "pl_get_lstm_weights: the layer's weights are not set");
+    DeviceGuard guard(h->cfg.device);
+    launch_f64_to_f32(h->stream, ly.p_wih.x, w_ih, (int64_t)ly.p_wih.n);
+    launch_f64_to_f32(h->stream, ly.p_whh.x, w_hh, (int64_t)ly.p_whh.n);
+    launch_f64_to_f32(h->stream, ly.p_bih.x, b_ih, (int64_t)ly.p_bih.n);
+    launch_f64_to_f32(h->stream, ly.p_bhh.x, b_hh, (int64_t)ly.p_bhh.n);
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(h->stream));
+    return PL_OK;
+}
+
+int pl_get_linear(pl_handle* h, int model_id, float* w, float* b) {
+    if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_get_linear: NULL argument");
+    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_get_linear: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (md.L == 0 || !md.lin_set) return fail(PL_ERR_STATE, "pl_get_linear: the output layer's weights are not set");
+    DeviceGuard guard(h->cfg.device);
+    launch_f64_to_f32(h->stream, md.p_wlin.x, w, (int64_t)md.p_wlin.n);
+    launch_f64_to_f32(h->stream, md.p_blin.x, b, (int64_t)md.p_blin.n);
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(h->stream));
+    return PL_OK;
+}
+
 int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg_ms_out, double* flops_per_launch_out) {
     if (!h || !avg_ms_out || reps < 1) return fail(PL_ERR_INVALID, "pl_bench_kernel: bad argument");
     if (kernel < PL_KERNEL_LSTM_FWD_STEP || kernel > PL_KERNEL_LSTM_BWD_SWEEP) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
@@ -924,6 +1086,8 @@ int pl_debug_read(pl_handle* h, const char* name, float* out, int64_t max_elems,
     int kind = 0;   // 0 activation type, 1 f32, 2 f64
     auto model_buf = [&](Model& md, const std::string& rest) -> bool {
         if (rest == "dh_ext") { src = md.dh_ext; n = (int64_t)md.Tl * h->Bp * md.Hp; kind = 0; return true; }
+        if (rest == "gWlin" && md.train_ready) { src = md.gWlin; n = (int64_t)md.out_p * md.Hp; kind = 1; return true; }
+        if (rest == "gblin" && md.train_ready) { src = md.gblin; n = (int64_t)md.out_p; kind = 1; return true; }
         if (rest.size() < 2) return false;
         const int l = std::atoi(rest.c_str() + 1);
         if (l < 0 || l >= md.L) return false;
@@ -934,6 +1098,10 @@ int pl_debug_read(pl_handle* h, const char* name, float* out, int64_t max_elems,
             case 'c': src = ly.c; n = (int64_t)md.Tl * h->Bp * md.Hp; kind = 0; return true;
             case 'W': src = ly.Whh; n = (int64_t)4 * md.Hp * md.Hp; kind = 0; return true;
             case 'b': src = ly.bias; n = (int64_t)4 * md.Hp; kind = 1; return true;
+            // weight gradients of the last pl_train_pred_step, padded compute layout [4Hp][in_p] / [4Hp][Hp] / [4Hp]
+            case 'i': if (!md.train_ready) return false; src = ly.gWih; n = (int64_t)4 * md.Hp * ly.in_p; kind = 1; return true;
+            case 'r': if (!md.train_ready) return false; src = ly.gWhh; n = (int64_t)4 * md.Hp * md.Hp; kind = 1; return true;
+            case 'd': if (!md.train_ready) return false; src = ly.gb; n = (int64_t)4 * md.Hp; kind = 1; return true;
             default: return false;
         }
     };

@@ -223,11 +223,6 @@ __global__ void adam_bias_kernel(const float* __restrict__ grad, int nblk, int R
     packed[blk * Rp + r] = (float)s;
 }
 
-__global__ void f64_rows_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) dst[idx] = (float)src[idx];
-}
-
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -290,10 +285,6 @@ void launch_adam_bias(hipStream_t stream, const float* grad, int nblk, int R, in
                       double* am1, double* av1, float* packed, const AdamHyper& hp) {
     hipLaunchKernelGGL(adam_bias_kernel, dim3(blocks256(nblk * R)), dim3(256), 0, stream, grad, nblk, R, Rp, x0, am0, av0, x1, am1, av1,
                        packed, hp.lr, hp.b1, hp.b2, hp.eps, hp.bc1, hp.bc2);
-}
-
-void launch_f64_to_f32_rows(hipStream_t stream, const double* src, float* dst, int64_t n) {
-    hipLaunchKernelGGL(f64_rows_to_f32_kernel, dim3(blocks256(n)), dim3(256), 0, stream, src, dst, n);
 }
 
 }  // namespace pl

@@ -85,6 +85,9 @@ class HipPlanner:
         self._h = C.c_void_p()
         _capi.check(self.lib, self.lib.pl_create(C.byref(cfg), C.byref(self._h)), "pl_create")
         self.has_embedder = emb_sd is not None
+        self._dims = {"pred": (lay_p, hid_p, "post_linear"), "pred_in": in_p}
+        if emb_sd is not None:
+            self._dims.update({"embedder": (lay_e, hid_e, "linear_mapping"), "embedder_in": self.M})
         self.set_weights(pred_sd, emb_sd)
 
     # ---- plumbing ---------------------------------------------------------------------------
@@ -121,6 +124,55 @@ class HipPlanner:
                 self._call(self.lib.pl_set_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
             w, b = self._dev(sd[f"{lin}.weight"]), self._dev(sd[f"{lin}.bias"])
             self._call(self.lib.pl_set_linear, model_id, w.data_ptr(), b.data_ptr())
+
+    def get_weights(self, model="pred"):
+        """Current parameters of ``"pred"`` / ``"embedder"`` as a torch state dict (float32, on the engine's device):
+        after ``train_pred_step`` this is what ``pred_model.load_state_dict`` needs (the reference mutates the module in
+        place, paule/paule.py:1372-1377)."""
+        pred = model == "pred"
+        if not pred and not self.has_embedder:
+            raise ValueError("this engine has no embedder")
+        model_id = _capi.PL_MODEL_PRED if pred else _capi.PL_MODEL_EMBED
+        n_layers, H, lin = self._dims[model]
+        sd = {}
+        for l in range(n_layers):
+            in_l = self._dims[model + "_in"] if l == 0 else H
+            ts = [torch.empty(shape, dtype=torch.float32, device=self.device)
+                  for shape in ((4 * H, in_l), (4 * H, H), (4 * H,), (4 * H,))]
+            self._call(self.lib.pl_get_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
+            for k, t in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), ts):
+                sd[f"lstm.{k}_l{l}"] = t
+        out = self.M if pred else self.S
+        w = torch.empty((out, H), dtype=torch.float32, device=self.device)
+        b = torch.empty((out,), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_get_linear, model_id, w.data_ptr(), b.data_ptr())
+        sd[f"{lin}.weight"], sd[f"{lin}.bias"] = w, b
+        return sd
+
+    # ---- continued learning of the predictive model (paule/paule.py:1353-1379) ------------------
+    def train_pred_step(self, cp, mel_target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        """One ``pred_optimizer`` step on a mini-batch: ``cp`` (n, T, cp_dim) -> ``mel_target`` (n, T/2, mel_dim), n <= batch;
+        RMSE over the whole batch, torch.optim.Adam on the parameters (paule/paule.py:287-288, :1372-1377).  Returns the
+        loss of this step as a 0-d device tensor (no host sync)."""
+        cp = self._dev(cp)
+        if cp.dim() == 2:
+            cp = cp.unsqueeze(0)
+        n = int(cp.shape[0])
+        if not 1 <= n <= self.B:
+            raise ValueError(f"mini-batch of {n} samples does not fit an engine built for batch {self.B}")
+        cp = self._dev(cp, (n, self.T, self.C))
+        mel = self._dev(mel_target)
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        mel = self._dev(mel, (n, self.T // 2, self.M))
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_train_pred_step, n, cp.data_ptr(), mel.data_ptr(), C.c_float(lr), C.c_float(betas[0]),
+                   C.c_float(betas[1]), C.c_float(eps), loss.data_ptr())
+        self._keep = (cp, mel)   # the launches are asynchronous: keep the operands alive until the next call
+        return loss
+
+    def reset_pred_optimizer(self):
+        self._call(self.lib.pl_reset_pred_optimizer)
 
     def set_speech_classifier(self, classifier=None, weight=0.1):
         """LinearClassifier(mel_dim -> 1) term (paule/models.py:887-910; ``use_speech_classifier=True``): module or state

@@ -30,6 +30,11 @@ def golden_set_a():
     return _load("set_a_h720.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_train():
+    return _load("train_small.npz")
+
+
 def state_dict_from(g, prefix):
     import torch
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}

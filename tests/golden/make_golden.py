@@ -269,6 +269,43 @@ def main():
             out[f"{name}/grad_at_{k}"] = torch.stack(grads[k]).numpy()
     np.savez_compressed(os.path.join(HERE, "set_a_h720.npz"), **out)
     print("set_a_h720.npz:", len(out), "arrays")
+
+    # ---- fixture 3: continued learning of the predictive model (paule/paule.py:1353-1379) ------------------------------
+    # The mini-batch loop body (:1372-1377) with the reference's ForwardModel, RMSELoss instance and optimizer choice
+    # (:287-288); which samples form a batch is data plumbing (random.sample / create_epoch_batches) and is fixed here.
+    pspec = dict(num_lstm_layers=2, hidden_size=24)
+    N, T = 5, 40
+    wl = synthetic.make_workload(N, T, None, pred=pspec, emb=dict(num_lstm_layers=1, hidden_size=8))
+    pred_model = ref_models.ForwardModel(**pspec).double()
+    pred_model.load_state_dict(wl.pred_sd)
+    pred_optimizer = torch.optim.Adam(pred_model.parameters(), lr=0.001)     # paule/paule.py:287
+    pred_criterion = ns["rmse_loss"]                                          # paule/paule.py:288
+    cps = wl.cp0                                                              # "cp_norm" of produced samples
+    prod_mel = wl.target_mel                                                  # "melspec_norm_synthesized"
+    schedule = [[0, 1, 2], [3, 4], [0, 1, 2, 3, 4], [2], [4, 0], [1, 3, 2]]
+    out = dict(N=N, T=T, cps=cps.numpy(), prod_mel=prod_mel.numpy(), n_steps=len(schedule))
+    out.update(npz_state("pred", wl.pred_sd))
+    losses = []
+    for k, j in enumerate(schedule):
+        out[f"batch_{k}"] = np.array(j)
+        batch_input, batch_output = cps[j], prod_mel[j]
+        lens_input_j = torch.tensor([T] * len(j))
+        Y_hat = pred_model(batch_input, lens_input_j)                         # :1372
+        pred_optimizer.zero_grad()                                            # :1374
+        pred_loss = pred_criterion(Y_hat, batch_output)                       # :1375
+        pred_loss.backward()                                                  # :1376
+        if k == 0:
+            for name, p_ in pred_model.named_parameters():
+                out[f"grad_step0/{name}"] = p_.grad.detach().numpy().copy()
+        pred_optimizer.step()                                                 # :1377
+        losses.append(float(pred_loss.item()))
+        if k in (0, len(schedule) - 1):
+            out.update(npz_state(f"after_{k + 1}", {n_: v.detach().clone() for n_, v in pred_model.state_dict().items()}))
+    out["losses"] = np.array(losses)
+    with torch.no_grad():
+        out["final_pred_mel"] = pred_model(cps).numpy()
+    np.savez_compressed(os.path.join(HERE, "train_small.npz"), **out)
+    print("train_small.npz:", len(out), "arrays")
     return 0
 
 

@@ -304,3 +304,116 @@ def test_full_size_properties_bf16(HipPlanner):
     eng.reset_optimizer()
     np.testing.assert_array_equal(_n(eng.step(6)), loss)
     eng.synchronize()
+
+
+# ---- continued learning of the predictive model (paule/paule.py:1353-1379) --------------------------
+def _unpad_grad(flat, nblk, R, C, Rp, Cp):
+    a = _n(flat).reshape(nblk, Rp, Cp)[:, :R, :C]
+    return a.reshape(nblk * R, C)
+
+
+def _train_engine(HipPlanner, g, dtype, batch=None):
+    sd = state_dict_from(g, "pred")
+    return HipPlanner(sd, None, batch=int(batch or g["N"]), n_frames=int(g["T"]), objective="acoustic", dtype=dtype), sd
+
+
+@pytest.mark.parametrize("batch", [None, 21])
+def test_train_pred_f32_vs_reference_fixture(HipPlanner, golden_train, batch):
+    """pl_train_pred_step against the reference's own run of the mini-batch loop body (ForwardModel, RMSELoss(eps=0),
+    torch.optim.Adam(lr=0.001); tests/golden/train_small.npz): loss of every step rtol 1e-5; every parameter gradient of
+    step 0 (padded compute layout, unpadded here) within 2e-5 of the largest entry; parameters after 1 and 6 steps.
+    Adam divides by sqrt(v): where |g| is of the order of eps = 1e-8 the f32 noise in g changes the update by a
+    fraction of lr, so parameters are held to 2 % of the lr * steps budget at the worst element and 1e-6 on average.
+    batch = 21: an engine built for more utterances than the mini-batch holds (rows beyond n_rows must not contribute)."""
+    g = golden_train
+    eng, sd = _train_engine(HipPlanner, g, "f32", batch)
+    L, H, I, M = 2, 24, 30, 60
+    Hp, Ip, Mp = 32, 32, 64
+    losses = []
+    for k in range(int(g["n_steps"])):
+        j = g[f"batch_{k}"]
+        losses.append(float(eng.train_pred_step(g["cps"][j], g["prod_mel"][j])))
+        if k == 0:
+            for l in range(L):
+                in_l, in_p = (I, Ip) if l == 0 else (H, Hp)
+                for tag, key, shape in (("i", "weight_ih", (4, H, in_l, Hp, in_p)), ("r", "weight_hh", (4, H, H, Hp, Hp))):
+                    ref = g[f"grad_step0/lstm.{key}_l{l}"]
+                    got = _unpad_grad(eng.debug_read(f"pred.{tag}{l}"), *shape)
+                    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=f"{key}_l{l}")
+                    assert _cos(got, ref) > 1 - 1e-9
+                gb = _n(eng.debug_read(f"pred.d{l}")).reshape(4, Hp)[:, :H].reshape(-1)
+                for key in ("bias_ih", "bias_hh"):
+                    ref = g[f"grad_step0/lstm.{key}_l{l}"]
+                    np.testing.assert_allclose(gb, ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=f"{key}_l{l}")
+            ref = g["grad_step0/post_linear.weight"]
+            got = _n(eng.debug_read("pred.gWlin")).reshape(Mp, Hp)[:M, :H]
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+            ref = g["grad_step0/post_linear.bias"]
+            np.testing.assert_allclose(_n(eng.debug_read("pred.gblin"))[:M], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+        if k in (0, int(g["n_steps"]) - 1):
+            got_sd = eng.get_weights("pred")
+            assert set(got_sd) == set(sd)
+            for name, w in got_sd.items():
+                d = np.abs(_n(w) - g[f"after_{k + 1}/{name}"])
+                assert d.max() <= 0.02 * 1e-3 * (k + 1) and d.mean() <= 1e-6, (name, k, d.max(), d.mean())
+    np.testing.assert_allclose(losses, g["losses"], rtol=LOSS_RTOL_F32)
+    # the planner reads the refreshed compute copies: forward at the training inputs with the trained weights
+    n = int(g["N"])
+    cp = np.zeros((eng.B, int(g["T"]), I), dtype=np.float32)
+    cp[:n] = g["cps"]
+    eng.set_cp(cp)
+    mel, _ = eng.get_pred(with_semvec=False)
+    np.testing.assert_allclose(_n(mel)[:n], g["final_pred_mel"], atol=1e-4, rtol=0)
+
+
+def test_train_pred_bf16_vs_reference_fixture(HipPlanner, golden_train):
+    """bf16 activations / weights with f32-accumulated gradients and f64 masters: loss curve rtol 2e-2, gradient cosine
+    >= 0.999 for the big matrices, parameters within 50 % of the lr * steps budget at the worst element (Adam is sign-like
+    where a gradient is bf16 noise) and 5 % on average."""
+    g = golden_train
+    eng, _ = _train_engine(HipPlanner, g, "bf16")
+    losses = []
+    for k in range(int(g["n_steps"])):
+        j = g[f"batch_{k}"]
+        losses.append(float(eng.train_pred_step(g["cps"][j], g["prod_mel"][j])))
+        if k == 0:
+            for l, shape in ((0, (4, 24, 30, 32, 32)), (1, (4, 24, 24, 32, 32))):
+                got = _unpad_grad(eng.debug_read(f"pred.i{l}"), *shape)
+                assert _cos(got, g[f"grad_step0/lstm.weight_ih_l{l}"]) >= COS_BF16
+                got = _unpad_grad(eng.debug_read(f"pred.r{l}"), 4, 24, 24, 32, 32)
+                assert _cos(got, g[f"grad_step0/lstm.weight_hh_l{l}"]) >= COS_BF16
+    np.testing.assert_allclose(losses, g["losses"], rtol=LOSS_RTOL_BF16)
+    n_steps = int(g["n_steps"])
+    for name, w in eng.get_weights("pred").items():
+        d = np.abs(_n(w) - g[f"after_{n_steps}/{name}"])
+        assert d.max() <= 0.5 * 1e-3 * n_steps and d.mean() <= 0.05 * 1e-3 * n_steps, (name, d.max(), d.mean())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_train_pred_set_a_vs_oracle(HipPlanner, dtype):
+    """Paule's default ForwardModel (L = 1, H = 720: persistent sweeps, 46 / 23 workgroups per group) trained for 3
+    mini-batch steps of 8 samples inside an engine built for 24 utterances, against the oracle trainer; then planning
+    continues on the trained weights (pred_mel of the planner == oracle model's output)."""
+    wl = synthetic.make_workload(24, 60, "A")
+    tr = op.OracleTrainer(op.forward_model_from_state_dict(wl.pred_sd))
+    eng = HipPlanner(wl.pred_sd, None, batch=24, n_frames=60, objective="acoustic", dtype=dtype)
+    lo, lh = [], []
+    for k in range(3):
+        j = np.arange(8 * k, 8 * k + 8)
+        lo.append(float(tr.train_pred_step(wl.cp0[j], wl.target_mel[j])))
+        lh.append(float(eng.train_pred_step(wl.cp0[j], wl.target_mel[j])))
+    eng.synchronize()
+    f32 = dtype == "f32"
+    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32 if f32 else LOSS_RTOL_BF16)
+    ref = tr.state_dict()
+    for name, w in eng.get_weights("pred").items():
+        d = np.abs(_n(w) - ref[name].numpy())
+        if f32:
+            assert d.max() <= 0.02 * 1e-3 * 3 and d.mean() <= 1e-6, (name, d.max(), d.mean())
+        else:
+            assert d.max() <= 2.0 * 1e-3 * 3 and d.mean() <= 0.1 * 1e-3 * 3, (name, d.max(), d.mean())
+    eng.set_cp(wl.cp0)
+    mel, _ = eng.get_pred(with_semvec=False)
+    with torch.no_grad():
+        ref_mel = tr.pred_model(wl.cp0).numpy()
+    np.testing.assert_allclose(_n(mel), ref_mel, atol=1e-4 if f32 else 3e-2, rtol=0)

@@ -139,3 +139,24 @@ def test_per_utterance_rule(golden_small):
     lo = one.step(3)
     _close(lf[:, 1:2], lo)
     _close(full.get_cp()[1:2], one.get_cp())
+
+
+def test_continued_learning_step_vs_reference_fixture(golden_train):
+    """OracleTrainer (paule/paule.py:287-288, :1372-1377 restated) against the reference's own ForwardModel / RMSELoss /
+    Adam run: losses of 6 mini-batch steps, every parameter gradient of step 0, the parameters after 1 and 6 steps."""
+    g = golden_train
+    tr = op.OracleTrainer(op.forward_model_from_state_dict(state_dict_from(g, "pred")))
+    cps, mel = torch.from_numpy(g["cps"]), torch.from_numpy(g["prod_mel"])
+    losses = []
+    for k in range(int(g["n_steps"])):
+        j = g[f"batch_{k}"]
+        losses.append(float(tr.train_pred_step(cps[j], mel[j])))
+        if k == 0:
+            for name, gr in tr.gradients().items():
+                np.testing.assert_allclose(gr.numpy(), g[f"grad_step0/{name}"], rtol=0, atol=1e-14, err_msg=name)
+        if k in (0, int(g["n_steps"]) - 1):
+            for name, w in tr.state_dict().items():
+                np.testing.assert_allclose(w.numpy(), g[f"after_{k + 1}/{name}"], rtol=0, atol=1e-13, err_msg=name)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-13)
+    with torch.no_grad():
+        np.testing.assert_allclose(tr.pred_model(cps).numpy(), g["final_pred_mel"], rtol=0, atol=1e-12)
