@@ -28,6 +28,9 @@ CONFIGS = {
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
     "cfg3_setB": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="B"),
     "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+    # one pred_optimizer step of the continued learning (paule/paule.py:1372-1377), batch_size = 8 (:404)
+    "train8": dict(batch=8, frames=300, objective="acoustic", dtype="bf16", model_set="A", train=True),
+    "train8_f32": dict(batch=8, frames=300, objective="acoustic", dtype="f32", model_set="A", train=True),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md chip-level parameters
 
@@ -67,6 +70,68 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
                        f"{wl_args['model_set']}, float32, torch CPU oracle ({dt:.1f} s)")
 
 
+def cpu_baseline_train(cfg, seconds_budget=20.0):
+    """OracleTrainer (torch autograd + torch.optim.Adam on the CPU) on the same mini-batch, float32."""
+    import torch
+    from oracle import planner as op
+    from paule_amd import synthetic
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
+    wl = synthetic.make_workload(cfg["batch"], cfg["frames"], cfg["model_set"])
+    tr = op.OracleTrainer(op.forward_model_from_state_dict(wl.pred_sd, torch.float32), dtype=torch.float32)
+    cp, mel = wl.cp0.float(), wl.target_mel.float()
+    tr.train_pred_step(cp, mel)
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 30):
+        tr.train_pred_step(cp, mel)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="optimiser steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} steps, mini-batch {cfg['batch']} x {cfg['frames']} frames, model set {cfg['model_set']}, float32, "
+                       f"torch CPU oracle ({dt:.1f} s)")
+
+
+def bench_train(args, cfg):
+    """One step = one optimiser step of the predictive model on a mini-batch resident in HBM (pl_train_pred_step)."""
+    import torch
+    from paule_amd import synthetic
+    from paule_amd.engine import HipPlanner
+    B, T = cfg["batch"], cfg["frames"]
+    wl = synthetic.make_workload(B, T, cfg["model_set"])
+    eng = HipPlanner(wl.pred_sd, None, batch=B, n_frames=T, objective="acoustic", dtype=cfg["dtype"])
+    cp, mel = wl.cp0.float().cuda(), wl.target_mel.float().cuda()
+    for _ in range(max(1, args.warmup)):
+        eng.train_pred_step(cp, mel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = [eng.train_pred_step(cp, mel) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.synchronize()
+    H, I, M = 720, 30, 60
+    per_frame = 4 * H * (I + H) + H * M
+    flops = 2 * B * T * per_frame * 3                      # forward + backward-data + weight gradients
+    ms, fl = eng.bench_kernel("bwd_sweep", "pred", reps=5)
+    eng.synchronize()
+    peak = PEAK_TFLOPS[cfg["dtype"]]
+    out = {"metric": f"pred_model optimiser steps/sec, mini-batch={B} x {T}-frame CP trajs", "value": args.steps / elapsed,
+           "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"],
+           "data": "synthetic (random-init weights, random smooth inputs / targets)",
+           "config": {"workload": f"{args.config}: continued learning of the predictive model, mini-batch {B} x {T} frames, "
+                                  f"model set {cfg['model_set']}, RMSE + Adam(lr 0.001)"},
+           "algorithmic_gflop_per_step": flops / 1e9, "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
+           "roofline": {"bound": "mfma", "kernel": "lstm_bwd_rs_sweep_kernel" if cfg["dtype"] == "bf16" else "lstm_bwd_sweep_f32_kernel",
+                        "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                        "frac": fl / (ms * 1e-3) / 1e12 / peak, "traffic": None, "avg_launch_us": ms * 1e3}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_train(cfg)
+    print(json.dumps(out), flush=True)
+
+
 def progress(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
@@ -81,6 +146,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if cfg.get("train"):
+        if args.gpus != 1:
+            raise SystemExit("the training configs are single-GPU")
+        return bench_train(args, cfg)
 
     import torch
     import torch.distributed as dist

@@ -152,10 +152,13 @@ void launch_unpad_rows(hipStream_t stream, const float* src, int B, int S, int S
 
 // ---- continued learning of the predictive model (train.hip) ------------------------------------------------------
 // C[M][N] (f32) = sum over t < Tk, b < nb of A[(tA0 + t) * Bp + b][m] * B[(tB0 + t) * Bp + b][n]; nb multiple of 16, M, N of 8
+// scratch (>= train_scratch_bytes of the largest product) holds split-K partials: a block's K loop is serial, so small
+// outputs are split over K to fill the chip and summed in a fixed order afterwards
+size_t train_scratch_bytes(int M, int N);
 void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
-                    int Bp, int nb, int Tk, int tA0, int tB0);
-// out[c] = sum over the same rows of A[.][c]
-void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* out);
+                    int Bp, int nb, int Tk, int tA0, int tB0, float* scratch, size_t scratch_bytes, int n_cu);
+// out[c] = sum over the same rows of A[.][c]; part: >= 64 * ncols doubles
+void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* out, double* part);
 // scal[0] = sqrt(mean((pred - target)^2)) over n elements (f64), scal[1] = the sum of squares; loss_out (device f32) optional
 void launch_train_rmse(hipStream_t stream, const float* pred, const float* target, int64_t n, double* scal, float* loss_out);
 void launch_train_dy(hipStream_t stream, int dt, const float* pred, const float* target, const double* scal, int n_rows, int T, int Tp,

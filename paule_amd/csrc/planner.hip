@@ -71,6 +71,9 @@ struct Model {
     bool lin_set = false;
     ParamState p_wlin, p_blin;
     float *gWlin = nullptr, *gblin = nullptr;
+    float* train_scratch = nullptr;           // split-K partials of the weight-gradient products
+    size_t train_scratch_bytes = 0;
+    double* colsum_part = nullptr;
     bool train_ready = false;                 // moments + gradient buffers allocated
     long long train_steps = 0;                // Adam step count of the parameter optimizer
     bool ready() const {
@@ -340,9 +343,11 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
         }
         if (train_nb > 0) {
             const void* lin = l == 0 ? in_act : md.layers[l - 1].h;
-            launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, ly.h, Hp, ly.gWhh, Hp, 4 * Hp, Hp, Bp, train_nb, Tl - 1, 1, 0);
-            launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, lin, ly.in_p, ly.gWih, ly.in_p, 4 * Hp, ly.in_p, Bp, train_nb, Tl, 0, 0);
-            launch_colsum(st, h->dt, ly.G, 4 * Hp, 4 * Hp, Bp, train_nb, Tl, 0, ly.gb);
+            launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, ly.h, Hp, ly.gWhh, Hp, 4 * Hp, Hp, Bp, train_nb, Tl - 1, 1, 0, md.train_scratch,
+                           md.train_scratch_bytes, h->n_cu);
+            launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, lin, ly.in_p, ly.gWih, ly.in_p, 4 * Hp, ly.in_p, Bp, train_nb, Tl, 0, 0,
+                           md.train_scratch, md.train_scratch_bytes, h->n_cu);
+            launch_colsum(st, h->dt, ly.G, 4 * Hp, 4 * Hp, Bp, train_nb, Tl, 0, ly.gb, md.colsum_part);
         }
         if (l > 0)   // dL/dh of the layer below = dA * Wih
             launch_gemm_nt(st, h->dt, false, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, md.dh_ext, Hp, Tl * Bp, Hp, 4 * Hp);
@@ -866,6 +871,11 @@ int ensure_train_state(pl_handle* h, Model& md) {
     }
     if ((rc = dev_alloc(h, &md.gWlin, (size_t)md.out_p * md.Hp))) return rc;
     if ((rc = dev_alloc(h, &md.gblin, (size_t)md.out_p))) return rc;
+    // split-K partials: two splits of the largest product (dW_hh), which also covers many splits of the small ones
+    md.train_scratch_bytes = (size_t)2 * 4 * md.Hp * md.Hp * sizeof(float);
+    if (md.train_scratch_bytes < train_scratch_bytes(4 * md.Hp, 128)) md.train_scratch_bytes = train_scratch_bytes(4 * md.Hp, 128);
+    if ((rc = dev_alloc(h, &md.train_scratch, md.train_scratch_bytes / sizeof(float)))) return rc;
+    if ((rc = dev_alloc(h, &md.colsum_part, (size_t)64 * 4 * md.Hp))) return rc;
     md.train_ready = true;
     return PL_OK;
 }
@@ -895,8 +905,9 @@ int pl_train_pred_step(pl_handle* h, int n_rows, const float* cp, const float* m
     launch_train_rmse(st, h->mel_bm, mel_target, (int64_t)n_rows * Tp * h->M, h->scal, loss_out);
     // backward (paule/paule.py:1376): dY, post_linear gradients, then the recurrences with weight gradients
     launch_train_dy(st, h->dt, h->mel_bm, mel_target, h->scal, n_rows, T, Tp, h->M, Bp, h->Mp, h->dY);
-    launch_gemm_tn(st, h->dt, h->dY, h->Mp, top.h, p.Hp, p.gWlin, p.Hp, h->Mp, p.Hp, Bp, nb, T, 0, 0);
-    launch_colsum(st, h->dt, h->dY, h->Mp, h->Mp, Bp, nb, T, 0, p.gblin);
+    launch_gemm_tn(st, h->dt, h->dY, h->Mp, top.h, p.Hp, p.gWlin, p.Hp, h->Mp, p.Hp, Bp, nb, T, 0, 0, p.train_scratch,
+                   p.train_scratch_bytes, h->n_cu);
+    launch_colsum(st, h->dt, h->dY, h->Mp, h->Mp, Bp, nb, T, 0, p.gblin, p.colsum_part);
     launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, T * Bp, p.Hp, h->Mp);
     model_backward(h, st, p, nullptr, nullptr, nb, h->X0);
     // pred_optimizer.step() (paule/paule.py:1377; torch.optim.Adam defaults, :287) + refresh of the packed compute copies

@@ -41,7 +41,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const AT* __restrict__ A, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int tiles_per_t = nb / 16, n_tiles = Tk * tiles_per_t;
+    const int tiles_per_t = nb / 16, tiles_all = Tk * tiles_per_t;
+    // split-K: blockIdx.z takes a contiguous range of K tiles and writes its own partial C (summed by sum_splits_kernel)
+    const int kt0 = (int)((long long)tiles_all * blockIdx.z / gridDim.z), kt1 = (int)((long long)tiles_all * (blockIdx.z + 1) / gridDim.z);
+    const int n_tiles = kt1 - kt0;
+    C += (size_t)blockIdx.z * M * ldc;
 
     // staging: thread -> (k row, 8 consecutive columns)
     const int ak = tid >> 4, ac = (tid & 15) * 8;            // A tile: 16 rows x 128 columns
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const AT* __restrict__ A, 
     const bool b_on = tid * 8 < BK * BN;
     float ra[8], rb[8];
     auto load = [&](int kt) {
-        const int t = kt / tiles_per_t, b0 = (kt % tiles_per_t) * 16;
+        const int t = (kt0 + kt) / tiles_per_t, b0 = ((kt0 + kt) % tiles_per_t) * 16;
         const size_t rowA = (size_t)(tA0 + t) * Bp + b0 + ak, rowB = (size_t)(tB0 + t) * Bp + b0 + bk;
         if (m0 + ac < M) widen8<AT>(A + rowA * lda + m0 + ac, ra);      // M, N are multiples of 8: a piece is whole or absent
         else
@@ -119,17 +123,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const AT* __restrict__ A, 
         }
 }
 
-// column sums over the active rows: out[c] = sum_(t, b < nb) A[(t0 + t) * Bp + b][c]; one thread per column, fixed order
+// column sums over the active rows: out[c] = sum_(t, b < nb) A[(t0 + t) * Bp + b][c].  Two fixed-order stages
+// (deterministic): blockIdx.y sums a contiguous range of time slabs into part[y][c] (f64), then one thread per column
+// adds the parts.
 template <typename AT>
-__global__ void colsum_kernel(const AT* __restrict__ A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* __restrict__ out) {
+__global__ void colsum_part_kernel(const AT* __restrict__ A, int lda, int ncols, int Bp, int nb, int Tk, int t0, double* __restrict__ part) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
+    const int ta = (int)((long long)Tk * blockIdx.y / gridDim.y), tb = (int)((long long)Tk * (blockIdx.y + 1) / gridDim.y);
     double s = 0.0;
-    for (int t = 0; t < Tk; ++t) {
+    for (int t = ta; t < tb; ++t) {
         const AT* row = A + ((size_t)(t0 + t) * Bp) * lda + c;
         for (int b = 0; b < nb; ++b) s += (double)to_f32<AT>(row[(size_t)b * lda]);
     }
+    part[(size_t)blockIdx.y * ncols + c] = s;
+}
+
+__global__ void colsum_final_kernel(const double* __restrict__ part, int S, int ncols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double s = 0.0;
+    for (int i = 0; i < S; ++i) s += part[(size_t)i * ncols + c];
     out[c] = (float)s;
+}
+
+// C[i] = sum_s P[s][i], fixed order
+__global__ void sum_splits_kernel(const float* __restrict__ P, int S, int64_t n, float* __restrict__ C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = P[i];
+    for (int k = 1; k < S; ++k) s += P[(size_t)k * n + i];
+    C[i] = s;
 }
 
 // batch-wide RMSE of the predicted mel against the produced mel (RMSELoss(eps=0), paule/util.py:564-572): one workgroup,
@@ -227,32 +251,52 @@ inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+// scratch: at least train_scratch_bytes(M, N) for split-K partials (ldc == N is required when the split is used)
+size_t train_scratch_bytes(int M, int N) { return (size_t)8 * M * N * sizeof(float); }
+
 void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
-                    int Bp, int nb, int Tk, int tA0, int tB0) {
+                    int Bp, int nb, int Tk, int tA0, int tB0, float* scratch, size_t scratch_bytes, int n_cu) {
     if (M <= 0 || N <= 0) return;
     const bool narrow = N <= 64;
-    const dim3 grid((N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (M + 127) / 128);
+    const int gx = (N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), gy = (M + 127) / 128;
+    // split-K so that ~2 blocks per CU are in flight: a block's K loop is serial (Tk * nb / 16 tiles of 16 rows)
+    const int tiles = Tk * (nb / 16);
+    int S = (2 * n_cu) / (gx * gy);
+    if (S > tiles / 8) S = tiles / 8;                                  // keep >= 8 K tiles per block
+    if (S > 64) S = 64;
+    while (S > 1 && (size_t)S * M * N * sizeof(float) > scratch_bytes) --S;
+    if (S < 2 || !scratch || ldc != N) S = 1;
+    float* dst = S > 1 ? scratch : C;
+    const dim3 grid(gx, gy, S);
 #define PL_TN(AT_)                                                                                                              \
     do {                                                                                                                        \
         if (narrow)                                                                                                             \
             hipLaunchKernelGGL((gemm_tn_kernel<AT_, 64>), grid, dim3(256), 0, stream, static_cast<const AT_*>(A), lda,          \
-                               static_cast<const AT_*>(B), ldb, C, ldc, M, N, Bp, nb, Tk, tA0, tB0);                            \
+                               static_cast<const AT_*>(B), ldb, dst, ldc, M, N, Bp, nb, Tk, tA0, tB0);                          \
         else                                                                                                                    \
             hipLaunchKernelGGL((gemm_tn_kernel<AT_, 128>), grid, dim3(256), 0, stream, static_cast<const AT_*>(A), lda,         \
-                               static_cast<const AT_*>(B), ldb, C, ldc, M, N, Bp, nb, Tk, tA0, tB0);                            \
+                               static_cast<const AT_*>(B), ldb, dst, ldc, M, N, Bp, nb, Tk, tA0, tB0);                          \
     } while (0)
     if (dt == BF16) PL_TN(bf16_t);
     else PL_TN(float);
 #undef PL_TN
+    if (S > 1) {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(sum_splits_kernel, dim3(blocks256(n)), dim3(256), 0, stream, scratch, S, n, C);
+    }
 }
 
-void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* out) {
+// part: at least 64 * ncols doubles
+void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* out, double* part) {
+    const int S = Tk < 64 ? Tk : 64;
+    const dim3 grid((ncols + 63) / 64, S);
     if (dt == BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((ncols + 63) / 64), dim3(64), 0, stream, static_cast<const bf16_t*>(A), lda, ncols,
-                           Bp, nb, Tk, t0, out);
+        hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, dim3(64), 0, stream, static_cast<const bf16_t*>(A), lda, ncols, Bp, nb, Tk, t0,
+                           part);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3((ncols + 63) / 64), dim3(64), 0, stream, static_cast<const float*>(A), lda, ncols, Bp,
-                           nb, Tk, t0, out);
+        hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(64), 0, stream, static_cast<const float*>(A), lda, ncols, Bp, nb, Tk, t0,
+                           part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, part, S, ncols, out);
 }
 
 void launch_train_rmse(hipStream_t stream, const float* pred, const float* target, int64_t n, double* scal, float* loss_out) {

@@ -143,6 +143,69 @@ class Paule():
             mels.append(np.asarray(self.mel_extractor(sig, sr), dtype=np.float64))
         return sigs, sr, np.stack(mels)
 
+    @staticmethod
+    def create_epoch_batches(df_length, batch_size, shuffle=True, same_size_batching=False,
+                             sorted_training_length_keys=None, training_length_dict=None):
+        """Index batches of one epoch (behaviour of paule/paule.py:320-382).  ``same_size_batching``: samples are grouped
+        by sequence length (``training_length_dict``: length -> indices), every length is shuffled and cut into full
+        batches, the left-overs of all lengths are batched together in length order (last batch may be smaller), and the
+        batch order is shuffled.  Otherwise: (shuffled) indices, wrapped around to fill the last batch."""
+        if same_size_batching and training_length_dict is None:
+            raise ValueError("Dictionary containing indices of samples with corresponding length needed for same_size_batching!")
+        if same_size_batching:
+            epoch, left_over = [], []
+            for length in np.sort(list(training_length_dict.keys())):
+                idxs = training_length_dict[length]
+                random.shuffle(idxs)                       # in place, like the reference (:356)
+                n_full = len(idxs) // batch_size
+                epoch += [idxs[i * batch_size:(i + 1) * batch_size] for i in range(n_full)]
+                if len(idxs) % batch_size:
+                    left_over += list(idxs[n_full * batch_size:])
+            left_over = np.asarray(left_over)
+            n_full = len(left_over) // batch_size
+            epoch += [left_over[i * batch_size:(i + 1) * batch_size] for i in range(n_full)]
+            if len(left_over) % batch_size:
+                epoch += [left_over[n_full * batch_size:]]
+            random.shuffle(epoch)
+            return epoch
+        idxs = list(range(df_length))
+        if shuffle:
+            random.shuffle(idxs)
+        if df_length % batch_size:
+            idxs += idxs[:batch_size - df_length % batch_size]
+        return [idxs[i * batch_size:(i + 1) * batch_size] for i in range(len(idxs) // batch_size)]
+
+    def _continue_learning_pred(self, planner, cp_steps_ii, prod_mel_steps_ii, *, n_batches, batch_size, n_epochs, lr):
+        """Continued learning of ``pred_model`` on the samples produced in this outer iteration (paule/paule.py:1244-1248,
+        :1289-1320, :1353-1379 with add_training_data_pred=False): sample at most batch_size * n_batches produced
+        (cp, mel) pairs, then n_epochs epochs of same-size mini-batches, each one ``pred_optimizer`` step on the device.
+        Returns the mean loss of every epoch (``pred_model_loss``, :1406).  With B > 1 every utterance of a logged step is
+        one produced sample.  ``self.pred_model`` is brought in sync with the trained parameters afterwards."""
+        cps = np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, *np.shape(c)[-2:]) for c in cp_steps_ii])
+        mels = np.concatenate([np.asarray(m, dtype=np.float32).reshape(-1, *np.shape(m)[-2:]) for m in prod_mel_steps_ii])
+        n = len(cps)
+        k = n if n < batch_size * n_batches else batch_size * n_batches           # :1289-1303
+        picked = random.sample(range(n), k=k)
+        cps, mels = cps[picked], mels[picked]
+        lens = np.full(k, cps.shape[1])
+        if batch_size > planner.B:
+            raise ValueError(f"batch_size={batch_size} of continued learning exceeds the planner's batch {planner.B}")
+        losses = []
+        for _ in range(n_epochs):
+            by_len = {int(l): np.where(lens == l)[0] for l in np.unique(lens)}    # :1313-1319 (rebuilt: shuffled in place)
+            epoch = self.create_epoch_batches(k, batch_size, shuffle=True, same_size_batching=True, training_length_dict=by_len)
+            step_losses = [planner.train_pred_step(cps[j], mels[j], lr=lr) for j in epoch]
+            losses.append(float(np.mean([float(x) for x in step_losses])))
+        if self.pred_model is not None:      # the reference trains self.pred_model in place: keep module / state dict in sync
+            sd = planner.get_weights("pred")
+            ref = self.pred_model.state_dict() if hasattr(self.pred_model, "state_dict") else self.pred_model
+            new = {k_: torch.as_tensor(v).to(device=ref[k_].device, dtype=ref[k_].dtype) for k_, v in sd.items()}
+            if hasattr(self.pred_model, "load_state_dict"):
+                self.pred_model.load_state_dict(new)
+            else:
+                self.pred_model.update(new)
+        return losses
+
     def plan_resynth(self, *, learning_rate_planning=0.01, learning_rate_learning=0.001,
                      learning_rate_learning_inv=None,
                      target_acoustic=None,
@@ -441,8 +504,8 @@ class Paule():
             pred_semvec_steps.append(pred_semvec_steps_ii)
             prod_semvec_steps.append(prod_semvec_steps_ii)
 
-            # execute and continue learning (paule/paule.py:1243-1454): model TRAINING is host/torch work outside the
-            # planning path; a hook may run it, after which the new weights are re-uploaded for the next inner loop.
+            # execute and continue learning (paule/paule.py:1243-1454).  The predictive model's mini-batch steps
+            # (:1353-1379) run on the device through the planner (pl_train_pred_step); a hook may replace them.
             if continue_learning:
                 if self.continue_learning_hook is not None:
                     losses = self.continue_learning_hook(self, cp_steps_ii, prod_mel_steps_ii, n_batches=n_batches,
@@ -450,9 +513,13 @@ class Paule():
                     if losses:
                         pred_model_loss.extend(losses)
                     planner.set_weights(self.pred_model, None)
+                elif prod_mel_steps_ii and hasattr(planner, "train_pred_step"):
+                    pred_model_loss.extend(self._continue_learning_pred(
+                        planner, cp_steps_ii, prod_mel_steps_ii, n_batches=n_batches, batch_size=batch_size,
+                        n_epochs=n_epochs, lr=learning_rate_learning or 0.001))
                 elif ii_outer == 0:
-                    warnings.warn("continue_learning=True but no continue_learning_hook was given: the predictive model "
-                                  "is kept fixed (model training is outside the MI355X planning path)", stacklevel=2)
+                    warnings.warn("continue_learning=True but nothing was synthesised (no synthesizer / mel_extractor): the "
+                                  "predictive model is kept fixed", stacklevel=2)
 
         if verbose:
             print("--- %.2f min ---" % ((time.time() - start_time) / 60))

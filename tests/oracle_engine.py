@@ -27,6 +27,20 @@ class OracleEngine:
             self.p.target_mel, self.p.target_semvec, self.p.past_cp = old.target_mel, old.target_semvec, old.past_cp
             self.p.classifier = old.classifier
 
+    # continued learning (OracleTrainer keeps its own model + optimizer; the planner is rebuilt on the new weights)
+    def train_pred_step(self, cp, mel_target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        if getattr(self, "trainer", None) is None:
+            self.trainer = op.OracleTrainer(op.forward_model_from_state_dict(self.pred_sd), lr=lr, betas=betas, eps=eps)
+        for grp in self.trainer.optimizer.param_groups:
+            grp["lr"] = lr
+        loss = self.trainer.train_pred_step(np.asarray(cp), np.asarray(mel_target))
+        self.pred_sd = self.trainer.state_dict()
+        self._build()
+        return loss
+
+    def get_weights(self, model="pred"):
+        return dict(self.pred_sd if model == "pred" else self.emb_sd)
+
     def set_weights(self, pred_model=None, embedder=None):
         sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
         if pred_model is not None:

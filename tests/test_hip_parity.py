@@ -417,3 +417,35 @@ def test_train_pred_set_a_vs_oracle(HipPlanner, dtype):
     with torch.no_grad():
         ref_mel = tr.pred_model(wl.cp0).numpy()
     np.testing.assert_allclose(_n(mel), ref_mel, atol=1e-4 if f32 else 3e-2, rtol=0)
+
+
+def test_paule_continue_learning_hip_equals_oracle_engine():
+    """Paule.plan_resynth with continue_learning=True end to end: the HIP planner (planning + pl_train_pred_step between the
+    outer iterations) against the same host code driving the CPU oracle: epoch losses of the continued learning, the trained
+    parameters and the plan that was made on them."""
+    from oracle_engine import OracleEngine
+    from paule_amd import paule as pp
+    small = synthetic.make_workload(2, 24, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                    emb=dict(num_lstm_layers=1, hidden_size=10))
+
+    def synth(cp):
+        return np.zeros(100), 44100
+
+    def melx(sig, sr):
+        return np.full((12, 60), 0.25)
+
+    out = []
+    for factory in (None, lambda pm, em, **kw: OracleEngine(pm, em, **kw)):
+        model = pp.Paule(pred_model={k: v.clone() for k, v in small.pred_sd.items()}, embedder=small.emb_sd,
+                         planner_factory=factory, synthesizer=synth, mel_extractor=melx,
+                         device=torch.device("cuda" if factory is None else "cpu"))
+        res = model.plan_resynth(target_acoustic=small.target_mel.numpy(), initial_cp=small.cp0.numpy(), initialize_from=None,
+                                 objective="acoustic", n_outer=2, n_inner=4, log_ii=2, continue_learning=True, n_batches=2,
+                                 batch_size=2, n_epochs=3, seed=7, verbose=False)
+        out.append((np.asarray(res.pred_model_loss), {k: _n(v) for k, v in model.pred_model.items()}, _n(res.planned_cp)))
+    (lh, wh, ch), (lo, wo, co) = out
+    np.testing.assert_allclose(lh, lo, rtol=1e-4)
+    for k in wo:
+        d = np.abs(wh[k] - wo[k])
+        assert d.max() <= 0.02 * 1e-3 * 12 and d.mean() <= 2e-6, (k, d.max(), d.mean())
+    np.testing.assert_allclose(ch, co, atol=1e-4, rtol=0)

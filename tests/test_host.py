@@ -107,6 +107,47 @@ def test_batched_targets_and_hooks(small):
     assert model.best_synthesis_acoustic.mel_loss < np.inf
 
 
+def test_create_epoch_batches():
+    """Same-size batching (paule/paule.py:349-371): every sample exactly once, full batches hold one length, only the
+    left-over batches mix lengths, at most one batch is smaller; plain mode wraps around (:373-381)."""
+    lens = np.array([40] * 7 + [52] * 5 + [60] * 3)
+    by_len = {int(l): np.where(lens == l)[0] for l in np.unique(lens)}
+    epoch = pp.Paule.create_epoch_batches(len(lens), 4, same_size_batching=True, training_length_dict=by_len)
+    flat = np.concatenate([np.asarray(b) for b in epoch])
+    assert sorted(flat.tolist()) == list(range(len(lens)))
+    assert sorted(len(b) for b in epoch) == [3, 4, 4, 4]
+    assert sum(len(set(lens[np.asarray(b)])) == 1 for b in epoch) >= 2
+    plain = pp.Paule.create_epoch_batches(10, 4, shuffle=False)
+    assert plain == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 0, 1]]
+    with pytest.raises(ValueError, match="Dictionary containing indices"):
+        pp.Paule.create_epoch_batches(10, 4, same_size_batching=True)
+
+
+def test_continue_learning_on_the_planner(small):
+    """continue_learning=True (paule/paule.py:1243-1407): after every outer iteration the produced (cp, mel) pairs train
+    the predictive model through the planner's train_pred_step; pred_model_loss gets one mean per epoch, the module's
+    parameters follow the planner's, and the next outer iteration plans on the trained model."""
+    def synth(cp):
+        return np.zeros(100), 44100
+
+    def melx(sig, sr):
+        return np.full((12, 60), 0.25)
+
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory,
+                     device=torch.device("cpu"), synthesizer=synth, mel_extractor=melx)
+    before = {k: v.clone() for k, v in model.pred_model.items()}
+    res = model.plan_resynth(target_acoustic=small.target_mel.numpy(), initial_cp=small.cp0.numpy(), initialize_from=None,
+                             objective="acoustic", n_outer=2, n_inner=4, log_ii=2, continue_learning=True, n_batches=2,
+                             batch_size=2, n_epochs=3, seed=7, verbose=False)
+    assert len(res.pred_model_loss) == 2 * 3 and all(np.isfinite(res.pred_model_loss))
+    assert res.pred_model_loss[-1] < res.pred_model_loss[0]            # the constant produced mel is easy to fit
+    after = model.pred_model
+    assert any(not torch.equal(before[k].double(), after[k].double()) for k in before)
+    # 2 log steps x 2 utterances = 4 produced samples = batch_size * n_batches: 2 steps per epoch, 3 epochs, 2 outer its
+    changed = max(float((before[k].double() - after[k].double()).abs().max()) for k in before)
+    assert 0 < changed <= 0.001 * 2 * 3 * 2 * 1.1                       # 12 Adam steps move a parameter by ~lr each
+
+
 def test_speech_classifier_config(small):
     """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
     clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}

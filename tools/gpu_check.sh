@@ -25,6 +25,8 @@ for s in $STEPS; do
     bench) step bench 400 python bench.py --steps 10 --warmup 2 ;;
     bench_cfg2) step bench_cfg2 300 python bench.py --config cfg2 --steps 10 --warmup 2 --no-cpu-baseline ;;
     bench_f32) step bench_f32 300 python bench.py --config cfg3_f32 --steps 5 --warmup 1 --no-cpu-baseline ;;
+    bench_train) step bench_train 300 python bench.py --config train8 --steps 30 --warmup 3
+                 step bench_train_f32 300 python bench.py --config train8_f32 --steps 30 --warmup 3 --no-cpu-baseline ;;
     bench_nograph) step bench_nograph 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph ;;
     rocprof) rm -rf gpurun_out/prof
              step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline
