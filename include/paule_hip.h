@@ -48,7 +48,8 @@ enum { PL_OBJ_ACOUSTIC = 0, PL_OBJ_ACOUSTIC_SEMVEC = 1, PL_OBJ_SEMVEC = 2 };
 
 /* model ids for pl_set_lstm_weights / pl_set_linear */
 enum { PL_MODEL_PRED = 0 /* ForwardModel, paule/models.py:326 */,
-       PL_MODEL_EMBED = 1 /* EmbeddingModel, paule/models.py:413 */ };
+       PL_MODEL_EMBED = 1 /* EmbeddingModel, paule/models.py:413 */,
+       PL_MODEL_INVERSE = 2 /* InverseModelMelTimeSmoothResidual, paule/models.py:177 (optional, pl_config.inv_layers) */ };
 
 /* columns of one loss_log row (weighted sub-losses as logged at paule/paule.py:942-945, :988-992) */
 enum { PL_LOSS_TOTAL = 0, PL_LOSS_MEL = 1, PL_LOSS_SEMVEC = 2, PL_LOSS_VEL = 3, PL_LOSS_JERK = 4,
@@ -78,6 +79,12 @@ typedef struct pl_config {
     int32_t device;           /* HIP device ordinal */
     int32_t use_graph;        /* 1: capture one inner iteration into a hipGraph and replay it; 0: eager launches */
     void *stream;             /* hipStream_t the work is enqueued on (NULL = default stream) */
+    /* optional inverse model for the initialisation from the target acoustics (paule/paule.py:143-150,
+     * :550-556): InverseModelMelTimeSmoothResidual(num_lstm_layers, hidden_size) with mel_smooth_filter_size = 3,
+     * time_filter_size = 5 and Identity activations (the ctor defaults, paule/models.py:186-198).  inv_layers = 0: none. */
+    int32_t inv_layers, inv_hidden;
+    int32_t inv_mel_blocks;   /* mel_smooth_layers, 3 */
+    int32_t inv_res_blocks;   /* resid_blocks, 5 (0 also drops resid_weighting, paule/models.py:206, :240) */
 } pl_config;
 
 /* Fills *cfg with the reference's defaults (weights, lr, betas, clamp, dims 30/60/300). */
@@ -128,6 +135,18 @@ int pl_get_pred(pl_handle *h, float *pred_mel_out, float *pred_semvec_out);
 /* EmbeddingModel.forward on an arbitrary mel [B, T/2, mel_dim] (paule/paule.py:533-535, :1131):
  * lens [B] int32 device pointer or NULL (= T/2 for every utterance, paule/paule.py:922-924). */
 int pl_embed_mel(pl_handle *h, const float *mel, const int32_t *lens, float *semvec_out);
+
+/* ---- inverse model: initial CP from the target mel -------------------------------------------------
+ * The LSTM stack and post_linear are uploaded with pl_set_lstm_weights / pl_set_linear and model_id PL_MODEL_INVERSE
+ * (lstm.weight_ih_l{k} [4H, 3 * mel_dim], ..., post_linear [cp_dim, H]).  Convolutions, torch Conv1d layout, device ptrs:
+ *   PL_CONV_MEL   MelBlocks[block].ConvLayers[idx]             w [mel_dim/3, 3, 5], b [mel_dim/3]  (paule/models.py:148-150)
+ *   PL_CONV_RES   ResidualConvBlocks[block].band_conv1d_{idx+1} w [cp_dim, 1, 5],    b [cp_dim]     (paule/models.py:123-124)
+ *   PL_CONV_RW    resid_weighting (block = idx = 0)             w [cp_dim, 2, 5],    b [cp_dim]     (paule/models.py:207-208) */
+enum { PL_CONV_MEL = 0, PL_CONV_RES = 1, PL_CONV_RW = 2 };
+int pl_set_inverse_conv(pl_handle *h, int kind, int block, int idx, const float *w, const float *b);
+/* initial_cp = inv_model(target_mel) (paule/paule.py:552-553): mel [B, n_mel_frames, mel_dim] -> cp_out [B, 2 * n_mel_frames,
+ * cp_dim]; n_mel_frames <= T/2.  clip != 0 applies .clip(min=-1, max=1) of paule/paule.py:555. */
+int pl_inverse_forward(pl_handle *h, const float *mel, int n_mel_frames, float *cp_out, int clip);
 
 /* ---- continued learning of the predictive model (paule/paule.py:1353-1379) ---------------------
  * One optimiser step of `pred_model` on a mini-batch, entirely on the device, replacing

@@ -8,6 +8,8 @@ Follows the reference line by line in *behaviour* (not in text):
                  :617-637 (vel/acc/jerk = stencil applied 1x/2x/3x)
 * criterion    : paule/paule.py:592-597 (weights), :647-662 / :705-717 / :760-773
 * loop         : paule/paule.py:797 (Adam), :911-913, :921-925, :1052, :1199-1211
+* inverse model of the initialisation (``OracleInverseModel``): paule/models.py:47-81 (velocity / acceleration
+  features, double_sequence), :142-169 (MelChannelConv1D), :114-139 (TimeConvResBlock), :177-247
 * continued learning of the predictive model (``OracleTrainer``): paule/paule.py:287-288
   (Adam on the parameters, RMSE criterion), :1372-1377 (one mini-batch step)
 
@@ -298,3 +300,70 @@ class OracleTrainer:
 
     def state_dict(self):
         return {k: v.detach().clone() for k, v in self.pred_model.state_dict().items()}
+
+
+# --------------------------------------------------------------------------------------
+# inverse model (initial CP from the target mel, paule/paule.py:550-556)
+# --------------------------------------------------------------------------------------
+class _OracleMelConv(torch.nn.Module):
+    def __init__(self, units, width):
+        super().__init__()
+        self.ConvLayers = torch.nn.ModuleList([torch.nn.Conv1d(units, units // width, 5, padding=2, groups=units // width)
+                                               for _ in range(width)])
+
+
+class _OracleTimeRes(torch.nn.Module):
+    def __init__(self, units):
+        super().__init__()
+        self.band_conv1d_1 = torch.nn.Conv1d(units, units, 5, padding=2, groups=units)
+        self.band_conv1d_2 = torch.nn.Conv1d(units, units, 5, padding=2, groups=units)
+
+
+class OracleInverseModel(torch.nn.Module):
+    """InverseModelMelTimeSmoothResidual with the default filter sizes and Identity activations (paule/models.py:186-198),
+    same state-dict keys.  forward: (B, T', M) mel -> (B, 2 T', C) control parameters."""
+
+    def __init__(self, input_size=60, output_size=30, hidden_size=180, num_lstm_layers=4, mel_smooth_layers=3, resid_blocks=5):
+        super().__init__()
+        self.MelBlocks = torch.nn.ModuleList([_OracleMelConv(input_size, 3) for _ in range(mel_smooth_layers)])
+        self.lstm = torch.nn.LSTM(3 * input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
+        self.post_linear = torch.nn.Linear(hidden_size, output_size)
+        self.ResidualConvBlocks = torch.nn.ModuleList([_OracleTimeRes(output_size) for _ in range(resid_blocks)])
+        if resid_blocks > 0:
+            self.resid_weighting = torch.nn.Conv1d(2 * output_size, output_size, 5, padding=2, groups=output_size)
+
+    def forward(self, x, *args):
+        B, T, M = x.shape
+        h = x.transpose(1, 2)                                                     # (B, M, T')
+        for blk in self.MelBlocks:                                                # :222-227
+            zero = h.new_zeros(B, 1, T)
+            views = (torch.cat((zero, h[:, :-1]), dim=1), h, torch.cat((h[:, 1:], zero), dim=1))   # :152-158
+            outs = [conv(v) for conv, v in zip(blk.ConvLayers, views)]            # each (B, M/3, T')
+            h = h + torch.stack(outs, dim=2).reshape(B, M, T)                     # channel 3g + j <- conv j, group g (:165-166)
+        x = h.transpose(1, 2)
+        vel = x[:, 1:] - x[:, :-1]                                                # :56-60
+        acc = vel[:, 1:] - vel[:, :-1]
+        z = x.new_zeros(B, 1, M)
+        feats = torch.cat((x, torch.cat((vel, z), dim=1), torch.cat((z, acc, z), dim=1)), dim=2)
+        out, _ = self.lstm(feats)
+        out = self.post_linear(out)                                               # (B, T', C)
+        mid = torch.cat(((out[:, :-1] + out[:, 1:]) / 2.0, out[:, -1:]), dim=1)   # double_sequence, :72-79
+        o = torch.stack((out, mid), dim=2).reshape(B, 2 * T, -1).transpose(1, 2)  # (B, C, 2T')
+        raw = o
+        for blk in self.ResidualConvBlocks:                                       # :131-139, Identity activations
+            o = blk.band_conv1d_2(blk.band_conv1d_1(o)) + o
+        if len(self.ResidualConvBlocks) > 0:                                      # :240-243
+            C = o.shape[1]
+            o = self.resid_weighting(torch.stack((o, raw), dim=2).reshape(B, 2 * C, 2 * T))
+        return o.transpose(1, 2)
+
+
+def inverse_model_from_state_dict(sd, dtype=torch.float64):
+    n_layers = len([k for k in sd if k.startswith("lstm.weight_hh_l")])
+    n_mel = len({k.split(".")[1] for k in sd if k.startswith("MelBlocks.")})
+    n_res = len({k.split(".")[1] for k in sd if k.startswith("ResidualConvBlocks.")})
+    m = OracleInverseModel(input_size=int(sd["lstm.weight_ih_l0"].shape[1]) // 3, output_size=int(sd["post_linear.weight"].shape[0]),
+                           hidden_size=int(sd["lstm.weight_hh_l0"].shape[1]), num_lstm_layers=n_layers, mel_smooth_layers=n_mel,
+                           resid_blocks=n_res).to(dtype)
+    m.load_state_dict({k: torch.as_tensor(v).to(dtype) for k, v in sd.items()})
+    return m.eval()

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaule_hip.so")
 
 PL_F32, PL_BF16 = 0, 1
 PL_OBJ = {"acoustic": 0, "acoustic_semvec": 1, "semvec": 2}
-PL_MODEL_PRED, PL_MODEL_EMBED = 0, 1
+PL_MODEL_PRED, PL_MODEL_EMBED, PL_MODEL_INVERSE = 0, 1, 2
+PL_CONV_MEL, PL_CONV_RES, PL_CONV_RW = 0, 1, 2
 PL_LOSS_COLS = 8
 
 # every symbol include/paule_hip.h declares
@@ -24,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
     "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
+    "pl_set_inverse_conv", "pl_inverse_forward",
     "pl_last_error", "pl_version",
 )
 
@@ -41,6 +43,7 @@ class PlConfig(C.Structure):
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("smiling", C.c_int32), ("device", C.c_int32),
         ("use_graph", C.c_int32), ("stream", C.c_void_p),
+        ("inv_layers", C.c_int32), ("inv_hidden", C.c_int32), ("inv_mel_blocks", C.c_int32), ("inv_res_blocks", C.c_int32),
     ]
 
 
@@ -88,6 +91,8 @@ def load_library(path: str | None = None):
     lib.pl_reset_pred_optimizer.argtypes = [vp]
     lib.pl_get_lstm_weights.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     lib.pl_get_linear.argtypes = [vp, C.c_int, fp, fp]
+    lib.pl_set_inverse_conv.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp]
+    lib.pl_inverse_forward.argtypes = [vp, fp, C.c_int, fp, C.c_int]
     lib.pl_device_bytes.restype = C.c_int64
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double
@@ -95,7 +100,7 @@ def load_library(path: str | None = None):
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
                  "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
-                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear"):
+                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib

@@ -171,4 +171,13 @@ void launch_adam_matrix(hipStream_t stream, int dt, const float* grad, int nblk,
 void launch_adam_bias(hipStream_t stream, const float* grad, int nblk, int R, int Rp, double* x0, double* am0, double* av0, double* x1,
                       double* am1, double* av1, float* packed, const AdamHyper& hp);
 
+// ---- inverse model forward (inverse.hip; InverseModelMelTimeSmoothResidual, paule/models.py:177-247) ---------------
+void launch_mel_block(hipStream_t st, const float* x, int B, int Tp, int M, const float* w, const float* b, float* y);
+void launch_vel_acc_pack(hipStream_t st, int dt, const float* x, int B, int Tp, int M, void* dst, int Bp, int in_p);
+void launch_double_seq(hipStream_t st, const float* Y, int B, int Tp, int C, int Bp, int Cp, float* z);
+void launch_time_conv5(hipStream_t st, const float* x, int B, int T, int C, const float* w, const float* b, const float* resid, float* y);
+void launch_resid_weight(hipStream_t st, const float* zs, const float* zl, int B, int T, int C, const float* w, const float* b, int clip,
+                         float* y);
+void launch_clip_copy(hipStream_t st, const float* x, int64_t n, int clip, float* y);
+
 }  // namespace pl

@@ -91,6 +91,14 @@ struct pl_handle {
     int B = 0, T = 0, Tp = 0, C = 0, M = 0, S = 0, Bp = 0, Cp = 0, Mp = 0, Sp = 0, dt = 0;
     hipStream_t stream = nullptr;
     Model pred, emb;
+    Model inv;                  // optional inverse model (initialisation from the target acoustics)
+    int inv_mel_blocks = 0, inv_res_blocks = 0;
+    float* inv_conv = nullptr;  // conv parameters: mel blocks [3][G][15] + [3][G] each, res convs [C][5] + [C] each, resid_weighting [C][10] + [C]
+    std::vector<char> inv_conv_set;
+    float* inv_x[2] = {nullptr, nullptr};      // [B][Tp][M] ping-pong of the mel blocks
+    void* inv_in = nullptr;                     // [Tp][Bp][pad32(3M)] LSTM input
+    float* inv_Y = nullptr;                     // [Tp][Bp][Cp] post_linear output
+    float* inv_z[3] = {nullptr, nullptr, nullptr};   // [B][2Tp][C]: lstm_output, smoothed, scratch
     float* c_run[2] = {nullptr, nullptr};
     float* dc_run[2] = {nullptr, nullptr};
     void* X0 = nullptr;
@@ -238,8 +246,8 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
 }
 
 // stacked LSTM forward over all Tl steps; in_act = time-major [Tl][Bp][in_p]
-void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act) {
-    const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
+void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl_use = 0) {
+    const int Bp = h->Bp, Hp = md.Hp, Tl = Tl_use > 0 ? Tl_use : md.Tl;
     const size_t a = h->act;
     const void* cur_in = in_act;
     for (int l = 0; l < md.L; ++l) {
@@ -498,6 +506,10 @@ int pl_default_config(pl_config* cfg) {
     cfg->device = 0;
     cfg->use_graph = 1;
     cfg->stream = nullptr;
+    cfg->inv_layers = 0;      // no inverse model unless asked for (Paule's: 1 x 720, paule/paule.py:146)
+    cfg->inv_hidden = 720;
+    cfg->inv_mel_blocks = 3;  // paule/models.py:190, :194
+    cfg->inv_res_blocks = 5;
     return PL_OK;
 }
 
@@ -518,6 +530,11 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if (cfg->objective != PL_OBJ_ACOUSTIC && cfg->emb_layers == 0)
         return fail(PL_ERR_INVALID, "pl_create: semvec objectives need an embedder (emb_layers > 0)");
     if (cfg->cp_dim < 5 && cfg->smiling) return fail(PL_ERR_INVALID, "pl_create: smiling needs cp_dim >= 5");
+    if (cfg->inv_layers < 0 || (cfg->inv_layers > 0 && (cfg->inv_hidden < 1 || cfg->inv_mel_blocks < 0 || cfg->inv_res_blocks < 0 ||
+                                                        cfg->inv_mel_blocks > 64 || cfg->inv_res_blocks > 64)))
+        return fail(PL_ERR_INVALID, "pl_create: bad inverse-model shape");
+    if (cfg->inv_layers > 0 && cfg->inv_mel_blocks > 0 && cfg->mel_dim % 3 != 0)
+        return fail(PL_ERR_INVALID, "pl_create: MelChannelConv1D needs mel_dim divisible by 3 (paule/models.py:146)");
     int ndev = 0;
     PL_HIP(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(PL_ERR_INVALID, "pl_create: no such HIP device");
@@ -542,6 +559,22 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         hmax = hmax > h->emb.Hp ? hmax : h->emb.Hp;
     }
     const size_t Bp = h->Bp, T = h->T, Tp = h->Tp, B = h->B;
+    if (cfg->inv_layers > 0) {
+        if ((rc = alloc_model(h, h->inv, cfg->inv_layers, cfg->inv_hidden, 3 * h->M, h->C, h->Tp))) return bail(rc);
+        hmax = hmax > h->inv.Hp ? hmax : h->inv.Hp;
+        h->inv_mel_blocks = cfg->inv_mel_blocks;
+        h->inv_res_blocks = cfg->inv_res_blocks;
+        const size_t G = h->M / 3, C = h->C;
+        const size_t n_conv = (size_t)h->inv_mel_blocks * 3 * G * 16 + (size_t)h->inv_res_blocks * 2 * C * 6 + C * 11;
+        if ((rc = dev_alloc(h, &h->inv_conv, n_conv))) return bail(rc);
+        h->inv_conv_set.assign((size_t)h->inv_mel_blocks * 3 + (size_t)h->inv_res_blocks * 2 + 1, 0);
+        for (int i = 0; i < 2; ++i)
+            if ((rc = dev_alloc(h, &h->inv_x[i], B * Tp * h->M))) return bail(rc);
+        if ((rc = alloc_act(h, &h->inv_in, Tp * Bp * h->inv.in_p))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->inv_Y, Tp * Bp * h->Cp))) return bail(rc);
+        for (int i = 0; i < 3; ++i)
+            if ((rc = dev_alloc(h, &h->inv_z[i], B * 2 * Tp * h->C))) return bail(rc);
+    }
     for (int i = 0; i < 2; ++i) {
         if ((rc = dev_alloc(h, &h->c_run[i], Bp * hmax))) return bail(rc);
         if ((rc = dev_alloc(h, &h->dc_run[i], Bp * hmax))) return bail(rc);
@@ -605,6 +638,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         const int slice = h->dt == F32 ? 16 : 32;   // hidden units per workgroup
         int pmax = h->pred.Hp / slice;
         if (cfg->emb_layers > 0 && h->emb.Hp / slice > pmax) pmax = h->emb.Hp / slice;
+        if (cfg->inv_layers > 0 && h->inv.Hp / slice > pmax) pmax = h->inv.Hp / slice;
         h->flag_stride = (pmax + 15) / 16 * 16;
         const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
@@ -635,8 +669,8 @@ int pl_destroy(pl_handle* h) {
 int pl_set_lstm_weights(pl_handle* h, int model_id, int layer, const float* w_ih, const float* w_hh, const float* b_ih,
                         const float* b_hh) {
     if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: NULL argument");
-    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
     if (layer < 0 || layer >= md.L) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: layer out of range for this model");
     DeviceGuard guard(h->cfg.device);
     LstmLayer& ly = md.layers[layer];
@@ -659,8 +693,8 @@ int pl_set_lstm_weights(pl_handle* h, int model_id, int layer, const float* w_ih
 
 int pl_set_linear(pl_handle* h, int model_id, const float* w, const float* b) {
     if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_set_linear: NULL argument");
-    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_set_linear: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_set_linear: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
     if (md.L == 0) return fail(PL_ERR_INVALID, "pl_set_linear: this handle has no such model");
     DeviceGuard guard(h->cfg.device);
     hipStream_t st = h->stream;
@@ -945,8 +979,8 @@ int pl_reset_pred_optimizer(pl_handle* h) {
 
 int pl_get_lstm_weights(pl_handle* h, int model_id, int layer, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
     if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: NULL argument");
-    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
     if (layer < 0 || layer >= md.L) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: layer out of range for this model");
     LstmLayer& ly = md.layers[layer];
     if (!ly.set) return fail(PL_ERR_STATE, "pl_get_lstm_weights: the layer's weights are not set");
@@ -963,8 +997,8 @@ int pl_get_lstm_weights(pl_handle* h, int model_id, int layer, float* w_ih, floa
 
 int pl_get_linear(pl_handle* h, int model_id, float* w, float* b) {
     if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_get_linear: NULL argument");
-    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_EMBED) return fail(PL_ERR_INVALID, "pl_get_linear: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : h->emb;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_get_linear: bad model_id");
+    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
     if (md.L == 0 || !md.lin_set) return fail(PL_ERR_STATE, "pl_get_linear: the output layer's weights are not set");
     DeviceGuard guard(h->cfg.device);
     launch_f64_to_f32(h->stream, md.p_wlin.x, w, (int64_t)md.p_wlin.n);
@@ -973,6 +1007,84 @@ int pl_get_linear(pl_handle* h, int model_id, float* w, float* b) {
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
     return PL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// inverse model forward (paule/models.py:210-247; paule/paule.py:550-556)
+// ---------------------------------------------------------------------------------------------------
+int pl_set_inverse_conv(pl_handle* h, int kind, int block, int idx, const float* w, const float* b) {
+    if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_set_inverse_conv: NULL argument");
+    if (h->inv.L == 0) return fail(PL_ERR_INVALID, "pl_set_inverse_conv: the handle has no inverse model (pl_config.inv_layers)");
+    const size_t G = h->M / 3, C = h->C;
+    const size_t mel_block = 3 * G * 16, res_base = (size_t)h->inv_mel_blocks * mel_block, rw_base = res_base + (size_t)h->inv_res_blocks * 2 * C * 6;
+    float *dw = nullptr, *db = nullptr;
+    size_t nw = 0, nbias = 0, slot = 0;
+    if (kind == PL_CONV_MEL && block >= 0 && block < h->inv_mel_blocks && idx >= 0 && idx < 3) {
+        dw = h->inv_conv + block * mel_block + idx * G * 15;
+        db = h->inv_conv + block * mel_block + 3 * G * 15 + idx * G;
+        nw = G * 15; nbias = G; slot = (size_t)block * 3 + idx;
+    } else if (kind == PL_CONV_RES && block >= 0 && block < h->inv_res_blocks && idx >= 0 && idx < 2) {
+        dw = h->inv_conv + res_base + ((size_t)block * 2 + idx) * C * 6;
+        db = dw + C * 5;
+        nw = C * 5; nbias = C; slot = (size_t)h->inv_mel_blocks * 3 + (size_t)block * 2 + idx;
+    } else if (kind == PL_CONV_RW && block == 0 && idx == 0) {
+        dw = h->inv_conv + rw_base;
+        db = dw + C * 10;
+        nw = C * 10; nbias = C; slot = h->inv_conv_set.size() - 1;
+    } else {
+        return fail(PL_ERR_INVALID, "pl_set_inverse_conv: no such convolution in this inverse model");
+    }
+    DeviceGuard guard(h->cfg.device);
+    PL_HIP(hipMemcpyAsync(dw, w, sizeof(float) * nw, hipMemcpyDeviceToDevice, h->stream));
+    PL_HIP(hipMemcpyAsync(db, b, sizeof(float) * nbias, hipMemcpyDeviceToDevice, h->stream));
+    PL_HIP(hipStreamSynchronize(h->stream));
+    h->inv_conv_set[slot] = 1;
+    return PL_OK;
+}
+
+int pl_inverse_forward(pl_handle* h, const float* mel, int n_mel_frames, float* cp_out, int clip) {
+    if (!h || !mel || !cp_out) return fail(PL_ERR_INVALID, "pl_inverse_forward: NULL argument");
+    Model& iv = h->inv;
+    if (iv.L == 0) return fail(PL_ERR_INVALID, "pl_inverse_forward: the handle has no inverse model (pl_config.inv_layers)");
+    if (n_mel_frames < 1 || n_mel_frames > h->Tp) return fail(PL_ERR_INVALID, "pl_inverse_forward: n_mel_frames has to be in [1, n_frames / 2]");
+    if (!iv.ready()) return fail(PL_ERR_STATE, "pl_inverse_forward: inverse-model LSTM / post_linear weights are not set");
+    for (size_t i = 0; i < h->inv_conv_set.size(); ++i)
+        if (!h->inv_conv_set[i] && !(i + 1 == h->inv_conv_set.size() && h->inv_res_blocks == 0))
+            return fail(PL_ERR_STATE, "pl_inverse_forward: a convolution of the inverse model is not set");
+    DeviceGuard guard(h->cfg.device);
+    hipStream_t st = h->stream;
+    const int B = h->B, Bp = h->Bp, M = h->M, C = h->C, Tn = n_mel_frames, T2 = 2 * n_mel_frames;
+    const size_t G = M / 3;
+    const size_t mel_block = 3 * G * 16, res_base = (size_t)h->inv_mel_blocks * mel_block, rw_base = res_base + (size_t)h->inv_res_blocks * 2 * C * 6;
+    // mel smoothing with residual connections (paule/models.py:220-228)
+    const float* x = mel;
+    for (int i = 0; i < h->inv_mel_blocks; ++i) {
+        const float* w = h->inv_conv + i * mel_block;
+        launch_mel_block(st, x, B, Tn, M, w, w + 3 * G * 15, h->inv_x[i & 1]);
+        x = h->inv_x[i & 1];
+    }
+    // velocity / acceleration features, LSTM stack, post_linear (:230-232)
+    launch_vel_acc_pack(st, h->dt, x, B, Tn, M, h->inv_in, Bp, iv.in_p);
+    model_forward(h, st, iv, h->inv_in, Tn);
+    launch_gemm_nt(st, h->dt, true, iv.layers[iv.L - 1].h, iv.Hp, iv.Wlin, iv.Hp, iv.blin, h->inv_Y, h->Cp, Tn * Bp, h->Cp, iv.Hp);
+    // double_sequence (:233), time smoothing with residual connections (:235-238), resid_weighting (:240-243)
+    launch_double_seq(st, h->inv_Y, B, Tn, C, Bp, h->Cp, h->inv_z[0]);
+    if (h->inv_res_blocks == 0) {
+        launch_clip_copy(st, h->inv_z[0], (int64_t)B * T2 * C, clip, cp_out);
+        return check_launch();
+    }
+    const float* cur = h->inv_z[0];
+    for (int i = 0; i < h->inv_res_blocks; ++i) {
+        const float* w1 = h->inv_conv + res_base + ((size_t)i * 2) * C * 6;
+        const float* w2 = w1 + C * 6;
+        launch_time_conv5(st, cur, B, T2, C, w1, w1 + C * 5, nullptr, h->inv_z[2]);
+        float* nxt = (cur == h->inv_z[1]) ? const_cast<float*>(cur) : h->inv_z[1];   // z[1] <- conv2(z[2]) + cur (elementwise in place is safe)
+        launch_time_conv5(st, h->inv_z[2], B, T2, C, w2, w2 + C * 5, cur, nxt);
+        cur = nxt;
+    }
+    const float* rw = h->inv_conv + rw_base;
+    launch_resid_weight(st, cur, h->inv_z[0], B, T2, C, rw, rw + C * 10, clip, cp_out);
+    return check_launch();
 }
 
 int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg_ms_out, double* flops_per_launch_out) {

@@ -40,7 +40,7 @@ class HipPlanner:
 
     def __init__(self, pred_model, embedder=None, *, batch, n_frames, objective="acoustic", dtype="f32",
                  lr=0.01, betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False,
-                 weights=None, device=None, use_graph=True):
+                 weights=None, device=None, use_graph=True, inv_model=None):
         self.lib = _capi.load_library()          # raises HipLibraryError when the extension is missing
         if not torch.cuda.is_available():
             raise _capi.HipLibraryError("no HIP device visible: paule_amd runs on MI355X only (no CPU fallback)")
@@ -72,6 +72,21 @@ class HipPlanner:
         else:
             self.S = 0
             cfg.emb_layers, cfg.emb_hidden = 0, 0
+        inv_sd = _state_dict(inv_model)
+        self.has_inverse = inv_sd is not None
+        if inv_sd is not None:
+            in_i, hid_i, lay_i = _lstm_dims(inv_sd)
+            if in_i != 3 * self.M or int(inv_sd["post_linear.weight"].shape[0]) != self.C:
+                raise ValueError("inverse model has to map mel_dim (x 3 with velocity / acceleration) to cp_dim")
+            n_mel = len({k.split(".")[1] for k in inv_sd if k.startswith("MelBlocks.")})
+            n_res = len({k.split(".")[1] for k in inv_sd if k.startswith("ResidualConvBlocks.")})
+            if n_res > 0 and "resid_weighting.weight" not in inv_sd:
+                raise NotImplementedError("lstm_resid=False with residual blocks is not supported (Paule uses the default True)")
+            for k, v in inv_sd.items():
+                if k.startswith(("MelBlocks.", "ResidualConvBlocks.", "resid_weighting.")) and k.endswith("weight") and v.shape[-1] != 5:
+                    raise NotImplementedError("only the default filter sizes (mel 3 / time 5) are supported")
+            cfg.inv_layers, cfg.inv_hidden, cfg.inv_mel_blocks, cfg.inv_res_blocks = lay_i, hid_i, n_mel, n_res
+            self._inv_blocks = (n_mel, n_res)
         cfg.dtype, cfg.objective = DTYPES[dtype], _capi.PL_OBJ[objective]
         if weights:
             for k in ("w_mel", "w_sem", "w_vel", "w_jerk", "w_ll"):
@@ -89,6 +104,9 @@ class HipPlanner:
         if emb_sd is not None:
             self._dims.update({"embedder": (lay_e, hid_e, "linear_mapping"), "embedder_in": self.M})
         self.set_weights(pred_sd, emb_sd)
+        if inv_sd is not None:
+            self._dims.update({"inverse": (lay_i, hid_i, "post_linear"), "inverse_in": 3 * self.M})
+            self.set_inverse_weights(inv_sd)
 
     # ---- plumbing ---------------------------------------------------------------------------
     def _dev(self, a, shape=None):
@@ -125,14 +143,48 @@ class HipPlanner:
             w, b = self._dev(sd[f"{lin}.weight"]), self._dev(sd[f"{lin}.bias"])
             self._call(self.lib.pl_set_linear, model_id, w.data_ptr(), b.data_ptr())
 
+    # ---- inverse model: initial CP from the target mel (paule/paule.py:550-556) ------------------
+    def set_inverse_weights(self, inv_model):
+        sd = _state_dict(inv_model)
+        _, _, n_layers = _lstm_dims(sd)
+        for l in range(n_layers):
+            ts = [self._dev(sd[f"lstm.{k}_l{l}"]) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            self._call(self.lib.pl_set_lstm_weights, _capi.PL_MODEL_INVERSE, l, *[t.data_ptr() for t in ts])
+        w, b = self._dev(sd["post_linear.weight"]), self._dev(sd["post_linear.bias"])
+        self._call(self.lib.pl_set_linear, _capi.PL_MODEL_INVERSE, w.data_ptr(), b.data_ptr())
+        n_mel, n_res = self._inv_blocks
+        convs = [(_capi.PL_CONV_MEL, i, j, f"MelBlocks.{i}.ConvLayers.{j}") for i in range(n_mel) for j in range(3)]
+        convs += [(_capi.PL_CONV_RES, i, j, f"ResidualConvBlocks.{i}.band_conv1d_{j + 1}") for i in range(n_res) for j in range(2)]
+        if n_res > 0:
+            convs.append((_capi.PL_CONV_RW, 0, 0, "resid_weighting"))
+        for kind, blk, idx, key in convs:
+            w, b = self._dev(sd[key + ".weight"]), self._dev(sd[key + ".bias"])
+            self._call(self.lib.pl_set_inverse_conv, kind, blk, idx, w.data_ptr(), b.data_ptr())
+
+    def inverse_forward(self, mel, clip=True):
+        """``inv_model(target_mel)`` (+ ``.clip(-1, 1)``, paule/paule.py:552-555): mel (B, n, mel_dim), n <= T/2 -> (B, 2n, cp_dim)."""
+        if not self.has_inverse:
+            raise ValueError("this engine was built without inv_model=")
+        mel = self._dev(mel)
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        n = int(mel.shape[1])
+        mel = self._dev(mel, (self.B, n, self.M))
+        out = torch.empty((self.B, 2 * n, self.C), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_inverse_forward, mel.data_ptr(), n, out.data_ptr(), int(bool(clip)))
+        self._keep_inv = mel
+        return out
+
     def get_weights(self, model="pred"):
         """Current parameters of ``"pred"`` / ``"embedder"`` as a torch state dict (float32, on the engine's device):
         after ``train_pred_step`` this is what ``pred_model.load_state_dict`` needs (the reference mutates the module in
         place, paule/paule.py:1372-1377)."""
         pred = model == "pred"
-        if not pred and not self.has_embedder:
+        if model == "embedder" and not self.has_embedder:
             raise ValueError("this engine has no embedder")
         model_id = _capi.PL_MODEL_PRED if pred else _capi.PL_MODEL_EMBED
+        if model not in ("pred", "embedder"):
+            raise ValueError("model has to be 'pred' or 'embedder'")
         n_layers, H, lin = self._dims[model]
         sd = {}
         for l in range(n_layers):

@@ -1,4 +1,5 @@
-"""``paule.models`` API surface for the planning path: ForwardModel and EmbeddingModel.
+"""``paule.models`` API surface for the planning path: ForwardModel, EmbeddingModel and the inverse model of the
+initialisation (InverseModelMelTimeSmoothResidual).
 
 Same constructor signatures, defaults and ``state_dict`` key layout as the reference
 (paule/models.py:335-346, :421-437), so ``load_state_dict`` of the reference's pretrained
@@ -114,3 +115,65 @@ class EmbeddingModel(_HipModule):
         if len(lens) == 1 and B > 1:
             lens = lens * B
         return eng.embed_mel(x, lens).to(x.dtype)
+
+
+def _stub_pred_sd(mel_dim, cp_dim=30):
+    z = torch.zeros
+    return {"lstm.weight_ih_l0": z(4, cp_dim), "lstm.weight_hh_l0": z(4, 1), "lstm.bias_ih_l0": z(4), "lstm.bias_hh_l0": z(4),
+            "post_linear.weight": z(mel_dim, 1), "post_linear.bias": z(mel_dim)}
+
+
+class _MelChannelConv1D(torch.nn.Module):          # parameter container, paule/models.py:142-150
+    def __init__(self, input_units, filter_size_channel):
+        super().__init__()
+        assert input_units % filter_size_channel == 0, 'output_size has to devisible by %d' % filter_size_channel
+        out_units = input_units // filter_size_channel
+        self.ConvLayers = torch.nn.ModuleList([torch.nn.Conv1d(input_units, out_units, 5, padding=2, groups=out_units)
+                                               for _ in range(filter_size_channel)])
+
+
+class _TimeConvResBlock(torch.nn.Module):          # parameter container, paule/models.py:114-128 (filter size 5, channelwise)
+    def __init__(self, input_units):
+        super().__init__()
+        self.band_conv1d_1 = torch.nn.Conv1d(input_units, input_units, kernel_size=5, padding=2, groups=input_units)
+        self.band_conv1d_2 = torch.nn.Conv1d(input_units, input_units, kernel_size=5, padding=2, groups=input_units)
+
+
+class InverseModelMelTimeSmoothResidual(_HipModule):
+    """mel -> CP inverse model (paule/models.py:177-247): mel-channel smoothing convolutions with residual connections,
+    velocity / acceleration features, stacked LSTM, Linear, double_sequence, time-smoothing residual blocks and the
+    channelwise weighting of smoothed and raw LSTM output.  Same constructor and state-dict keys as the reference; the
+    default filter sizes (3 / 5) and Identity activations -- what Paule instantiates (paule/paule.py:146) -- are
+    supported.  ``forward`` runs on the MI355X (pl_inverse_forward)."""
+
+    def __init__(self, input_size=60, output_size=30, hidden_size=180, num_lstm_layers=4, mel_smooth_layers=3,
+                 mel_smooth_filter_size=3, mel_resid_activation=torch.nn.Identity(), resid_blocks=5, time_filter_size=5,
+                 pre_resid_activation=torch.nn.Identity(), post_resid_activation=torch.nn.Identity(),
+                 output_activation=torch.nn.Identity(), lstm_resid=True):
+        super().__init__()
+        for act in (mel_resid_activation, pre_resid_activation, post_resid_activation, output_activation):
+            if not isinstance(act, torch.nn.Identity):
+                raise NotImplementedError("only Identity activations (the reference's defaults) run on the HIP path")
+        if mel_smooth_filter_size != 3 or time_filter_size != 5:
+            raise NotImplementedError("only mel_smooth_filter_size=3 / time_filter_size=5 (the defaults) run on the HIP path")
+        if resid_blocks > 0 and not lstm_resid:
+            raise NotImplementedError("lstm_resid=False is not supported")
+        self.lstm_resid = lstm_resid
+        self.MelBlocks = torch.nn.ModuleList([_MelChannelConv1D(input_size, mel_smooth_filter_size) for _ in range(mel_smooth_layers)])
+        self.lstm = torch.nn.LSTM(3 * input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
+        self.post_linear = torch.nn.Linear(hidden_size, output_size)
+        self.ResidualConvBlocks = torch.nn.ModuleList([_TimeConvResBlock(output_size) for _ in range(resid_blocks)])
+        if self.lstm_resid and len(self.ResidualConvBlocks) > 0:
+            self.resid_weighting = torch.nn.Conv1d(2 * output_size, output_size, time_filter_size, padding=2, groups=output_size)
+
+    def _refresh(self, eng):
+        eng.set_inverse_weights(self.state_dict())
+
+    def forward(self, x, *args):
+        _require_gpu(x, "InverseModelMelTimeSmoothResidual")
+        B, Tp, M = x.shape
+        key = (B, Tp, x.device.index, self.compute_dtype)
+        eng = self._engine(key, lambda: HipPlanner(_stub_pred_sd(M, self.post_linear.out_features), None, batch=B,
+                                                   n_frames=max(2 * Tp, 14), dtype=self.compute_dtype, device=x.device,
+                                                   inv_model=self.state_dict()))
+        return eng.inverse_forward(x, clip=False).to(x.dtype)

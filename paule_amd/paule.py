@@ -301,13 +301,25 @@ class Paule():
         B = target_mel.shape[0]
 
         # ---- initial cp (paule/paule.py:550-573) ----
+        planner = None
         if initial_cp is None:
             if initialize_from == "acoustic":
                 if self.inv_model is None:
-                    raise NotImplementedError("initialize_from='acoustic' needs inv_model= (the inverse model is not on "
-                                              "the planning path); or pass initial_cp= with initialize_from=None")
-                with torch.no_grad():
-                    initial_cp = _np(self.inv_model(torch.as_tensor(target_mel))).clip(min=-1, max=1)
+                    raise NotImplementedError("initialize_from='acoustic' needs inv_model= (an InverseModelMelTimeSmoothResidual "
+                                              "module / state dict, or any callable); or pass initial_cp= with initialize_from=None")
+                inv_sd = self.inv_model if isinstance(self.inv_model, dict) else (
+                    self.inv_model.state_dict() if hasattr(self.inv_model, "MelBlocks") else None)
+                if inv_sd is not None:
+                    # the inverse model runs on the device, inside the planner's handle (pl_inverse_forward): the planner is
+                    # built first; its length is known: past_cp + 2 x target mel frames (paule/paule.py:553, :582-583)
+                    n_past = 0 if past_cp is None else np.asarray(_np(past_cp)).shape[0]
+                    planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=n_past + 2 * target_mel.shape[1],
+                                                    objective=objective, dtype=self.compute_dtype, lr=learning_rate_planning,
+                                                    smiling=self.smiling, device=self.device, inv_model=inv_sd)
+                    initial_cp = _np(planner.inverse_forward(target_mel, clip=True))
+                else:
+                    with torch.no_grad():
+                        initial_cp = _np(self.inv_model(torch.as_tensor(target_mel))).clip(min=-1, max=1)
             elif initialize_from == "semvec":
                 if self.cp_gen_model is None:
                     raise NotImplementedError("initialize_from='semvec' needs cp_gen_model=")
@@ -350,9 +362,10 @@ class Paule():
                 target_semvec = np.repeat(target_semvec, B, axis=0)
 
         # ---- engine ----
-        planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=T, objective=objective,
-                                        dtype=self.compute_dtype, lr=learning_rate_planning, smiling=self.smiling,
-                                        device=self.device)
+        if planner is None:
+            planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=T, objective=objective,
+                                            dtype=self.compute_dtype, lr=learning_rate_planning, smiling=self.smiling,
+                                            device=self.device)
         self.planner = planner
         planner.set_cp(initial_cp)
         planner.reset_optimizer()                       # a fresh Adam per call (paule/paule.py:797)

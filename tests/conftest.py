@@ -35,6 +35,11 @@ def golden_train():
     return _load("train_small.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_inverse():
+    return _load("inverse_small.npz")
+
+
 def state_dict_from(g, prefix):
     import torch
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}

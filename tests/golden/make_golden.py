@@ -306,6 +306,26 @@ def main():
         out["final_pred_mel"] = pred_model(cps).numpy()
     np.savez_compressed(os.path.join(HERE, "train_small.npz"), **out)
     print("train_small.npz:", len(out), "arrays")
+
+    # ---- fixture 4: the inverse model of the initialisation (paule/paule.py:550-556) ---------------------------------
+    torch.manual_seed(synthetic.SEED + 11)
+    inv = ref_models.InverseModelMelTimeSmoothResidual(num_lstm_layers=2, hidden_size=24).double()
+    with torch.no_grad():                   # default init leaves the convolutions tiny: scale them so every stage matters
+        for name, p_ in inv.named_parameters():
+            if "Conv" in name or "conv" in name or "resid_weighting" in name:
+                p_.mul_(1.5)
+    mel = synthetic.make_workload(3, 40, None, pred=dict(num_lstm_layers=1, hidden_size=8),
+                                  emb=dict(num_lstm_layers=1, hidden_size=8)).target_mel      # (3, 20, 60)
+    out = dict(mel=mel.numpy())
+    out.update(npz_state("inv", {k: v.detach().clone() for k, v in inv.state_dict().items()}))
+    with torch.no_grad():
+        xx = mel.detach().clone()                                                 # paule/paule.py:551
+        initial_cp = inv(xx)                                                      # :553
+        out["cp_raw"] = initial_cp.numpy()
+        out["cp_clipped"] = initial_cp.detach().cpu().numpy().clip(min=-1, max=1)   # :555
+        out["cp_raw_13"] = inv(mel[:, :13].clone()).numpy()                       # a shorter sequence through the same model
+    np.savez_compressed(os.path.join(HERE, "inverse_small.npz"), **out)
+    print("inverse_small.npz:", len(out), "arrays")
     return 0
 
 

@@ -9,12 +9,14 @@ from oracle import planner as op
 class OracleEngine:
     def __init__(self, pred_model, embedder=None, *, batch, n_frames, objective="acoustic", dtype="f32", lr=0.01,
                  betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False, weights=None, device=None,
-                 use_graph=True):
+                 use_graph=True, inv_model=None):
         sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
         self.pred_sd, self.emb_sd = sd(pred_model), sd(embedder) if embedder is not None else None
         self.B, self.T, self.Tp = batch, n_frames, n_frames // 2
         self.kw = dict(objective=objective, lr=lr, betas=betas, eps=eps, clamp=clamp, smiling=smiling)
         self.has_embedder = self.emb_sd is not None
+        self.inv = op.inverse_model_from_state_dict(sd(inv_model)) if inv_model is not None else None
+        self.has_inverse = self.inv is not None
         self._build()
 
     def _build(self):
@@ -26,6 +28,11 @@ class OracleEngine:
             self.p.xx, self.p.optimizer = old.xx, old.optimizer
             self.p.target_mel, self.p.target_semvec, self.p.past_cp = old.target_mel, old.target_semvec, old.past_cp
             self.p.classifier = old.classifier
+
+    def inverse_forward(self, mel, clip=True):
+        with torch.no_grad():
+            cp = self.inv(torch.as_tensor(np.asarray(mel), dtype=torch.float64))
+        return cp.clamp(-1.0, 1.0) if clip else cp
 
     # continued learning (OracleTrainer keeps its own model + optimizer; the planner is rebuilt on the new weights)
     def train_pred_step(self, cp, mel_target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):

@@ -449,3 +449,56 @@ def test_paule_continue_learning_hip_equals_oracle_engine():
         d = np.abs(wh[k] - wo[k])
         assert d.max() <= 0.02 * 1e-3 * 12 and d.mean() <= 2e-6, (k, d.max(), d.mean())
     np.testing.assert_allclose(ch, co, atol=1e-4, rtol=0)
+
+
+# ---- inverse model: initial CP from the target mel (paule/paule.py:550-556) -------------------------
+def _stub_pred(mel_dim=60, cp_dim=30):
+    z = torch.zeros
+    return {"lstm.weight_ih_l0": z(4, cp_dim), "lstm.weight_hh_l0": z(4, 1), "lstm.bias_ih_l0": z(4), "lstm.bias_hh_l0": z(4),
+            "post_linear.weight": z(mel_dim, 1), "post_linear.bias": z(mel_dim)}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_inverse_forward_vs_reference_fixture(HipPlanner, golden_inverse, dtype):
+    """pl_inverse_forward against the reference's InverseModelMelTimeSmoothResidual run (tests/golden/inverse_small.npz;
+    outputs up to |4|): f32 atol 5e-5 raw and clipped, and a 13-frame sequence in a handle built for 20; bf16 (LSTM and
+    post_linear in bf16, convolutions f32): atol 0.08."""
+    g = golden_inverse
+    B, Tm = g["mel"].shape[:2]
+    eng = HipPlanner(_stub_pred(), None, batch=B, n_frames=2 * Tm, dtype=dtype, inv_model=state_dict_from(g, "inv"))
+    atol = 5e-5 if dtype == "f32" else 0.08
+    np.testing.assert_allclose(_n(eng.inverse_forward(g["mel"], clip=False)), g["cp_raw"], atol=atol, rtol=0)
+    np.testing.assert_allclose(_n(eng.inverse_forward(g["mel"], clip=True)), g["cp_clipped"], atol=atol, rtol=0)
+    np.testing.assert_allclose(_n(eng.inverse_forward(g["mel"][:, :13].copy(), clip=False)), g["cp_raw_13"], atol=atol, rtol=0)
+
+
+def test_inverse_model_module_default_shape_vs_oracle():
+    """paule_amd.models.InverseModelMelTimeSmoothResidual(num_lstm_layers=1, hidden_size=720) -- what Paule instantiates
+    (paule/paule.py:146) -- random init, forward on the GPU against the oracle model with the same state dict; B = 37 runs
+    the LSTM through the f32 persistent sweeps (3 groups of 16 rows)."""
+    from paule_amd import models
+    torch.manual_seed(5)
+    m = models.InverseModelMelTimeSmoothResidual(num_lstm_layers=1, hidden_size=720)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    mel = synthetic.make_workload(37, 64, "B").target_mel                    # (37, 32, 60)
+    ref = op.inverse_model_from_state_dict(sd)
+    with torch.no_grad():
+        want = ref(mel).numpy()
+    got = m(mel.float().cuda())
+    assert got.shape == (37, 64, 30)
+    np.testing.assert_allclose(_n(got), want, atol=2e-5, rtol=0)
+
+
+def test_paule_initialize_from_acoustic_hip(golden_inverse):
+    """Paule.plan_resynth(initialize_from='acoustic') with the inverse model on the device: initial_cp equals the reference's
+    clipped inverse output, and the plan starts from it."""
+    from paule_amd import paule as pp
+    small = synthetic.make_workload(2, 40, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                    emb=dict(num_lstm_layers=1, hidden_size=10))
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, inv_model=state_dict_from(golden_inverse, "inv"),
+                     device=torch.device("cuda"))
+    res = model.plan_resynth(target_acoustic=golden_inverse["mel"][:2], target_semvec=small.target_semvec.numpy(),
+                             initialize_from="acoustic", objective="acoustic_semvec", n_outer=1, n_inner=3, log_ii=3,
+                             continue_learning=False, log_cps=True, verbose=False)
+    np.testing.assert_allclose(res.initial_cp, golden_inverse["cp_clipped"][:2], atol=5e-5, rtol=0)
+    assert res.planned_cp.shape == (2, 40, 30) and np.isfinite(res.planned_cp).all()

@@ -148,6 +148,25 @@ def test_continue_learning_on_the_planner(small):
     assert 0 < changed <= 0.001 * 2 * 3 * 2 * 1.1                       # 12 Adam steps move a parameter by ~lr each
 
 
+def test_initialize_from_acoustic_on_the_planner(small, golden_inverse):
+    """initialize_from='acoustic' (paule/paule.py:550-556) with the inverse model handed in as a state dict: the planner is
+    built first and runs inv_model(target_mel).clip(-1, 1) itself; with past_cp the plan is past + 2 x mel frames long."""
+    inv_sd = state_dict_from(golden_inverse, "inv")
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, inv_model=inv_sd, planner_factory=_factory,
+                     device=torch.device("cpu"))
+    mel = golden_inverse["mel"][:2]                                   # (2, 20, 60)
+    res = model.plan_resynth(target_acoustic=mel, initialize_from="acoustic", objective="acoustic", n_outer=1, n_inner=2,
+                             log_ii=2, continue_learning=False, verbose=False)
+    np.testing.assert_allclose(res.initial_cp, golden_inverse["cp_clipped"][:2], atol=1e-12)
+    assert res.planned_cp.shape == (2, 40, 30)
+    past = np.zeros((6, 30))
+    res = model.plan_resynth(target_acoustic=mel, target_semvec=small.target_semvec.numpy(), initialize_from="acoustic",
+                             past_cp=past, objective="acoustic", n_outer=1, n_inner=2, log_ii=2, continue_learning=False,
+                             verbose=False)
+    assert res.planned_cp.shape == (2, 46, 30)
+    np.testing.assert_allclose(res.initial_cp[:, 6:], golden_inverse["cp_clipped"][:2], atol=1e-12)
+
+
 def test_speech_classifier_config(small):
     """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
     clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}

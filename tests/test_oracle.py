@@ -160,3 +160,16 @@ def test_continued_learning_step_vs_reference_fixture(golden_train):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-13)
     with torch.no_grad():
         np.testing.assert_allclose(tr.pred_model(cps).numpy(), g["final_pred_mel"], rtol=0, atol=1e-12)
+
+
+def test_inverse_model_vs_reference_fixture(golden_inverse):
+    """OracleInverseModel against the reference's InverseModelMelTimeSmoothResidual (paule/models.py:177-247): raw output,
+    the clipped initial CP of paule/paule.py:555, and a shorter sequence through the same parameters."""
+    g = golden_inverse
+    m = op.inverse_model_from_state_dict(state_dict_from(g, "inv"))
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["mel"]))
+        y13 = m(torch.from_numpy(g["mel"][:, :13].copy()))
+    np.testing.assert_allclose(y.numpy(), g["cp_raw"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(y.clamp(-1, 1).numpy(), g["cp_clipped"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(y13.numpy(), g["cp_raw_13"], rtol=0, atol=1e-12)
