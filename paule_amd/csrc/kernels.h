@@ -63,7 +63,7 @@ struct LstmSweepArgs {
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit
-int lstm_sweep_grid(int Hp, int Bp, int n_cu);
+int lstm_sweep_grid(int Hp, int Bp, int n_cu, bool spread_small = false);
 int lstm_sweep_group_rows(int Hp, int Bp, int n_cu);
 void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
 // backward sweep in reduce-scatter form (lstm_persist_rs.hip): same arguments + a.xchg of lstm_rs_exchange_bytes()

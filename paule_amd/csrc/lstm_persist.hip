@@ -441,11 +441,14 @@ int lstm_sweep_group_rows(int Hp, int Bp, int n_cu) {
     return Bp < 32 ? (Bp + 7) / 8 * 8 : 32;
 }
 
-int lstm_sweep_grid(int Hp, int Bp, int n_cu) {
+int lstm_sweep_grid(int Hp, int Bp, int n_cu, bool spread_small) {
     const int P = Hp / 32, gs = lstm_sweep_group_rows(Hp, Bp, n_cu);
     if (gs == 0) return 0;
     const int groups = (Bp + gs - 1) / gs;
     int res = n_cu / P;
+    // fewer groups than XCDs: launch 8 slots anyway (blocks of the empty slots leave at once), so that a group's
+    // workgroups (blockIdx % 8 == group) still land on one XCD and can use the verified same-XCD hand-off
+    if (spread_small && groups < 8 && res >= 8) return 8 * P;
     if (res > groups) res = groups;
     if (res >= 8) res = res / 8 * 8;   // a multiple of the XCD count keeps a group's workgroups on one XCD (speed only)
     return res < 1 ? 0 : res * P;

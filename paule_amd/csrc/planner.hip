@@ -137,6 +137,8 @@ struct pl_handle {
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
+    bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
+                                // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
     unsigned long long spin_ticks = 200000000ull;   // 2 s
     unsigned poll_mask = 63u;
@@ -233,7 +235,7 @@ void zero_sweep_counters(pl_handle* h, hipStream_t st) {
 int sweep_grid_for(pl_handle* h, int Hp) {
     if (!h->use_sweep) return 0;
     if (h->dt == F32) return (h->f32_sweep && lstm_sweep_f32_supported(Hp)) ? lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu) : 0;
-    return lstm_sweep_supported(h->dt, Hp) ? lstm_sweep_grid(Hp, h->Bp, h->n_cu) : 0;
+    return lstm_sweep_supported(h->dt, Hp) ? lstm_sweep_grid(Hp, h->Bp, h->n_cu, h->small_grid) : 0;
 }
 int sweep_group_rows_for(pl_handle* h, int Hp) { return h->dt == F32 ? 16 : lstm_sweep_group_rows(Hp, h->Bp, h->n_cu); }
 void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, const LstmSweepArgs& s) {
@@ -617,6 +619,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_SMALL_GRID")) h->small_grid = std::atoi(z) != 0;
         if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
             size_t xb = lstm_sweep_f32_supported(h->pred.Hp) ? lstm_f32_exchange_bytes(h->pred.Hp, h->Bp) : 0;
             if (cfg->emb_layers > 0 && lstm_sweep_f32_supported(h->emb.Hp)) {

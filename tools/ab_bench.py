@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of engine variants in ONE process on ONE device (MI355X guide, methodology rule 24).
-usage: ab_bench.py VAR=a,b[,c] [rounds] [iters]      e.g.  ab_bench.py PAULE_HIP_XCD_FAST=0,1 8 10"""
+usage: ab_bench.py VAR=a,b[,c] [rounds] [iters]      e.g.  ab_bench.py PAULE_HIP_XCD_FAST=0,1 8 10
+       ab_bench.py "A=0,B=2/A=1,B=3" [rounds] [iters]  variants separated by "/", each a list of assignments
+env: AB_BATCH (256), AB_DTYPE (bf16)"""
 import os
 import sys
 import time
@@ -12,15 +14,20 @@ import torch  # noqa: E402
 from paule_amd import synthetic  # noqa: E402
 from paule_amd.engine import HipPlanner  # noqa: E402
 
-var, vals = sys.argv[1].split("=")
-vals = vals.split(",")
+if "/" in sys.argv[1]:
+    variants = [dict(a.split("=") for a in v.split(",")) for v in sys.argv[1].split("/")]
+    var, vals = "variant", [",".join(f"{k}={x}" for k, x in v.items()) for v in variants]
+else:
+    var, vals = sys.argv[1].split("=")
+    vals = vals.split(",")
+    variants = [{var: v} for v in vals]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 cfg = dict(batch=int(os.environ.get("AB_BATCH", 256)), frames=300, objective="acoustic_semvec", dtype=os.environ.get("AB_DTYPE", "bf16"))
 wl = synthetic.make_workload(cfg["batch"], cfg["frames"], "A")
 engines = []
-for v in vals:
-    os.environ[var] = v
+for v in variants:
+    os.environ.update(v)
     e = HipPlanner(wl.pred_sd, wl.emb_sd, batch=cfg["batch"], n_frames=cfg["frames"], objective=cfg["objective"], dtype=cfg["dtype"])
     e.set_targets(wl.target_mel, wl.target_semvec)
     e.set_cp(wl.cp0)
