@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,31 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                         \
             return fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
+
+// A persistent sweep needs all workgroups of a batch group resident at once; two sweeps of DIFFERENT handles running
+// concurrently on one device (two streams) could each hold CUs the other one's partners need, and both would spin into
+// their bounded timeouts.  Every entry point that launches sweeps therefore chains its work behind the previous such
+// call on the same device (one event per device, submission serialised by a mutex): handles on different streams of one
+// process execute their sweeps one after the other.  Same stream: a no-op.  (Processes sharing one GPU are not covered.)
+struct SweepChain {
+    static constexpr int kMaxDev = 64;
+    static std::mutex& mu(int dev) { static std::mutex m[kMaxDev]; return m[dev]; }
+    static hipEvent_t& evt(int dev) { static hipEvent_t e[kMaxDev] = {}; return e[dev]; }
+    int dev;
+    hipStream_t stream;
+    bool on;
+    SweepChain(int device, hipStream_t st) : dev(device), stream(st), on(device >= 0 && device < kMaxDev) {
+        if (!on) return;
+        mu(dev).lock();
+        if (evt(dev)) (void)hipStreamWaitEvent(stream, evt(dev), 0);
+    }
+    ~SweepChain() {
+        if (!on) return;
+        if (!evt(dev)) (void)hipEventCreateWithFlags(&evt(dev), hipEventDisableTiming);
+        if (evt(dev)) (void)hipEventRecord(evt(dev), stream);
+        mu(dev).unlock();
+    }
+};
 
 struct DeviceGuard {
     int prev = -1;
@@ -802,6 +828,7 @@ int pl_step(pl_handle* h, int n_iters, float* loss_log, float* grad_out) {
     if (!h->have_targets) return fail(PL_ERR_STATE, "pl_step: pl_set_targets has not been called");
     if (with_sem && !h->have_sem_target) return fail(PL_ERR_STATE, "pl_step: objective needs a target_semvec");
     DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
     if (h->cfg.use_graph && !h->graph_exec && n_iters > 0) {
         rc = build_graph(h);
         if (rc) return rc;
@@ -862,6 +889,7 @@ int pl_get_pred(pl_handle* h, float* pred_mel_out, float* pred_semvec_out) {
     if (rc) return rc;
     if (pred_semvec_out && h->emb.L == 0) return fail(PL_ERR_INVALID, "pl_get_pred: pred_semvec requested but the handle has no embedder");
     DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
     hipStream_t st = h->stream;
     pred_forward(h, st);
     if (pred_mel_out)
@@ -878,6 +906,7 @@ int pl_embed_mel(pl_handle* h, const float* mel, const int32_t* lens, float* sem
     if (h->emb.L == 0) return fail(PL_ERR_INVALID, "pl_embed_mel: the handle has no embedder");
     if (!h->emb.ready()) return fail(PL_ERR_STATE, "pl_embed_mel: embedder weights are not set");
     DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
     hipStream_t st = h->stream;
     launch_pack_mel(st, h->dt, mel, h->B, h->Tp, h->M, h->mel_tm, h->Bp, h->Mp);
     emb_forward(h, st, lens);
@@ -928,6 +957,7 @@ int pl_train_pred_step(pl_handle* h, int n_rows, const float* cp, const float* m
     Model& p = h->pred;
     if (!p.ready()) return fail(PL_ERR_STATE, "pl_train_pred_step: predictive-model weights are not set");
     DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
     int rc = ensure_train_state(h, p);
     if (rc) return rc;
     hipStream_t st = h->stream;
@@ -1055,6 +1085,7 @@ int pl_inverse_forward(pl_handle* h, const float* mel, int n_mel_frames, float* 
         if (!h->inv_conv_set[i] && !(i + 1 == h->inv_conv_set.size() && h->inv_res_blocks == 0))
             return fail(PL_ERR_STATE, "pl_inverse_forward: a convolution of the inverse model is not set");
     DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
     hipStream_t st = h->stream;
     const int B = h->B, Bp = h->Bp, M = h->M, C = h->C, Tn = n_mel_frames, T2 = 2 * n_mel_frames;
     const size_t G = M / 3;
@@ -1096,6 +1127,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
     Model& md = model_id == PL_MODEL_EMBED ? h->emb : h->pred;
     if (md.L == 0 || !md.ready()) return fail(PL_ERR_STATE, "pl_bench_kernel: model weights are not set");
     DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
     LstmLayer& ly = md.layers[0];
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
     const size_t a = h->act;

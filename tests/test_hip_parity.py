@@ -502,3 +502,82 @@ def test_paule_initialize_from_acoustic_hip(golden_inverse):
                              continue_learning=False, log_cps=True, verbose=False)
     np.testing.assert_allclose(res.initial_cp, golden_inverse["cp_clipped"][:2], atol=5e-5, rtol=0)
     assert res.planned_cp.shape == (2, 40, 30) and np.isfinite(res.planned_cp).all()
+
+
+def test_two_handles_on_two_streams_do_not_starve_each_other(HipPlanner):
+    """Persistent sweeps of different handles must not run concurrently (each needs its groups' workgroups co-resident): two
+    engines on two streams, driven from two threads at B = 256 (184 workgroups each), finish without a bounded-wait timeout
+    and give the result of a solo run (the library chains sweep launches per device)."""
+    import threading
+    wl = synthetic.make_workload(256, 40, "A")
+    def make(stream):
+        with torch.cuda.stream(stream):
+            e = HipPlanner(wl.pred_sd, wl.emb_sd, batch=256, n_frames=40, objective="acoustic_semvec", dtype="bf16")
+            e.set_targets(wl.target_mel, wl.target_semvec)
+            e.set_cp(wl.cp0)
+        return e
+    solo = make(torch.cuda.current_stream())
+    solo.step(12, return_loss=False)
+    want = solo.get_cp()
+    solo.synchronize()
+    want = _n(want)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    engines = [make(st) for st in streams]
+    torch.cuda.synchronize()
+    errors = []
+    def drive(e):
+        try:
+            for _ in range(4):
+                e.step(3, return_loss=False)
+            e.synchronize()
+        except Exception as ex:   # noqa: BLE001
+            errors.append(ex)
+    threads = [threading.Thread(target=drive, args=(e,)) for e in engines]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for e in engines:
+        got = e.get_cp()          # enqueued on the engine's own stream
+        e.synchronize()
+        np.testing.assert_array_equal(_n(got), want)
+
+
+def test_long_sequences_f32_vs_oracle(HipPlanner):
+    """T = 2000 CP frames (cfg5's length; T' = 1000 embedder steps): flag / stash indexing over long sweeps, f32 against the
+    oracle on the stacked class-default models (set B), 3 iterations."""
+    wl = synthetic.make_workload(2, 2000, "B")
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=2, n_frames=2000, objective="acoustic_semvec")
+    for pl in (orc, eng):
+        pl.set_targets(wl.target_mel, wl.target_semvec)
+        pl.set_cp(wl.cp0)
+    lo, lh = _n(orc.step(3)), _n(eng.step(3))
+    eng.synchronize()
+    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(_n(eng.get_cp()), _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+
+
+def test_minimum_length_and_single_utterance(HipPlanner):
+    """B = 1 (the reference's own batch) at the shortest plannable length T = 14 (jerk needs T - 12 >= 1 frames), both dtypes'
+    sweeps with a single group of 8 / 16 rows."""
+    wl = synthetic.make_workload(1, 14, "A")
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    orc.set_targets(wl.target_mel, wl.target_semvec)
+    orc.set_cp(wl.cp0)
+    lo, co = _n(orc.step(5)), _n(orc.get_cp())
+    for dtype in ("f32", "bf16"):
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=1, n_frames=14, objective="acoustic_semvec", dtype=dtype)
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        lh = _n(eng.step(5))
+        eng.synchronize()
+        if dtype == "f32":
+            np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
+            np.testing.assert_allclose(_n(eng.get_cp()), co, atol=CP_ATOL_F32, rtol=0)
+        else:
+            np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
+            assert np.abs(_n(eng.get_cp()) - co).max() <= 0.5 * 0.01 * 5
