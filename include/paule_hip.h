@@ -17,7 +17,10 @@
  * tensors after a call returns (needed because continued learning mutates pred_model
  * between outer iterations, paule/paule.py:1372-1377).  One handle <-> one device <->
  * one stream; calls on one handle are not re-entrant; different handles may be driven
- * from different threads / processes (one per GPU).  pl_step is stream-asynchronous;
+ * from different threads / processes (one per GPU).  Handles of one process that share a
+ * device may use different streams: the library chains the launches that run persistent
+ * LSTM sweeps (they need their workgroups co-resident) behind each other per device.
+ * Several PROCESSES on one GPU are not supported.  pl_step is stream-asynchronous;
  * pl_get_* and pl_step with output pointers enqueue their copies on the same stream.
  */
 #ifndef PAULE_HIP_H
