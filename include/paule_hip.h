@@ -157,15 +157,17 @@ int pl_inverse_forward(pl_handle *h, const float *mel, int n_mel_frames, float *
  *     pred_loss = self.pred_criterion(Y_hat, batch_output); pred_loss.backward(); self.pred_optimizer.step()
  * (paule/paule.py:1372-1377) with pred_criterion = RMSELoss(eps=0) over the whole batch (:288) and
  * pred_optimizer = torch.optim.Adam (:287; lr = learning_rate_learning, :473-474).
- *   n_rows      samples of the mini-batch, 1 <= n_rows <= batch; all of length T (same_size_batching, :1356-1358)
- *   cp          [n_rows, T, cp_dim]     batch_input  (cp_norm of produced samples)
- *   mel_target  [n_rows, T/2, mel_dim]  batch_output (melspec_norm_synthesized)
+ *   n_rows      samples of the mini-batch, 1 <= n_rows <= batch
+ *   n_frames    their (padded) length, 2 <= n_frames <= T: pad_batch_online pads a batch to its longest sample (:1362-1368;
+ *               same_size_batching keeps that small, :1356-1358); padded frames take part in the loss as in the reference
+ *   cp          [n_rows, n_frames, cp_dim]     batch_input  (cp_norm of produced samples)
+ *   mel_target  [n_rows, n_frames/2, mel_dim]  batch_output (melspec_norm_synthesized)
  *   loss_out    device float or NULL: pred_loss of this step (before the update)
  * The handle keeps f64 masters of every parameter and the Adam moments; the packed compute copies the planner reads
  * are refreshed by the same launch sequence, so the next pl_step / pl_get_pred uses the new weights (no re-upload,
  * contrast paule/paule.py:1372-1377 mutating pred_model in place).  Stream-asynchronous.  Clobbers only scratch. */
-int pl_train_pred_step(pl_handle *h, int n_rows, const float *cp, const float *mel_target, float lr, float beta1,
-                       float beta2, float eps, float *loss_out);
+int pl_train_pred_step(pl_handle *h, int n_rows, int n_frames, const float *cp, const float *mel_target, float lr,
+                       float beta1, float beta2, float eps, float *loss_out);
 /* Fresh torch.optim.Adam state for the parameters (moments = 0, step count = 0). */
 int pl_reset_pred_optimizer(pl_handle *h);
 /* Current parameters in torch layout (the layouts of pl_set_lstm_weights / pl_set_linear), float32 device pointers:

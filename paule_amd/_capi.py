@@ -87,7 +87,7 @@ def load_library(path: str | None = None):
     lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
     lib.pl_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_int64, C.POINTER(C.c_int64)]
     lib.pl_bench_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
-    lib.pl_train_pred_step.argtypes = [vp, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+    lib.pl_train_pred_step.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
     lib.pl_reset_pred_optimizer.argtypes = [vp]
     lib.pl_get_lstm_weights.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     lib.pl_get_linear.argtypes = [vp, C.c_int, fp, fp]

@@ -332,8 +332,8 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, 
 // weight gradients dW_hh = sum_t dA_t^T h_{t-1}, dW_ih = sum_t dA_t^T in_t, db = sum_t dA_t are taken from the dA stash
 // (in_act = the model's input slab), and the input gradient of layer 0 is not needed.
 void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn, int train_nb = 0,
-                    const void* in_act = nullptr) {
-    const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
+                    const void* in_act = nullptr, int Tl_use = 0) {
+    const int Bp = h->Bp, Hp = md.Hp, Tl = Tl_use > 0 ? Tl_use : md.Tl;
     const size_t a = h->act;
     for (int l = md.L - 1; l >= 0; --l) {
         LstmLayer& ly = md.layers[l];
@@ -948,10 +948,11 @@ int ensure_train_state(pl_handle* h, Model& md) {
 
 }  // namespace
 
-int pl_train_pred_step(pl_handle* h, int n_rows, const float* cp, const float* mel_target, float lr, float beta1, float beta2,
-                       float eps, float* loss_out) {
+int pl_train_pred_step(pl_handle* h, int n_rows, int n_frames, const float* cp, const float* mel_target, float lr, float beta1,
+                       float beta2, float eps, float* loss_out) {
     if (!h || !cp || !mel_target) return fail(PL_ERR_INVALID, "pl_train_pred_step: NULL argument");
     if (n_rows < 1 || n_rows > h->B) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_rows has to be in [1, batch]");
+    if (n_frames < 2 || n_frames > h->T) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_frames has to be in [2, n_frames of the handle]");
     if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f))
         return fail(PL_ERR_INVALID, "pl_train_pred_step: bad optimizer hyper-parameter");
     Model& p = h->pred;
@@ -961,10 +962,10 @@ int pl_train_pred_step(pl_handle* h, int n_rows, const float* cp, const float* m
     int rc = ensure_train_state(h, p);
     if (rc) return rc;
     hipStream_t st = h->stream;
-    const int Bp = h->Bp, T = h->T, Tp = h->Tp, nb = pad16(n_rows);
+    const int Bp = h->Bp, T = n_frames, Tp = n_frames / 2, nb = pad16(n_rows);
     // forward: Y_hat = pred_model(batch_input) (paule/paule.py:1372); rows >= n_rows of every slab are zero input
     launch_pack_mel(st, h->dt, cp, n_rows, T, h->C, h->X0, Bp, h->Cp);
-    model_forward(h, st, p, h->X0);
+    model_forward(h, st, p, h->X0, T);
     const LstmLayer& top = p.layers[p.L - 1];
     launch_gemm_nt(st, h->dt, true, top.h, p.Hp, p.Wlin, p.Hp, p.blin, h->Y, h->Mp, T * Bp, h->Mp, p.Hp);
     launch_pool_mel(st, h->dt, h->Y, n_rows, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm);
@@ -976,7 +977,7 @@ int pl_train_pred_step(pl_handle* h, int n_rows, const float* cp, const float* m
                    p.train_scratch_bytes, h->n_cu);
     launch_colsum(st, h->dt, h->dY, h->Mp, h->Mp, Bp, nb, T, 0, p.gblin, p.colsum_part);
     launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, T * Bp, p.Hp, h->Mp);
-    model_backward(h, st, p, nullptr, nullptr, nb, h->X0);
+    model_backward(h, st, p, nullptr, nullptr, nb, h->X0, T);
     // pred_optimizer.step() (paule/paule.py:1377; torch.optim.Adam defaults, :287) + refresh of the packed compute copies
     p.train_steps += 1;
     AdamHyper hp{(double)lr, (double)beta1, (double)beta2, (double)eps, 1.0 - std::pow((double)beta1, (double)p.train_steps),

@@ -203,7 +203,8 @@ class HipPlanner:
 
     # ---- continued learning of the predictive model (paule/paule.py:1353-1379) ------------------
     def train_pred_step(self, cp, mel_target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
-        """One ``pred_optimizer`` step on a mini-batch: ``cp`` (n, T, cp_dim) -> ``mel_target`` (n, T/2, mel_dim), n <= batch;
+        """One ``pred_optimizer`` step on a mini-batch: ``cp`` (n, t, cp_dim) -> ``mel_target`` (n, t/2, mel_dim), n <= batch,
+        t <= n_frames of the engine;
         RMSE over the whole batch, torch.optim.Adam on the parameters (paule/paule.py:287-288, :1372-1377).  Returns the
         loss of this step as a 0-d device tensor (no host sync)."""
         cp = self._dev(cp)
@@ -212,13 +213,16 @@ class HipPlanner:
         n = int(cp.shape[0])
         if not 1 <= n <= self.B:
             raise ValueError(f"mini-batch of {n} samples does not fit an engine built for batch {self.B}")
-        cp = self._dev(cp, (n, self.T, self.C))
+        t = int(cp.shape[1])
+        if not 2 <= t <= self.T:
+            raise ValueError(f"samples of {t} frames do not fit an engine built for {self.T} frames")
+        cp = self._dev(cp, (n, t, self.C))
         mel = self._dev(mel_target)
         if mel.dim() == 2:
             mel = mel.unsqueeze(0)
-        mel = self._dev(mel, (n, self.T // 2, self.M))
+        mel = self._dev(mel, (n, t // 2, self.M))
         loss = torch.empty((), dtype=torch.float32, device=self.device)
-        self._call(self.lib.pl_train_pred_step, n, cp.data_ptr(), mel.data_ptr(), C.c_float(lr), C.c_float(betas[0]),
+        self._call(self.lib.pl_train_pred_step, n, t, cp.data_ptr(), mel.data_ptr(), C.c_float(lr), C.c_float(betas[0]),
                    C.c_float(betas[1]), C.c_float(eps), loss.data_ptr())
         self._keep = (cp, mel)   # the launches are asynchronous: keep the operands alive until the next call
         return loss

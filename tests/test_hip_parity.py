@@ -366,6 +366,24 @@ def test_train_pred_f32_vs_reference_fixture(HipPlanner, golden_train, batch):
     np.testing.assert_allclose(_n(mel)[:n], g["final_pred_mel"], atol=1e-4, rtol=0)
 
 
+def test_train_pred_shorter_samples_vs_oracle(HipPlanner, golden_train):
+    """Mini-batches padded to fewer frames than the engine was built for (pad_batch_online pads to the longest sample of a
+    batch, paule/paule.py:1362-1368): 26 and 33 (odd: last frame has no mel partner) of 40 frames, against the oracle."""
+    g = golden_train
+    eng, sd = _train_engine(HipPlanner, g, "f32", batch=9)
+    tr = op.OracleTrainer(op.forward_model_from_state_dict(sd))
+    lh, lo = [], []
+    for t in (26, 33, 40, 26):
+        cp, mel = g["cps"][:4, :t], g["prod_mel"][:4, :t // 2]
+        lo.append(float(tr.train_pred_step(cp, mel)))
+        lh.append(float(eng.train_pred_step(cp.copy(), mel.copy())))
+    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32)
+    ref = tr.state_dict()
+    for name, w in eng.get_weights("pred").items():
+        d = np.abs(_n(w) - ref[name].numpy())
+        assert d.max() <= 0.02 * 1e-3 * 4 and d.mean() <= 1e-6, (name, d.max(), d.mean())
+
+
 def test_train_pred_bf16_vs_reference_fixture(HipPlanner, golden_train):
     """bf16 activations / weights with f32-accumulated gradients and f64 masters: loss curve rtol 2e-2, gradient cosine
     >= 0.999 for the big matrices, parameters within 50 % of the lr * steps budget at the worst element (Adam is sign-like
