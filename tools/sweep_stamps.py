@@ -14,15 +14,17 @@ from paule_amd import synthetic  # noqa: E402
 from paule_amd.engine import HipPlanner  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+OBJ = sys.argv[2] if len(sys.argv) > 2 else "acoustic_semvec"   # "acoustic": the last forward sweep is the predictive model's (fused input)
 wl = synthetic.make_workload(B, 300, "A")
-eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=300, objective="acoustic_semvec", dtype="bf16")
+eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=300, objective=OBJ, dtype="bf16")
 eng.set_targets(wl.target_mel, wl.target_semvec)
 eng.set_cp(wl.cp0)
 eng.step(3)
 eng.synchronize()
 raw = np.fromfile(os.environ["PL_STAMP_FILE"] + ".sweep", dtype=np.uint64).reshape(2, 256, 8).astype(np.float64) * 0.01
 for d, name, steps, labels in (
-        (0, "forward sweep (embedder layer 1, 150 steps)", 150,
+        (0, "forward sweep (embedder layer 1, 150 steps)" if OBJ != "acoustic" else "forward sweep (pred model, fused input, 300 steps)",
+         150 if OBJ != "acoustic" else 300,
          ["step top/prefetch", "wait arrivals", "h tile sc1 loads+LDS", "MFMA chain", "cell+store issue", "store drain", "barrier+add"]),
         (1, "backward sweep (pred model, 300 steps), mode " + os.environ.get("PAULE_HIP_BWD_MODE", "1"), 300,
          ["step top/prefetch", "wait arrivals", "partial ingest", "cell+stash+dA image", "MFMA+partial image", "hand-off store issue",
