@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stress the in-launch exchange of the persistent LSTM sweeps: many forward(+backward) sweeps back to back,
-counting bounded-wait timeouts.  usage: sweep_stress.py [n_rounds] [mode: pred|step]"""
+counting bounded-wait timeouts.  usage: sweep_stress.py [n_rounds] [mode: pred|step|burst] [batch] [dtype]"""
 import os
 import sys
 import time
@@ -14,8 +14,10 @@ from paule_amd.engine import HipPlanner  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 mode = sys.argv[2] if len(sys.argv) > 2 else "pred"
-wl = synthetic.make_workload(256, 300, "A")
-eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=256, n_frames=300, objective="acoustic_semvec", dtype="bf16")
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+wl = synthetic.make_workload(B, 300, "A")
+eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=300, objective="acoustic_semvec", dtype=dtype)
 eng.set_targets(wl.target_mel, wl.target_semvec)
 eng.set_cp(wl.cp0)
 fails, t0 = 0, time.time()
@@ -30,5 +32,5 @@ for i in range(n):
         eng.synchronize()
     except ValueError:
         fails += 1
-print(f"zero_mode={os.environ.get('PAULE_HIP_ZERO_MODE', '0')} mode={mode}: {fails} timeouts in {n} rounds "
+print(f"zero_mode={os.environ.get('PAULE_HIP_ZERO_MODE', '0')} mode={mode} batch={B} dtype={dtype}: {fails} timeouts in {n} rounds "
       f"({(time.time() - t0) / n * 1e3:.2f} ms per round)", flush=True)
