@@ -599,3 +599,25 @@ def test_minimum_length_and_single_utterance(HipPlanner):
         else:
             np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
             assert np.abs(_n(eng.get_cp()) - co).max() <= 0.5 * 0.01 * 5
+
+
+def test_bf16_long_run_tracks_f32(HipPlanner):
+    """A whole plan's worth of inner iterations (the reference's default: 5 outer x 24 inner = 120, paule/paule.py:399-400) on
+    Paule's default models: the bf16 path must not drift away from the f32 path -- loss curve within 2 % over all 120
+    iterations (total loss falls by orders of magnitude meanwhile), final CP within 20 % of the distance travelled."""
+    wl = synthetic.make_workload(6, 60, "A")
+    runs = {}
+    for dtype in ("f32", "bf16"):
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=6, n_frames=60, objective="acoustic_semvec", dtype=dtype)
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        loss = _n(eng.step(120))
+        eng.synchronize()
+        runs[dtype] = (loss[:, :, 0], _n(eng.get_cp()))
+    lf, cf = runs["f32"]
+    lb, cb = runs["bf16"]
+    assert np.isfinite(lb).all()
+    np.testing.assert_allclose(lb, lf, rtol=2e-2)
+    assert lf[-1].mean() < 0.5 * lf[0].mean()
+    travelled = np.abs(cf - _n(wl.cp0)).mean()
+    assert np.abs(cb - cf).mean() <= 0.2 * travelled, (np.abs(cb - cf).mean(), travelled)
