@@ -28,6 +28,8 @@ CONFIGS = {
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
     "cfg3_setB": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="B"),
     "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+    # cfg4's whole batch (2048 utterances) on ONE GPU: 15.5 GB of the 288 GB; 64 batch groups swept 8 at a time
+    "cfg4_1gpu": dict(batch=2048, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     # one pred_optimizer step of the continued learning (paule/paule.py:1372-1377), batch_size = 8 (:404)
     "train8": dict(batch=8, frames=300, objective="acoustic", dtype="bf16", model_set="A", train=True),
     "train8_f32": dict(batch=8, frames=300, objective="acoustic", dtype="f32", model_set="A", train=True),
