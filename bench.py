@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--strong-total", type=int, default=0,
+                    help="strong scaling: this many utterances in total, split evenly over the ranks (e.g. 2048 = cfg4); "
+                         "default 0 = weak scaling with the config's per-GPU batch")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if cfg.get("train"):
@@ -170,6 +173,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     B, T = cfg["batch"], cfg["frames"]
+    if args.strong_total:
+        if args.strong_total % world:
+            raise SystemExit(f"--strong-total {args.strong_total} is not divisible by {world} ranks")
+        B = args.strong_total // world
     # same random-init weights on every rank (same seed), different utterances per rank (weak scaling)
     wl = synthetic.make_workload(B, T, cfg["model_set"], seed=synthetic.SEED)
     if rank:
@@ -215,7 +222,9 @@ def main():
 
     if rank == 0:
         progress(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
-        it_s = world * args.steps / elapsed
+        # weak scaling: every rank iterates its own batch of B, the job does world x steps "batch = B" iterations;
+        # strong scaling: one iteration covers the whole --strong-total batch across the ranks
+        it_s = (1 if args.strong_total else world) * args.steps / elapsed
         flops_it = eng.flops_per_iteration
         # dominant kernel: the LSTM backward sweep of the predictive model (one launch = T steps), or the launch-per-step
         # backward kernel when the sweeps are switched off / unsupported.  Timed with hipEvents on the engine's stream.
@@ -250,18 +259,19 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "planning iters/sec, batch=256 x 300-frame CP trajs" if args.config.startswith("cfg3") else
-                      f"planning iters/sec, batch={B} x {T}-frame CP trajs",
+            "metric": "planning iters/sec, batch=256 x 300-frame CP trajs" if args.config.startswith("cfg3") and not args.strong_total
+                      else f"planning iters/sec, batch={args.strong_total or B} x {T}-frame CP trajs",
             "value": it_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.strong_total else "weak",
             "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic (random-init weights, random smooth targets)",
             "config": {"workload": f"{args.config}: {B} utterances/GPU x {T} CP frames, objective {cfg['objective']}, "
                                    f"model set {cfg['model_set']}", "objective": cfg["objective"],
                        "batch_per_gpu": B, "global_batch": B * world, "n_frames": T, "model_set": cfg["model_set"],
                        "parallelism": f"batch-sharded x{world}, no collective in the loop", "hip_graph": not args.no_graph},
-            "utt_iters_per_s": it_s * B,
+            "utt_iters_per_s": world * B * args.steps / elapsed,
             "algorithmic_gflop_per_iter": flops_it / 1e9,
-            "whole_iteration_mfma_frac": (flops_it * it_s / world) / (peak * 1e12),
+            "whole_iteration_mfma_frac": (flops_it * args.steps / elapsed) / (peak * 1e12),   # per GPU
             "finite": finite, "final_loss_mean": float(loss[-1, :, 0].mean().item()),
             "device_bytes": eng.device_bytes,
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak,
