@@ -69,6 +69,10 @@ void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, cons
 // backward sweep in reduce-scatter form (lstm_persist_rs.hip): same arguments + a.xchg of lstm_rs_exchange_bytes()
 size_t lstm_rs_exchange_bytes(int Hp, int Bp);
 void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a);
+// bf16 sweeps on groups of 16 rows for batches of up to 128 rows (lstm_persist16.hip); same arguments, group_rows <= 16
+bool lstm_sweep16_wanted(int Hp, int Bp, int n_cu);
+int lstm_sweep16_grid(int Hp, int Bp, int n_cu, bool spread_small);
+void launch_lstm_sweep16(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
 // f32 sweeps (lstm_persist_f32.hip): groups of 16 rows, Hp / 16 workgroups per group, backward in reduce-scatter form
 bool lstm_sweep_f32_supported(int Hp);
 int lstm_sweep_f32_grid(int Hp, int Bp, int n_cu);

@@ -163,6 +163,7 @@ struct pl_handle {
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
+    bool sweep16 = true;        // PAULE_HIP_SWEEP16: 16-row groups for bf16 batches of up to 128 rows (lstm_persist16.hip)
     bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
                                 // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
@@ -258,15 +259,26 @@ void zero_sweep_counters(pl_handle* h, hipStream_t st) {
 }
 
 // persistent-sweep dispatch by arithmetic type: grid 0 = launch-per-step kernels
-int sweep_grid_for(pl_handle* h, int Hp) {
+// 16-row groups (lstm_persist16.hip) for small bf16 batches; the backward needs the reduce-scatter exchange
+bool use_sweep16(pl_handle* h, int Hp, bool bwd) {
+    if (h->dt != BF16 || !h->sweep16 || !lstm_sweep_supported(h->dt, Hp) || !lstm_sweep16_wanted(Hp, h->Bp, h->n_cu)) return false;
+    return !bwd || (h->bwd_mode == 1 && h->sweep_xchg);
+}
+int sweep_grid_for(pl_handle* h, int Hp, bool bwd = false) {
     if (!h->use_sweep) return 0;
     if (h->dt == F32) return (h->f32_sweep && lstm_sweep_f32_supported(Hp)) ? lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu) : 0;
+    if (use_sweep16(h, Hp, bwd)) return lstm_sweep16_grid(Hp, h->Bp, h->n_cu, h->small_grid);
     return lstm_sweep_supported(h->dt, Hp) ? lstm_sweep_grid(Hp, h->Bp, h->n_cu, h->small_grid) : 0;
 }
-int sweep_group_rows_for(pl_handle* h, int Hp) { return h->dt == F32 ? 16 : lstm_sweep_group_rows(Hp, h->Bp, h->n_cu); }
+int sweep_group_rows_for(pl_handle* h, int Hp, bool bwd = false) {
+    if (h->dt == F32 || use_sweep16(h, Hp, bwd)) return 16;
+    return lstm_sweep_group_rows(Hp, h->Bp, h->n_cu);
+}
 void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, const LstmSweepArgs& s) {
     if (h->dt == F32)
         launch_lstm_sweep_f32(st, bwd, Hp, grid, s);
+    else if (use_sweep16(h, Hp, bwd))
+        launch_lstm_sweep16(st, bwd, Hp, grid, s);
     else if (bwd && h->bwd_mode == 1 && h->sweep_xchg)
         launch_lstm_bwd_rs_sweep(st, Hp, grid, s);
     else
@@ -338,12 +350,12 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
     for (int l = md.L - 1; l >= 0; --l) {
         LstmLayer& ly = md.layers[l];
         const bool sparse_top = (l == md.L - 1) && dh_last;
-        const int sweep_grid = sweep_grid_for(h, Hp);
+        const int sweep_grid = sweep_grid_for(h, Hp, true);
         if (sweep_grid > 0) {
             LstmSweepArgs s{};
             s.Bp = Bp;
             s.T = Tl;
-            s.group_rows = sweep_group_rows_for(h, Hp);
+            s.group_rows = sweep_group_rows_for(h, Hp, true);
             s.G = ly.G;
             s.W = ly.WhhT;
             s.c = ly.c;
@@ -646,6 +658,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_SMALL_GRID")) h->small_grid = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_SWEEP16")) h->sweep16 = std::atoi(z) != 0;
         if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
             size_t xb = lstm_sweep_f32_supported(h->pred.Hp) ? lstm_f32_exchange_bytes(h->pred.Hp, h->Bp) : 0;
             if (cfg->emb_layers > 0 && lstm_sweep_f32_supported(h->emb.Hp)) {
@@ -1133,12 +1146,12 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
     const int Bp = h->Bp, Hp = md.Hp, Tl = md.Tl;
     const size_t a = h->act;
     if (kernel >= PL_KERNEL_LSTM_FWD_SWEEP) {
-        const int grid = sweep_grid_for(h, Hp);
-        if (grid <= 0) return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: the persistent sweep is not used for this dtype / shape");
         const bool bwd = kernel == PL_KERNEL_LSTM_BWD_SWEEP;
+        const int grid = sweep_grid_for(h, Hp, bwd);
+        if (grid <= 0) return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: the persistent sweep is not used for this dtype / shape");
         LstmSweepArgs s{};
         s.Bp = Bp; s.T = Tl; s.G = ly.G; s.W = bwd ? ly.WhhT : ly.Whh; s.h = ly.h; s.c = ly.c;
-        s.group_rows = sweep_group_rows_for(h, Hp);
+        s.group_rows = sweep_group_rows_for(h, Hp, bwd);
         s.dh_ext = bwd ? md.dh_ext : nullptr;
         s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
         s.flag_stride = h->flag_stride;

@@ -279,7 +279,7 @@ def test_bf16_model_gradients_in_isolation(HipPlanner, golden_small):
         assert _cos(_n(grad)[0], g[key]) >= COS_BF16, term
 
 
-def test_full_size_properties_bf16(HipPlanner):
+def test_full_size_properties_bf16(HipPlanner, monkeypatch):
     """BASELINE.json's headline shape (B = 256, T = 300, set A, acoustic_semvec, bf16): size-independent properties.
     (1) batch rows are independent: utterance b of the big batch == the same utterance planned in a batch of 16;
     (2) the loss decreases; (3) CP stays inside the clamp; (4) replaying from the same start is bit-identical."""
@@ -293,13 +293,20 @@ def test_full_size_properties_bf16(HipPlanner):
     assert np.isfinite(loss).all() and np.isfinite(cp).all()
     assert (loss[-1, :, 0] < loss[0, :, 0]).all()
     assert np.abs(cp).max() <= 1.05 + 1e-6
-    sub = HipPlanner(wl.pred_sd, wl.emb_sd, batch=16, n_frames=T, objective="acoustic_semvec", dtype="bf16")
     sl = slice(100, 116)
-    sub.set_targets(wl.target_mel[sl], wl.target_semvec[sl])
-    sub.set_cp(wl.cp0[sl])
-    loss_s = _n(sub.step(6))
-    np.testing.assert_array_equal(loss_s, loss[:, sl])
-    np.testing.assert_array_equal(_n(sub.get_cp()), cp[sl])
+    for sweep16 in ("0", "1"):   # 0: the same 32-row kernels as the big batch -> bit-equal; 1: the 16-row kernels a batch of 16 gets by default
+        monkeypatch.setenv("PAULE_HIP_SWEEP16", sweep16)
+        sub = HipPlanner(wl.pred_sd, wl.emb_sd, batch=16, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        sub.set_targets(wl.target_mel[sl], wl.target_semvec[sl])
+        sub.set_cp(wl.cp0[sl])
+        loss_s = _n(sub.step(6))
+        if sweep16 == "0":
+            np.testing.assert_array_equal(loss_s, loss[:, sl])
+            np.testing.assert_array_equal(_n(sub.get_cp()), cp[sl])
+        else:
+            np.testing.assert_allclose(loss_s, loss[:, sl], rtol=2e-3, atol=2e-4)
+            assert np.abs(_n(sub.get_cp()) - cp[sl]).mean() <= 1e-4
+    monkeypatch.delenv("PAULE_HIP_SWEEP16")
     eng.set_cp(wl.cp0)
     eng.reset_optimizer()
     np.testing.assert_array_equal(_n(eng.step(6)), loss)
@@ -621,3 +628,30 @@ def test_bf16_long_run_tracks_f32(HipPlanner):
     assert lf[-1].mean() < 0.5 * lf[0].mean()
     travelled = np.abs(cf - _n(wl.cp0)).mean()
     assert np.abs(cb - cf).mean() <= 0.2 * travelled, (np.abs(cb - cf).mean(), travelled)
+
+
+@pytest.mark.parametrize("shape", [dict(B=3, T=40, set=None), dict(B=20, T=30, set="A"), dict(B=100, T=24, set="B")])
+def test_bf16_sweep16_equals_sweep32(HipPlanner, golden_small, shape, monkeypatch):
+    """Batches of up to 128 rows use groups of 16 rows on the 16x16x32 MFMA (lstm_persist16.hip); same arithmetic as the
+    32-row kernels up to the f32 summation order of the MFMA k-steps and of the partial dh tiles: loss curves agree to
+    2e-3, CP to 2e-3 (bf16 noise through Adam), and both sit inside the bf16 bars against the oracle elsewhere."""
+    if shape["set"] is None:
+        g = golden_small
+        mk = lambda: _engine(HipPlanner, g, "acoustic_semvec", dtype="bf16")
+    else:
+        wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
+        def mk():
+            e = HipPlanner(wl.pred_sd, wl.emb_sd, batch=shape["B"], n_frames=shape["T"], objective="acoustic_semvec", dtype="bf16")
+            e.set_targets(wl.target_mel, wl.target_semvec)
+            e.set_cp(wl.cp0)
+            return e
+    outs = []
+    for s16 in ("1", "0"):
+        monkeypatch.setenv("PAULE_HIP_SWEEP16", s16)
+        eng = mk()
+        loss = _n(eng.step(5))
+        eng.synchronize()
+        outs.append((loss, _n(eng.get_cp())))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-3, atol=2e-4)
+    d = np.abs(outs[0][1] - outs[1][1])
+    assert d.max() <= 0.5 * 0.01 * 5 and d.mean() <= 1e-4, (d.max(), d.mean())
