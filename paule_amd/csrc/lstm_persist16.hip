@@ -17,6 +17,10 @@
 // All six outputs of a forward step (h hand-off + 4 gates + c stash) leave through LDS as whole 64-byte row pieces.
 #include "sweep_common.h"
 
+#ifndef PL16_OCC
+#define PL16_OCC 1   // workgroups per CU the kernels are compiled for (2: <= 256 registers per lane)
+#endif
+
 namespace pl {
 
 namespace {
@@ -30,7 +34,7 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builti
 // forward
 // ---------------------------------------------------------------------------------------------------
 template <int KS, int KSX>   // KS = Hp / 16; KSX = in_p / 32 (0: G holds the precomputed input projection)
-__global__ __launch_bounds__(256, 1) void lstm_fwd16_sweep_kernel(LstmSweepArgs a) {
+__global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
     constexpr int KS32 = KS / 2;                 // MFMA k-steps of 32
     constexpr int ROWB = Hp * 2;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd16_sweep_kernel(LstmSweepArgs 
 // backward (reduce-scatter of partial dh tiles; backward-DATA only)
 // ---------------------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(256, 1) void lstm_bwd16_rs_sweep_kernel(LstmSweepArgs a) {
+__global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
     constexpr int P = Hp / 32;
     constexpr int NTT = Hp / 16;                 // N tiles of 16 hidden units
@@ -394,14 +398,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_rs_sweep_kernel(LstmSweepAr
 // 16-row groups pay when all of them are resident at once (8 per 23-workgroup slice set at H = 720): batches up to 128 rows
 bool lstm_sweep16_wanted(int Hp, int Bp, int n_cu) {
     const int P = Hp / 32;
-    if (P < 1 || Bp > 128) return false;
+    if (P < 1 || Bp > 128 * PL16_OCC) return false;
     const int groups = (Bp + 15) / 16;
-    return groups * P <= n_cu || Bp <= 16;
+    return groups * P <= PL16_OCC * n_cu || Bp <= 16;
 }
 
 int lstm_sweep16_grid(int Hp, int Bp, int n_cu, bool spread_small) {
     const int P = Hp / 32, groups = (Bp + 15) / 16;
-    int res = n_cu / P;
+    int res = PL16_OCC * n_cu / P;
     if (res < 1) return 0;
     if (spread_small && groups < 8 && res >= 8) return 8 * P;   // 8 group slots keep a group on one XCD (lstm_persist.hip)
     if (res > groups) res = groups;
