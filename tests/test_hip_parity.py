@@ -655,3 +655,36 @@ def test_bf16_sweep16_equals_sweep32(HipPlanner, golden_small, shape, monkeypatc
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-3, atol=2e-4)
     d = np.abs(outs[0][1] - outs[1][1])
     assert d.max() <= 0.5 * 0.01 * 5 and d.mean() <= 1e-4, (d.max(), d.mean())
+
+
+def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
+    """Nonzero return code -> ValueError with the library's message (the reference's convention for its one C library,
+    paule/util.py:33-34): call-sequence errors (PL_ERR_STATE) and bad arguments (PL_ERR_INVALID); nothing aborts, and the
+    handle stays usable afterwards."""
+    g = golden_small
+    sd_p, sd_e = state_dict_from(g, "pred"), state_dict_from(g, "emb")
+    eng = HipPlanner(sd_p, sd_e, batch=int(g["B"]), n_frames=int(g["T"]), objective="acoustic_semvec")
+    with pytest.raises(ValueError, match="pl_set_cp has not been called"):
+        eng.step(1)
+    eng.set_cp(g["cp0"])
+    with pytest.raises(ValueError, match="pl_set_targets has not been called"):
+        eng.step(1)
+    eng.set_targets(g["target_mel"], None)
+    with pytest.raises(ValueError, match="target_semvec"):
+        eng.step(1)                                    # acoustic_semvec without a semantic target
+    with pytest.raises(ValueError, match="expected shape"):
+        eng.set_cp(g["cp0"][:, :-1])                   # wrong length is caught on the host
+    with pytest.raises(ValueError, match="without inv_model"):
+        eng.inverse_forward(g["target_mel"])
+    with pytest.raises(ValueError, match="does not fit an engine"):
+        eng.train_pred_step(np.zeros((int(g["B"]) + 1, int(g["T"]), 30), np.float32), np.zeros((int(g["B"]) + 1, int(g["T"]) // 2, 60), np.float32))
+    with pytest.raises(ValueError, match="n_frames"):
+        eng._call(eng.lib.pl_train_pred_step, 1, 1, 1, 1, 0.001, 0.9, 0.999, 1e-8, None)   # n_frames = 1 (the non-NULL dummy pointers are never touched)
+    eng.set_targets(g["target_mel"], g["target_semvec"])
+    eng.set_cp(g["cp0"])
+    loss = _n(eng.step(20))
+    np.testing.assert_allclose(loss, g["acoustic_semvec/loss_log"], rtol=LOSS_RTOL_F32, atol=1e-7)   # still a working handle
+    with pytest.raises(ValueError, match="need an embedder"):
+        HipPlanner(sd_p, None, batch=2, n_frames=20, objective="semvec")
+    with pytest.raises(ValueError, match="n_frames must be >= 14"):
+        HipPlanner(sd_p, sd_e, batch=2, n_frames=12)
