@@ -60,6 +60,7 @@ struct LstmSweepArgs {
     const void* Wih;       // packed [4*Hp][in_p]
     const float* bias;     // b_ih + b_hh, [4*Hp]
     int in_p;
+    int stash_via_lds;     // forward, 32-row kernel: 1 = the five stash arrays leave through LDS as 64-byte row pieces
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
     static_assert(KS % 2 == 0, "Hp is a multiple of 32");
     constexpr int HRS = 64 + 16;                 // row stride of the outgoing h tile [32 rows][32 units] bf16
     __shared__ __attribute__((aligned(16))) unsigned char himg[32 * RS];
-    __shared__ __attribute__((aligned(16))) unsigned char hst[32 * HRS];
+    __shared__ __attribute__((aligned(16))) unsigned char hst[6 * 32 * HRS];   // [h, gates i f g o, c][32 rows][32 units]
     __shared__ __attribute__((aligned(16))) unsigned char ximg[KSX ? 32 * XRS : 16];
     __shared__ int lds_flag;
 
@@ -203,6 +203,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
             // leave as ONE instruction's contiguous piece (4 lanes x 16 B): whole sectors, which the consumers' reads
             // of the shared L2 need (16-byte pieces from four different waves read back at half the rate)
             *reinterpret_cast<uint2*>(hst + bl * HRS + (8 * wave + 4 * hh) * 2) = pack_bf16x4(vh[0], vh[1], vh[2], vh[3]);
+            const bool stash_lds = a.stash_via_lds != 0;
+            if (stash_lds) {   // the five stash arrays leave through LDS too: whole 64-byte row pieces instead of 8-byte scatters
+                unsigned char* o = hst + 32 * HRS + bl * HRS + (8 * wave + 4 * hh) * 2;
+                *reinterpret_cast<uint2*>(o) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);
+                *reinterpret_cast<uint2*>(o + 32 * HRS) = pack_bf16x4(vf[0], vf[1], vf[2], vf[3]);
+                *reinterpret_cast<uint2*>(o + 2 * 32 * HRS) = pack_bf16x4(vg[0], vg[1], vg[2], vg[3]);
+                *reinterpret_cast<uint2*>(o + 3 * 32 * HRS) = pack_bf16x4(vo[0], vo[1], vo[2], vo[3]);
+                *reinterpret_cast<uint2*>(o + 4 * 32 * HRS) = pack_bf16x4(vc[0], vc[1], vc[2], vc[3]);
+            }
             __syncthreads();
             if (tid < 128) {
                 const int row = tid >> 2, qt = tid & 3;
@@ -217,7 +226,28 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
                     else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
                 }
             }
-            asm volatile("" ::: "memory");   // keep the five stash stores behind it
+            asm volatile("" ::: "memory");   // keep the stash stores behind it
+            if (stash_lds) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int e = tid + 256 * i;   // piece: array e / 128, row (e % 128) / 4, quarter e % 4
+                    if (e < 640) {
+                        const int arr = e >> 7, row = (e & 127) >> 2, qt = e & 3, rb = gs * g + row;
+                        if (row < gs && rb < Bp) {
+                            const uint4 sv = *reinterpret_cast<const uint4*>(hst + (arr + 1) * 32 * HRS + row * HRS + qt * 16);
+                            bf16_t* dst = arr < 4 ? G + (size_t)t * slabG + (size_t)rb * G4 + arr * Hp + 32 * p + 8 * qt
+                                                  : Cs + (size_t)t * slabH + (size_t)rb * Hp + 32 * p + 8 * qt;
+                            *reinterpret_cast<uint4*>(dst) = sv;
+                        }
+                    }
+                }
+                PL_ST(4);
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the hand-off store is older than the (at most 3) stash stores
+                PL_ST(5);
+                publish<3>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
+                PL_ST(6);
+                continue;
+            }
             if (ok) {
                 bf16_t* go = G + (size_t)t * slabG + (size_t)b * G4 + j;
                 *reinterpret_cast<uint2*>(go) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);
