@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
     constexpr int HRS = 64 + 16;                 // outgoing h tile [16 rows][16 units] f32
     constexpr int XRS = KSX * 64 + 16;           // x_t image [16 rows][in_p] f32
     __shared__ __attribute__((aligned(16))) unsigned char himg[16 * RS];
-    __shared__ __attribute__((aligned(16))) unsigned char hst[16 * HRS];
+    __shared__ __attribute__((aligned(16))) unsigned char hst[6 * 16 * HRS];   // [h, gates i f g o, c][16 rows][16 units] f32
     __shared__ __attribute__((aligned(16))) unsigned char ximg[KSX ? 16 * XRS : 16];
     __shared__ int lds_flag;
 
@@ -165,7 +165,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
             const float vh = vo * tanhf(c_state);
             if (t == 0 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // hand-off first: the workgroup's h tile (16 rows x 16 units) leaves as whole 64-byte row pieces
-            *reinterpret_cast<float*>(hst + bl * HRS + (4 * wave + kq) * 4) = vh;
+            {   // all six outputs leave through LDS as whole 64-byte row pieces (a lane's own values are single floats)
+                unsigned char* o = hst + bl * HRS + (4 * wave + kq) * 4;
+                *reinterpret_cast<float*>(o) = vh;
+                *reinterpret_cast<float*>(o + 1 * 16 * HRS) = vi;
+                *reinterpret_cast<float*>(o + 2 * 16 * HRS) = vf;
+                *reinterpret_cast<float*>(o + 3 * 16 * HRS) = vg;
+                *reinterpret_cast<float*>(o + 4 * 16 * HRS) = vo;
+                *reinterpret_cast<float*>(o + 5 * 16 * HRS) = c_state;
+            }
             __syncthreads();
             if (tid < 64) {
                 const int row = tid >> 2, qt = tid & 3;
@@ -173,19 +181,22 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
                 const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 4));
                 st16_handoff(ro, (unsigned)(((16 * g + row) * Hp + 16 * p + 4 * qt) * 4), hv, plain_handoff);
             }
-            asm volatile("" ::: "memory");   // keep the five stash stores behind it
-            {
-                float* go = G + (size_t)t * slabG + (size_t)b * G4 + j;
-                go[0] = vi;
-                go[Hp] = vf;
-                go[2 * Hp] = vg;
-                go[3 * Hp] = vo;
-                Cs[(size_t)t * slabH + (size_t)b * Hp + j] = c_state;
+            asm volatile("" ::: "memory");   // keep the stash stores behind it
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + 256 * i;   // piece: array e / 64 (gates i f g o, c), row (e % 64) / 4, quarter e % 4
+                if (e < 320) {
+                    const int arr = e >> 6, row = (e & 63) >> 2, qt = e & 3, rb = 16 * g + row;
+                    const float4 sv = *reinterpret_cast<const float4*>(hst + (arr + 1) * 16 * HRS + row * HRS + qt * 16);
+                    float* dst = arr < 4 ? G + (size_t)t * slabG + (size_t)rb * G4 + arr * Hp + 16 * p + 4 * qt
+                                         : Cs + (size_t)t * slabH + (size_t)rb * Hp + 16 * p + 4 * qt;
+                    *reinterpret_cast<float4*>(dst) = sv;
+                }
             }
             PL_ST(4);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the hand-off store is older than the (at most 2) stash stores
             PL_ST(5);
-            publish<5>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
+            publish<2>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
         }
     }
