@@ -1164,6 +1164,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         PL_HIP(hipEventCreate(&e1));
         PL_HIP(hipEventRecord(e0, h->stream));
         s.xchg = h->sweep_xchg;
+        s.stash_via_lds = h->stash_lds ? 1 : 0;
         for (int i = 0; i < reps; ++i) {
             zero_sweep_counters(h, h->stream);
             launch_sweep(h, h->stream, bwd, Hp, grid, s);
