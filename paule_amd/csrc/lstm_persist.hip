@@ -17,16 +17,15 @@
 //             through LDS, then each thread runs the cell backward for (1 batch row x 4 hidden units).
 //             The running dc never leaves registers.
 //
-// In-launch exchange (all P workgroups of a group need the whole h_t / dA_t of the group): the producers
-// store their slice WRITE-THROUGH (sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup
-// barriers, ONE lane adds 1 to the group's per-step arrival counter (agent scope).  Consumers: one lane
-// polls the counter with sc1 loads until it reads P, the workgroup barriers, then EVERY load of the
-// handed-off bytes is an sc1 buffer load (L1 bypass) -- the form of the MI355X guide's hand-off table,
-// row 1 (one lane per storing workgroup signals for all its stores; 8/16-byte sc1 stores and loads; one
-// workgroup per CU; hipMalloc memory).  Counters are zeroed by a memset node before every launch.
-// Every spin is bounded (s_memrealtime); on timeout a status word is set and every workgroup leaves.
-// Results do not depend on placement or dispatch order; same-XCD placement of a group (blockIdx % groups)
-// is a speed choice only.
+// In-launch exchange (all P workgroups of a group need the whole h_t / dA_t of the group; sweep_common.h): the producers
+// store their slice WRITE-THROUGH (sc1), every storing wave drains its hand-off stores with a counted s_waitcnt (the
+// stash stores issued behind them stay in flight), the workgroup barriers, ONE lane raises the workgroup's arrival
+// flag for the step.  Consumers: one wave polls the P flags of the step with one sc1 load per poll (lane i reads flag
+// i), the workgroup barriers, then EVERY load of the handed-off bytes is an sc1 buffer load (L1 bypass) -- the form of
+// the MI355X guide's hand-off table, row 1.  Flags are zeroed before every launch by a kernel of ours (sc1 stores;
+// hipMemset nodes are not ordered under back-to-back graph replay).  Every spin is bounded (s_memrealtime); on a
+// timeout a status word is set and every workgroup leaves.  Results do not depend on placement or dispatch order;
+// a group whose workgroups find themselves on one XCD may hand off through the shared L2 (verified at run time).
 #include "sweep_common.h"
 
 namespace pl {
