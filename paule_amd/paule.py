@@ -101,16 +101,30 @@ class Paule():
             raise NotImplementedError("use_somatosensory_feedback is not on the MI355X planning path (SURVEY.md 8f rank 4)")
         self.use_somatosensory_feedback = False
         self.use_speech_classifier = use_speech_classifier
-        self.speech_classifier = speech_classifier
+        # default models: the reference loads its pretrained weights from paule/pretrained_models/ next to the module
+        # (paule/paule.py:121-127, :146-150, :167-171, :215-222; a 200 MB download, paule/util.py:936-955).  Same file names, looked
+        # up under $PAULE_PRETRAINED_DIR or <this package>/pretrained_models; the architecture is read off the state dict.
+        def pretrained(rel, what, needed=True):
+            import os
+            root = os.environ.get("PAULE_PRETRAINED_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pretrained_models")
+            path = os.path.join(root, rel)
+            if not os.path.isfile(path):
+                if not needed:
+                    return None
+                raise FileNotFoundError(f"{what}: pretrained weights are not bundled (looked for {path}); pass {what}= (a module or "
+                                        "state dict) or point PAULE_PRETRAINED_DIR at the reference's pretrained_models directory")
+            return torch.load(path, map_location="cpu", weights_only=True)
+
         if use_speech_classifier and speech_classifier is None:
-            # the reference loads pretrained_models/speech_classifier/linear_model_rec_as_nonspeech.pt (paule/paule.py:215-222)
-            raise FileNotFoundError("pretrained weights are not bundled: pass speech_classifier= (a Linear(60 -> 1) module "
-                                    "or state dict with linear.weight / linear.bias, paule/models.py:887-910)")
-        if pred_model is None or embedder is None:
-            # the reference loads paule/pretrained_models/*.pt here (paule/paule.py:121-175); that 200 MB download
-            # (paule/util.py:936-955) does not exist offline, so the models have to be handed in.
-            raise FileNotFoundError("pretrained weights are not bundled: pass pred_model= and embedder= "
-                                    "(paule_amd.models.ForwardModel / EmbeddingModel or state dicts)")
+            speech_classifier = pretrained("speech_classifier/linear_model_rec_as_nonspeech.pt", "speech_classifier")
+        self.speech_classifier = speech_classifier
+        if pred_model is None:
+            pred_model = pretrained("predictive/pred_model_common_voice_1_720_lr_0001_50_00001_50_000001_50_0000001_200.pt", "pred_model")
+        if embedder is None:
+            embedder = pretrained("embedder/embed_model_common_voice_syn_rec_2_720_0_dropout_07_noise_6e05_rmse_lr_00001_200.pt", "embedder")
+        if inv_model is None:   # only needed by initialize_from="acoustic": optional here
+            inv_model = pretrained("inverse/inv_model_common_voice_3_1_720_5_lr_0001_50_00001_50_000001_50_0000001_200.pt", "inv_model",
+                                   needed=False)
         self.pred_model = pred_model
         self.embedder = embedder
         self.inv_model = inv_model

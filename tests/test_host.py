@@ -167,10 +167,29 @@ def test_initialize_from_acoustic_on_the_planner(small, golden_inverse):
     np.testing.assert_allclose(res.initial_cp[:, 6:], golden_inverse["cp_clipped"][:2], atol=1e-12)
 
 
+def test_default_models_from_pretrained_dir(small, golden_inverse, tmp_path, monkeypatch):
+    """Paule() without models loads the reference's pretrained files (paule/paule.py:121-127, :146-150, :167-171) from
+    $PAULE_PRETRAINED_DIR when they are there, and says which file is missing when they are not."""
+    monkeypatch.setenv("PAULE_PRETRAINED_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="pred_model_common_voice_1_720"):
+        pp.Paule(planner_factory=_factory, device=torch.device("cpu"))
+    files = {"predictive/pred_model_common_voice_1_720_lr_0001_50_00001_50_000001_50_0000001_200.pt": small.pred_sd,
+             "embedder/embed_model_common_voice_syn_rec_2_720_0_dropout_07_noise_6e05_rmse_lr_00001_200.pt": small.emb_sd,
+             "inverse/inv_model_common_voice_3_1_720_5_lr_0001_50_00001_50_000001_50_0000001_200.pt": state_dict_from(golden_inverse, "inv")}
+    for rel, sd in files.items():
+        (tmp_path / rel).parent.mkdir(parents=True, exist_ok=True)
+        torch.save({k: v.clone() for k, v in sd.items()}, tmp_path / rel)
+    model = pp.Paule(planner_factory=_factory, device=torch.device("cpu"))
+    assert set(model.pred_model) == set(small.pred_sd) and set(model.inv_model) == set(files[list(files)[2]])
+    res = model.plan_resynth(target_acoustic=golden_inverse["mel"][:1], initialize_from="acoustic", objective="acoustic", n_outer=1,
+                             n_inner=2, log_ii=2, continue_learning=False, verbose=False)
+    np.testing.assert_allclose(res.initial_cp, golden_inverse["cp_clipped"][0], atol=1e-12)
+
+
 def test_speech_classifier_config(small):
     """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
     clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}
-    with pytest.raises(FileNotFoundError):
+    with pytest.raises(FileNotFoundError, match="speech_classifier"):
         pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, use_speech_classifier=True)
     model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory, device=torch.device("cpu"),
                      use_speech_classifier=True, speech_classifier=clf)
