@@ -133,6 +133,11 @@ class Paule():
         self.pred_optimizer = pred_optimizer
         self.inv_optimizer = inv_optimizer
         self.continue_data = continue_data
+        self.continue_data_limit = 1000   # max amount of training data stored in the instance (paule/paule.py:277)
+        if self.continue_data is not None and len(self.continue_data) > self.continue_data_limit:   # :279-282
+            keep = random.sample(range(len(self.continue_data)), self.continue_data_limit)
+            self.continue_data = (self.continue_data.iloc[keep].reset_index(drop=True) if hasattr(self.continue_data, "iloc")
+                                  else [self.continue_data[i] for i in keep])
         self.compute_dtype = compute_dtype
         self.synthesizer = synthesizer
         self.mel_extractor = mel_extractor
@@ -189,27 +194,76 @@ class Paule():
             idxs += idxs[:batch_size - df_length % batch_size]
         return [idxs[i * batch_size:(i + 1) * batch_size] for i in range(len(idxs) // batch_size)]
 
-    def _continue_learning_pred(self, planner, cp_steps_ii, prod_mel_steps_ii, *, n_batches, batch_size, n_epochs, lr):
-        """Continued learning of ``pred_model`` on the samples produced in this outer iteration (paule/paule.py:1244-1248,
-        :1289-1320, :1353-1379 with add_training_data_pred=False): sample at most batch_size * n_batches produced
-        (cp, mel) pairs, then n_epochs epochs of same-size mini-batches, each one ``pred_optimizer`` step on the device.
-        Returns the mean loss of every epoch (``pred_model_loss``, :1406).  With B > 1 every utterance of a logged step is
-        one produced sample.  ``self.pred_model`` is brought in sync with the trained parameters afterwards."""
-        cps = np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, *np.shape(c)[-2:]) for c in cp_steps_ii])
-        mels = np.concatenate([np.asarray(m, dtype=np.float32).reshape(-1, *np.shape(m)[-2:]) for m in prod_mel_steps_ii])
-        n = len(cps)
-        k = n if n < batch_size * n_batches else batch_size * n_batches           # :1289-1303
+    def _continue_learning_pred(self, planner, cp_steps_ii, prod_mel_steps_ii, *, n_batches, batch_size, n_epochs, lr,
+                                add_training_data_pred=False, target_semvec=None):
+        """Continued learning of ``pred_model`` after an outer iteration (paule/paule.py:1244-1320, :1353-1379, :1406,
+        :1439-1443): the (cp, mel) pairs produced in this iteration -- with ``add_training_data_pred`` half of every batch comes
+        from ``self.continue_data`` instead (:1250-1287) -- are sampled, sorted by length and cut into same-size mini-batches for
+        ``n_epochs`` epochs; a batch is padded to its longest sample by repeating the last frame (``pad_batch_online``,
+        paule/util.py:674-726) and is one ``pred_optimizer`` step on the device.  Returns the mean loss of every epoch
+        (``pred_model_loss``).  With B > 1 every utterance of a logged step is one produced sample.  Afterwards
+        ``self.pred_model`` holds the trained parameters and ``self.continue_data`` has grown by the produced samples."""
+        prod_cps = [np.asarray(x, dtype=np.float32) for c in cp_steps_ii for x in np.asarray(c).reshape(-1, *np.shape(c)[-2:])]
+        prod_mels = [np.asarray(x, dtype=np.float32) for m in prod_mel_steps_ii for x in np.asarray(m).reshape(-1, *np.shape(m)[-2:])]
+        n = len(prod_cps)
+        records = None
+        if self.continue_data is not None:
+            records = self.continue_data.to_dict("records") if hasattr(self.continue_data, "to_dict") else list(self.continue_data)
+        train_cps, train_mels = None, None
+        if add_training_data_pred:
+            if not records:
+                raise ValueError("add_training_data_pred=True needs continue_data (samples with 'cp_norm' and 'melspec_norm_synthesized')")
+            half = int(0.5 * batch_size) * n_batches
+            if n < half:                                                         # :1252-1263 (order of the two draws as there)
+                pick_prod = random.sample(range(n), k=n)
+                pick_data = random.sample(range(len(records)), k=n)
+            else:                                                                # :1264-1267
+                pick_data = random.sample(range(len(records)), k=half)
+                pick_prod = random.sample(range(n), k=half)
+            train_cps = [np.asarray(records[i]["cp_norm"], dtype=np.float32) for i in pick_data] + [prod_cps[i] for i in pick_prod]
+            train_mels = [np.asarray(records[i]["melspec_norm_synthesized"], dtype=np.float32) for i in pick_data] + \
+                         [prod_mels[i] for i in pick_prod]
+        k = n if n < batch_size * n_batches else batch_size * n_batches           # :1289-1303 (drawn in either case)
         picked = random.sample(range(n), k=k)
-        cps, mels = cps[picked], mels[picked]
-        lens = np.full(k, cps.shape[1])
+        if train_cps is None:                                                     # :1310-1313
+            train_cps, train_mels = [prod_cps[i] for i in picked], [prod_mels[i] for i in picked]
+        order = np.argsort([len(c) for c in train_cps], kind="stable")            # sort_values(by="lens_input"), :1283, :1308
+        train_cps, train_mels = [train_cps[i] for i in order], [train_mels[i] for i in order]
+        lens = np.array([len(c) for c in train_cps])
         if batch_size > planner.B:
             raise ValueError(f"batch_size={batch_size} of continued learning exceeds the planner's batch {planner.B}")
+        if lens.max() > planner.T:
+            raise ValueError(f"a training sample of {lens.max()} frames does not fit the planner built for {planner.T} frames")
+
+        def padded(seqs, max_len):                                               # add_and_pad: repeat the last frame
+            return np.stack([np.concatenate((x, np.tile(x[-1:], (max_len - len(x), 1))), axis=0) for x in seqs])
+
         losses = []
         for _ in range(n_epochs):
             by_len = {int(l): np.where(lens == l)[0] for l in np.unique(lens)}    # :1313-1319 (rebuilt: shuffled in place)
-            epoch = self.create_epoch_batches(k, batch_size, shuffle=True, same_size_batching=True, training_length_dict=by_len)
-            step_losses = [planner.train_pred_step(cps[j], mels[j], lr=lr) for j in epoch]
+            epoch = self.create_epoch_batches(len(lens), batch_size, shuffle=True, same_size_batching=True, training_length_dict=by_len)
+            step_losses = []
+            for j in epoch:
+                cp_b = padded([train_cps[i] for i in j], max(len(train_cps[i]) for i in j))
+                mel_b = padded([train_mels[i] for i in j], max(len(train_mels[i]) for i in j))
+                if mel_b.shape[1] != cp_b.shape[1] // 2:
+                    raise ValueError("a training batch's mel length has to be half its cp length (ForwardModel halves the sequence)")
+                step_losses.append(planner.train_pred_step(cp_b, mel_b, lr=lr))
             losses.append(float(np.mean([float(x) for x in step_losses])))
+        if self.continue_data is not None:                                        # :1439-1443
+            vec = None if target_semvec is None else np.asarray(target_semvec)
+            new = [{"vector": None if vec is None else vec[min(i % max(len(vec), 1), len(vec) - 1)].copy(), "cp_norm": c,
+                    "melspec_norm_synthesized": m, "segment_data": False} for i, (c, m) in enumerate(zip(prod_cps, prod_mels))]
+            if hasattr(self.continue_data, "to_dict"):
+                import pandas as pd
+                data = pd.concat([self.continue_data, pd.DataFrame(new)]).reset_index(drop=True)
+                if len(data) > self.continue_data_limit:
+                    data = data.iloc[random.sample(range(len(data)), k=self.continue_data_limit)].reset_index(drop=True)
+            else:
+                data = list(self.continue_data) + new
+                if len(data) > self.continue_data_limit:
+                    data = [data[i] for i in random.sample(range(len(data)), k=self.continue_data_limit)]
+            self.continue_data = data
         if self.pred_model is not None:      # the reference trains self.pred_model in place: keep module / state dict in sync
             sd = planner.get_weights("pred")
             ref = self.pred_model.state_dict() if hasattr(self.pred_model, "state_dict") else self.pred_model
@@ -543,7 +597,8 @@ class Paule():
                 elif prod_mel_steps_ii and hasattr(planner, "train_pred_step"):
                     pred_model_loss.extend(self._continue_learning_pred(
                         planner, cp_steps_ii, prod_mel_steps_ii, n_batches=n_batches, batch_size=batch_size,
-                        n_epochs=n_epochs, lr=learning_rate_learning or 0.001))
+                        n_epochs=n_epochs, lr=learning_rate_learning or 0.001, add_training_data_pred=add_training_data_pred,
+                        target_semvec=target_semvec))
                 elif ii_outer == 0:
                     warnings.warn("continue_learning=True but nothing was synthesised (no synthesizer / mel_extractor): the "
                                   "predictive model is kept fixed", stacklevel=2)

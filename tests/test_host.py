@@ -167,6 +167,34 @@ def test_initialize_from_acoustic_on_the_planner(small, golden_inverse):
     np.testing.assert_allclose(res.initial_cp[:, 6:], golden_inverse["cp_clipped"][:2], atol=1e-12)
 
 
+def test_continue_learning_with_stored_training_data(small):
+    """add_training_data_pred=True (paule/paule.py:1250-1287): half of every training batch comes from continue_data, whose
+    samples may be shorter than the plan (padded to the batch's longest sample by repeating the last frame); the produced
+    samples are appended to continue_data afterwards (:1439-1443), here given as a pandas DataFrame like the reference's."""
+    import pandas as pd
+    rng = np.random.default_rng(3)
+    stored = pd.DataFrame({"vector": [np.zeros(300)] * 6,
+                           "cp_norm": [rng.uniform(-1, 1, (t, 30)) for t in (24, 24, 20, 20, 16, 24)],
+                           "melspec_norm_synthesized": [rng.uniform(0, 1, (t // 2, 60)) for t in (24, 24, 20, 20, 16, 24)],
+                           "segment_data": [False] * 6})
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory, device=torch.device("cpu"),
+                     synthesizer=lambda cp: (np.zeros(100), 44100), mel_extractor=lambda sig, sr: np.full((12, 60), 0.25),
+                     continue_data=stored)
+    res = model.plan_resynth(target_acoustic=small.target_mel.numpy(), target_semvec=small.target_semvec.numpy(),
+                             initial_cp=small.cp0.numpy(), initialize_from=None, objective="acoustic", n_outer=1, n_inner=4,
+                             log_ii=2, continue_learning=True, add_training_data_pred=True, n_batches=2, batch_size=2, n_epochs=2,
+                             seed=3, verbose=False)
+    assert len(res.pred_model_loss) == 2 and all(np.isfinite(res.pred_model_loss))
+    assert len(model.continue_data) == 6 + 4 and list(model.continue_data.columns) == list(stored.columns)
+    assert model.continue_data["cp_norm"].iloc[-1].shape == (24, 30)
+    with pytest.raises(ValueError, match="needs continue_data"):
+        pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=_factory, device=torch.device("cpu"),
+                 synthesizer=lambda cp: (np.zeros(100), 44100), mel_extractor=lambda sig, sr: np.full((12, 60), 0.25)
+                 ).plan_resynth(target_acoustic=small.target_mel.numpy(), initial_cp=small.cp0.numpy(), initialize_from=None,
+                                objective="acoustic", n_outer=1, n_inner=2, log_ii=2, continue_learning=True,
+                                add_training_data_pred=True, verbose=False)
+
+
 def test_default_models_from_pretrained_dir(small, golden_inverse, tmp_path, monkeypatch):
     """Paule() without models loads the reference's pretrained files (paule/paule.py:121-127, :146-150, :167-171) from
     $PAULE_PRETRAINED_DIR when they are there, and says which file is missing when they are not."""
