@@ -395,12 +395,15 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
 
 #define PL_SWEEP16_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
 
-// 16-row groups pay when all of them are resident at once (8 per 23-workgroup slice set at H = 720): batches up to 128 rows
+// 16-row groups pay when all of them are resident at once: measured up to 128 rows at H = 720 (8 groups x 23 workgroups =
+// 184 CUs, one group per XCD slot), and for narrow models at any batch that fills at most half the chip (H = 180: 6
+// workgroups per group, 256 rows = 16 groups = 96 CUs: cfg3_setB 8.55 -> 8.08 ms per iteration)
 bool lstm_sweep16_wanted(int Hp, int Bp, int n_cu) {
     const int P = Hp / 32;
-    if (P < 1 || Bp > 128 * PL16_OCC) return false;
+    if (P < 1) return false;
     const int groups = (Bp + 15) / 16;
-    return groups * P <= PL16_OCC * n_cu || Bp <= 16;
+    if (Bp <= 16) return true;
+    return groups * P <= PL16_OCC * n_cu && (Bp <= 128 * PL16_OCC || groups * P <= n_cu / 2);
 }
 
 int lstm_sweep16_grid(int Hp, int Bp, int n_cu, bool spread_small) {
