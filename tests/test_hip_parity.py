@@ -571,8 +571,9 @@ def test_two_handles_on_two_streams_do_not_starve_each_other(HipPlanner):
 
 def test_long_sequences_f32_vs_oracle(HipPlanner):
     """T = 2000 CP frames (cfg5's length; T' = 1000 embedder steps): flag / stash indexing over long sweeps, f32 against the
-    oracle on the stacked class-default models (set B), 3 iterations."""
-    wl = synthetic.make_workload(2, 2000, "B")
+    oracle on small stacked models (2 x 64 predictor, 1 x 96 embedder: the CPU oracle has to finish in seconds), 3 iterations."""
+    wl = synthetic.make_workload(2, 2000, None, pred=dict(num_lstm_layers=2, hidden_size=64),
+                                 emb=dict(num_lstm_layers=1, hidden_size=96))
     orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
                            objective="acoustic_semvec")
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=2, n_frames=2000, objective="acoustic_semvec")
@@ -583,6 +584,22 @@ def test_long_sequences_f32_vs_oracle(HipPlanner):
     eng.synchronize()
     np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
     np.testing.assert_allclose(_n(eng.get_cp()), _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+
+
+def test_long_sequences_bf16_sweeps(HipPlanner):
+    """The same length on Paule's default models in bf16 (cfg5: 16 utterances x 2000 frames; 16-row sweeps of 2000 / 1000 steps):
+    finite, falling loss, and bit-identical on replay."""
+    wl = synthetic.make_workload(16, 2000, "A")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=16, n_frames=2000, objective="acoustic_semvec", dtype="bf16")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(4))
+    eng.synchronize()
+    assert np.isfinite(loss).all() and (loss[-1, :, 0] < loss[0, :, 0]).all()
+    eng.set_cp(wl.cp0)
+    eng.reset_optimizer()
+    np.testing.assert_array_equal(_n(eng.step(4)), loss)
+    eng.synchronize()
 
 
 def test_minimum_length_and_single_utterance(HipPlanner):

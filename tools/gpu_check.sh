@@ -19,7 +19,7 @@ step() {  # name, timeout, command...
 : > gpurun_out/session.log
 for s in $STEPS; do
   case $s in
-    pytest) step pytest_gpu 900 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider ;;
+    pytest) step pytest_gpu 900 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider --durations=12 ;;
     pytest_k) step pytest_k 600 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider -k "${PYTEST_K:-f32}" ;;
     smoke) step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) step bench 400 python bench.py --steps 10 --warmup 2 ;;
