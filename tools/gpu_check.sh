@@ -1,5 +1,7 @@
 #!/bin/bash
-# One GPU-box session.  usage: tools/gpu_check.sh [step ...]   steps: pytest smoke bench bench_cfg2 rocprof (default: all)
+# One GPU-box session.  usage: tools/gpu_check.sh [step ...]
+# steps: pytest  pytest_k (PYTEST_K=expr)  smoke  bench  bench_cfg2  bench_f32  bench_train  bench_nograph  rocprof  pmc
+# (default: pytest smoke bench bench_cfg2 rocprof)
 # Stops after a timed-out / killed step (never start another GPU step after that).
 set -o pipefail
 mkdir -p gpurun_out
