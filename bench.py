@@ -258,6 +258,13 @@ def main():
                 traffic = json.load(open(tpath)).get(args.config, {}).get(kname + "_bytes_per_launch")
             except Exception:
                 traffic = None
+        # algorithmic HBM bytes per utterance-iteration = CP / Adam streams + stash written once and read once
+        spec = synthetic.MODEL_SETS[cfg["model_set"]]
+        esz = 2 if cfg["dtype"] == "bf16" else 4
+        layers = [(spec["pred"]["hidden_size"], T)] * spec["pred"]["num_lstm_layers"]
+        if cfg["objective"] != "acoustic":
+            layers += [(spec["emb"]["hidden_size"], T // 2)] * spec["emb"]["num_lstm_layers"]
+        bytes_utt = 6 * T * 30 * 4 + (T // 2) * 60 * esz + 2 * esz * sum(6 * hl * tl for hl, tl in layers)
         out = {
             "metric": "planning iters/sec, batch=256 x 300-frame CP trajs" if args.config.startswith("cfg3") and not args.strong_total
                       else f"planning iters/sec, batch={args.strong_total or B} x {T}-frame CP trajs",
@@ -272,6 +279,8 @@ def main():
             "utt_iters_per_s": world * B * args.steps / elapsed,
             "algorithmic_gflop_per_iter": flops_it / 1e9,
             "whole_iteration_mfma_frac": (flops_it * args.steps / elapsed) / (peak * 1e12),   # per GPU
+            "algorithmic_mbyte_per_utt_iter": bytes_utt / 1e6,
+            "whole_iteration_hbm_frac": (bytes_utt * B * args.steps / elapsed) / 8e12,         # per GPU, of 8 TB/s
             "finite": finite, "final_loss_mean": float(loss[-1, :, 0].mean().item()),
             "device_bytes": eng.device_bytes,
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak,
