@@ -164,6 +164,7 @@ struct pl_handle {
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
     bool stash_lds = true;      // PAULE_HIP_STASH_LDS: forward stash stores staged through LDS (whole 64-byte row pieces)
+    bool xcd_fast16 = true;     // PAULE_HIP_XCD_FAST16: forward same-XCD hand-off for the 16-row kernels
     bool sweep16 = true;        // PAULE_HIP_SWEEP16: 16-row groups for bf16 batches of up to 128 rows (lstm_persist16.hip)
     bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
                                 // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
@@ -313,7 +314,8 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, 
             s.counters = h->sweep_cnt;
             s.flag_stride = h->flag_stride;
             s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
-            s.xcd_fast = h->xcd_fast & 1;
+            // the forward same-XCD hand-off pays for the 16-row kernels (B = 8: 4.14 -> 4.02 ms, equal at B = 64), not for the 32-row ones
+            s.xcd_fast = (h->xcd_fast & 1) | ((h->xcd_fast16 && (h->xcd_fast & 2) && use_sweep16(h, Hp, false)) ? 1 : 0);
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps;
@@ -661,6 +663,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_SMALL_GRID")) h->small_grid = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_SWEEP16")) h->sweep16 = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_XCD_FAST16")) h->xcd_fast16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_STASH_LDS")) h->stash_lds = std::atoi(z) != 0;
         if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
             size_t xb = lstm_sweep_f32_supported(h->pred.Hp) ? lstm_f32_exchange_bytes(h->pred.Hp, h->Bp) : 0;
