@@ -23,6 +23,9 @@ if ROOT not in sys.path:
 
 CONFIGS = {
     # name: (batch per GPU, frames, objective, dtype, model set)
+    # cfg1: the reference's own case -- ONE utterance, Paule's default models, acoustic + semantic objective; the CPU baseline
+    # of this config runs the oracle in float64 (the reference's dtype) on that one utterance
+    "cfg1": dict(batch=1, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A", cpu_f64=True),
     "cfg2": dict(batch=64, frames=300, objective="acoustic", dtype="f32", model_set="A"),
     "cfg3": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
@@ -51,11 +54,13 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
         avail = os.cpu_count() or 1
     nthreads = max(1, min(avail, 16))
     torch.set_num_threads(nthreads)
-    sample_b = 16
+    f64 = bool(wl_args.get("cpu_f64"))
+    cdt = torch.float64 if f64 else torch.float32
+    sample_b = min(16, wl_args["batch"])
     wl = synthetic.make_workload(sample_b, wl_args["frames"], wl_args["model_set"])
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, torch.float32),
-                           op.embedding_model_from_state_dict(wl.emb_sd, torch.float32), objective=objective,
-                           dtype=torch.float32)
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, cdt),
+                           op.embedding_model_from_state_dict(wl.emb_sd, cdt), objective=objective,
+                           dtype=cdt)
     orc.set_targets(wl.target_mel, wl.target_semvec)
     orc.set_cp(wl.cp0)
     progress(f"cpu baseline: {nthreads} threads, sample of {sample_b} utterances")
@@ -69,7 +74,7 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
     return dict(value=utt_it_s / wl_args["batch"], unit=f"planning iters/sec at batch={wl_args['batch']} (extrapolated from the sample)",
                 utt_iters_per_s=utt_it_s, cores=torch.get_num_threads(), kind="port",
                 sample=f"{sample_b} utterances x {iters} iterations, T={wl_args['frames']}, {objective}, model set "
-                       f"{wl_args['model_set']}, float32, torch CPU oracle ({dt:.1f} s)")
+                       f"{wl_args['model_set']}, {'float64' if f64 else 'float32'}, torch CPU oracle ({dt:.1f} s)")
 
 
 def cpu_baseline_train(cfg, seconds_budget=20.0):
