@@ -705,3 +705,28 @@ def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
         HipPlanner(sd_p, None, batch=2, n_frames=20, objective="semvec")
     with pytest.raises(ValueError, match="n_frames must be >= 14"):
         HipPlanner(sd_p, sd_e, batch=2, n_frames=12)
+
+
+def test_full_size_cfg2_f32_against_oracle_rows(HipPlanner):
+    """cfg2 at full size (B = 64 x 300 frames, `acoustic`, f32, Paule's default predictive model): the first two utterances of the
+    batched HIP run against a float64 oracle run on those two alone (per-utterance rule a-0: the rows of a batch are B = 1
+    problems) at the f32 bar, and rows 16..31 bit-equal to a 16-utterance engine (same 16-row sweeps, no cross-row coupling)."""
+    B, T = 64, 300
+    wl = synthetic.make_workload(B, T, "A")
+    eng = HipPlanner(wl.pred_sd, None, batch=B, n_frames=T, objective="acoustic")
+    eng.set_targets(wl.target_mel, None)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(5))
+    cp = _n(eng.get_cp())
+    eng.synchronize()
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), None, objective="acoustic")
+    orc.set_targets(wl.target_mel[:2], None)
+    orc.set_cp(wl.cp0[:2])
+    lo = _n(orc.step(5))
+    np.testing.assert_allclose(loss[:, :2], lo, rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(cp[:2], _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+    sub = HipPlanner(wl.pred_sd, None, batch=16, n_frames=T, objective="acoustic")
+    sub.set_targets(wl.target_mel[16:32], None)
+    sub.set_cp(wl.cp0[16:32])
+    np.testing.assert_array_equal(_n(sub.step(5)), loss[:, 16:32])
+    np.testing.assert_array_equal(_n(sub.get_cp()), cp[16:32])
