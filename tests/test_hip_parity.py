@@ -730,3 +730,26 @@ def test_full_size_cfg2_f32_against_oracle_rows(HipPlanner):
     sub.set_cp(wl.cp0[16:32])
     np.testing.assert_array_equal(_n(sub.step(5)), loss[:, 16:32])
     np.testing.assert_array_equal(_n(sub.get_cp()), cp[16:32])
+
+
+def test_full_size_cfg3_bf16_against_oracle_rows(HipPlanner):
+    """cfg3 at full size (B = 256 x 300 frames, `acoustic_semvec`, bf16, Paule's default models): utterances 0 and 255 of the
+    batched HIP run against a float64 oracle run on those two alone, at the bf16 bars (loss rtol 2e-2 with the 5e-3 floor of
+    the small weighted terms; CP within 5 % of the lr * iterations budget on average, one lr step at worst)."""
+    B, T, n = 256, 300, 4
+    wl = synthetic.make_workload(B, T, "A")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(n))
+    cp = _n(eng.get_cp())
+    eng.synchronize()
+    rows = [0, 255]
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    orc.set_targets(wl.target_mel[rows], wl.target_semvec[rows])
+    orc.set_cp(wl.cp0[rows])
+    lo = _n(orc.step(n))
+    np.testing.assert_allclose(loss[:, rows], lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
+    d = np.abs(cp[rows] - _n(orc.get_cp()))
+    assert d.mean() <= 0.05 * 0.01 * n and d.max() <= 0.01 * n, (d.mean(), d.max())
