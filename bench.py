@@ -302,6 +302,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, cfg["objective"])
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()   # rank 0 is still timing single kernels: nobody tears the communicator down under it
         dist.destroy_process_group()
 
 
