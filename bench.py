@@ -31,6 +31,9 @@ CONFIGS = {
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
     "cfg3_setB": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="B"),
     "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+    # small enough for several ranks to share ONE GPU (two persistent sweeps side by side need all their workgroups resident):
+    # used with --dist-backend gloo --device-index 0 to rehearse the multi-rank path on a one-GPU box
+    "rehearsal": dict(batch=8, frames=60, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     # cfg4's whole batch (2048 utterances) on ONE GPU: 15.5 GB of the 288 GB; 64 batch groups swept 8 at a time
     "cfg4_1gpu": dict(batch=2048, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     # one pred_optimizer step of the continued learning (paule/paule.py:1372-1377), batch_size = 8 (:404)
@@ -151,6 +154,9 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the product path); gloo only to rehearse the multi-rank plumbing with several ranks on ONE GPU")
+    ap.add_argument("--device-index", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK)")
     ap.add_argument("--strong-total", type=int, default=0,
                     help="strong scaling: this many utterances in total, split evenly over the ranks (e.g. 2048 = cfg4); "
                          "default 0 = weak scaling with the config's per-GPU batch")
@@ -171,11 +177,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device_index < 0 else args.device_index
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    gloo = args.dist_backend == "gloo"
+    coll = (lambda t: t.cpu()) if gloo else (lambda t: t)   # gloo rehearsal: collectives on host copies
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     B, T = cfg["batch"], cfg["frames"]
     if args.strong_total:
@@ -208,7 +220,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = coll(torch.tensor([elapsed], dtype=torch.float64, device=device))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -216,10 +228,11 @@ def main():
     gather_ms = None
     cp = eng.get_cp()
     if world > 1:
-        outs = [torch.empty_like(cp) for _ in range(world)]
+        cpc = coll(cp)
+        outs = [torch.empty_like(cpc) for _ in range(world)]
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        dist.all_gather(outs, cp)
+        dist.all_gather(outs, cpc)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
     eng.synchronize()   # surfaces device-side failures (bounded in-kernel waits) -- outside the timed region
