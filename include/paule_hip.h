@@ -157,7 +157,8 @@ int pl_inverse_forward(pl_handle *h, const float *mel, int n_mel_frames, float *
  *     pred_loss = self.pred_criterion(Y_hat, batch_output); pred_loss.backward(); self.pred_optimizer.step()
  * (paule/paule.py:1372-1377) with pred_criterion = RMSELoss(eps=0) over the whole batch (:288) and
  * pred_optimizer = torch.optim.Adam (:287; lr = learning_rate_learning, :473-474).
- *   n_rows      samples of the mini-batch, 1 <= n_rows <= batch
+ *   n_rows      samples of the mini-batch, 1 <= n_rows <= batch rounded up to a multiple of 16 (the handle's padded rows: a
+ *               planner built for the reference's ONE utterance still trains on its mini-batches of 8, paule/paule.py:404)
  *   n_frames    their (padded) length, 2 <= n_frames <= T: pad_batch_online pads a batch to its longest sample (:1362-1368;
  *               same_size_batching keeps that small, :1356-1358); padded frames take part in the loss as in the reference
  *   cp          [n_rows, n_frames, cp_dim]     batch_input  (cp_norm of produced samples)

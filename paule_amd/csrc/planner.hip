@@ -625,7 +625,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     }
     if ((rc = alloc_act(h, &h->X0, T * Bp * h->Cp))) return bail(rc);
     if ((rc = dev_alloc(h, &h->Y, T * Bp * h->Mp))) return bail(rc);
-    if ((rc = dev_alloc(h, &h->mel_bm, B * Tp * h->M))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->mel_bm, Bp * Tp * h->M))) return bail(rc);   // Bp rows: a training mini-batch may use all padded rows
     if ((rc = alloc_act(h, &h->mel_tm, Tp * Bp * h->Mp))) return bail(rc);
     if ((rc = alloc_act(h, &h->dY, T * Bp * h->Mp))) return bail(rc);
     if ((rc = dev_alloc(h, &h->dX, T * Bp * h->Cp))) return bail(rc);
@@ -970,7 +970,7 @@ int ensure_train_state(pl_handle* h, Model& md) {
 int pl_train_pred_step(pl_handle* h, int n_rows, int n_frames, const float* cp, const float* mel_target, float lr, float beta1,
                        float beta2, float eps, float* loss_out) {
     if (!h || !cp || !mel_target) return fail(PL_ERR_INVALID, "pl_train_pred_step: NULL argument");
-    if (n_rows < 1 || n_rows > h->B) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_rows has to be in [1, batch]");
+    if (n_rows < 1 || n_rows > h->Bp) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_rows has to be in [1, batch rounded up to 16]");
     if (n_frames < 2 || n_frames > h->T) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_frames has to be in [2, n_frames of the handle]");
     if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f))
         return fail(PL_ERR_INVALID, "pl_train_pred_step: bad optimizer hyper-parameter");

@@ -55,6 +55,7 @@ class HipPlanner:
         self.device = torch.device("cuda", dev_index)
         pred_sd, emb_sd = _state_dict(pred_model), _state_dict(embedder)
         self.B, self.T, self.Tp = int(batch), int(n_frames), int(n_frames) // 2
+        self.train_capacity = (self.B + 15) // 16 * 16   # rows of the handle: what a training mini-batch may use
         self.objective, self.dtype = objective, dtype
         in_p, hid_p, lay_p = _lstm_dims(pred_sd)
         self.C = in_p
@@ -211,8 +212,9 @@ class HipPlanner:
         if cp.dim() == 2:
             cp = cp.unsqueeze(0)
         n = int(cp.shape[0])
-        if not 1 <= n <= self.B:
-            raise ValueError(f"mini-batch of {n} samples does not fit an engine built for batch {self.B}")
+        if not 1 <= n <= self.train_capacity:
+            raise ValueError(f"mini-batch of {n} samples does not fit an engine built for batch {self.B} "
+                             f"({self.train_capacity} rows with padding)")
         t = int(cp.shape[1])
         if not 2 <= t <= self.T:
             raise ValueError(f"samples of {t} frames do not fit an engine built for {self.T} frames")

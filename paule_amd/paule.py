@@ -230,8 +230,8 @@ class Paule():
         order = np.argsort([len(c) for c in train_cps], kind="stable")            # sort_values(by="lens_input"), :1283, :1308
         train_cps, train_mels = [train_cps[i] for i in order], [train_mels[i] for i in order]
         lens = np.array([len(c) for c in train_cps])
-        if batch_size > planner.B:
-            raise ValueError(f"batch_size={batch_size} of continued learning exceeds the planner's batch {planner.B}")
+        if batch_size > getattr(planner, "train_capacity", planner.B):
+            raise ValueError(f"batch_size={batch_size} of continued learning exceeds the planner's rows ({planner.train_capacity})")
         if lens.max() > planner.T:
             raise ValueError(f"a training sample of {lens.max()} frames does not fit the planner built for {planner.T} frames")
 

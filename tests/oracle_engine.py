@@ -13,6 +13,7 @@ class OracleEngine:
         sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
         self.pred_sd, self.emb_sd = sd(pred_model), sd(embedder) if embedder is not None else None
         self.B, self.T, self.Tp = batch, n_frames, n_frames // 2
+        self.train_capacity = (batch + 15) // 16 * 16
         self.kw = dict(objective=objective, lr=lr, betas=betas, eps=eps, clamp=clamp, smiling=smiling)
         self.has_embedder = self.emb_sd is not None
         self.inv = op.inverse_model_from_state_dict(sd(inv_model)) if inv_model is not None else None

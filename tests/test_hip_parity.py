@@ -694,7 +694,7 @@ def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
     with pytest.raises(ValueError, match="without inv_model"):
         eng.inverse_forward(g["target_mel"])
     with pytest.raises(ValueError, match="does not fit an engine"):
-        eng.train_pred_step(np.zeros((int(g["B"]) + 1, int(g["T"]), 30), np.float32), np.zeros((int(g["B"]) + 1, int(g["T"]) // 2, 60), np.float32))
+        eng.train_pred_step(np.zeros((17, int(g["T"]), 30), np.float32), np.zeros((17, int(g["T"]) // 2, 60), np.float32))
     with pytest.raises(ValueError, match="n_frames"):
         eng._call(eng.lib.pl_train_pred_step, 1, 1, 1, 1, 0.001, 0.9, 0.999, 1e-8, None)   # n_frames = 1 (the non-NULL dummy pointers are never touched)
     eng.set_targets(g["target_mel"], g["target_semvec"])
@@ -753,3 +753,25 @@ def test_full_size_cfg3_bf16_against_oracle_rows(HipPlanner):
     np.testing.assert_allclose(loss[:, rows], lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
     d = np.abs(cp[rows] - _n(orc.get_cp()))
     assert d.mean() <= 0.05 * 0.01 * n and d.max() <= 0.01 * n, (d.mean(), d.max())
+
+
+def test_plan_resynth_like_the_reference_test_on_the_gpu(golden_inverse):
+    """The reference's own smoke test (tests/test_paule.py:65-70, same arguments) through the HIP planner: initialisation by
+    the inverse model, planning, a synthesised log step every iteration, continued learning after every outer iteration -- and
+    the result equals the same host code driving the CPU oracle."""
+    from test_host import _reference_smoke_model, _factory
+    small = synthetic.make_workload(2, 24, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                    emb=dict(num_lstm_layers=1, hidden_size=10))
+    outs = []
+    for factory, dev in ((None, "cuda"), (_factory, "cpu")):
+        model = _reference_smoke_model(small, golden_inverse, factory, torch.device(dev))
+        res = model.plan_resynth(target_acoustic=golden_inverse["mel"][0], objective='acoustic_semvec',
+                                 initialize_from='acoustic', n_outer=2, n_inner=2, n_batches=1, batch_size=2,
+                                 n_epochs=2, seed=11, verbose=False)
+        outs.append(res)
+    hip, orc = outs
+    np.testing.assert_allclose(hip.initial_cp, orc.initial_cp, atol=5e-5, rtol=0)
+    np.testing.assert_allclose(hip.planned_cp, orc.planned_cp, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(hip.planned_loss_steps, orc.planned_loss_steps, rtol=1e-4)
+    np.testing.assert_allclose(hip.pred_model_loss, orc.pred_model_loss, rtol=1e-4)
+    np.testing.assert_allclose(hip.pred_semvec, orc.pred_semvec, atol=1e-4, rtol=0)

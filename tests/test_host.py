@@ -107,6 +107,30 @@ def test_batched_targets_and_hooks(small):
     assert model.best_synthesis_acoustic.mel_loss < np.inf
 
 
+def _reference_smoke_model(small, golden_inverse, factory, device):
+    """Paule as tests/test_paule.py:21-24 builds it, with what the offline box lacks handed in: small random-init models
+    instead of the downloaded weights, a stub synthesiser + mel extractor instead of VocalTractLab + librosa."""
+    return pp.Paule(pred_model={k: v.clone() for k, v in small.pred_sd.items()}, embedder=small.emb_sd,
+                    inv_model=state_dict_from(golden_inverse, "inv"), planner_factory=factory, device=device,
+                    synthesizer=lambda cp: (np.zeros(100), 44100),
+                    mel_extractor=lambda sig, sr: np.full((20, 60), 0.3))
+
+
+def test_plan_resynth_like_the_reference_test(small, golden_inverse):
+    """tests/test_paule.py:65-70 with its own arguments (objective='acoustic_semvec', initialize_from='acoustic', n_outer=2,
+    n_inner=2, n_batches=1, batch_size=2, n_epochs=2; log_ii and continue_learning at their defaults 1 / True): inverse-model
+    initialisation, a log step with synthesis every iteration, continued learning after each outer iteration.  The reference
+    asserts nothing about the result; here its shape contract is."""
+    model = _reference_smoke_model(small, golden_inverse, _factory, torch.device("cpu"))
+    results = model.plan_resynth(target_acoustic=golden_inverse["mel"][0], objective='acoustic_semvec',
+                                 initialize_from='acoustic', n_outer=2, n_inner=2, n_batches=1, batch_size=2,
+                                 n_epochs=2, verbose=False)
+    assert results.planned_cp.shape == (40, 30) and results.initial_cp.shape == (40, 30)
+    assert len(results.planned_loss_steps) == 4 and len(results.prod_loss_steps) == 4      # log_ii = 1: every iteration
+    assert len(results.pred_model_loss) == 2 * 2                                           # n_outer x n_epochs
+    assert results.prod_mel.shape == (20, 60) and results.pred_semvec.shape == (300,)
+
+
 def test_create_epoch_batches():
     """Same-size batching (paule/paule.py:349-371): every sample exactly once, full batches hold one length, only the
     left-over batches mix lengths, at most one batch is smaller; plain mode wraps around (:373-381)."""
