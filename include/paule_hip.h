@@ -171,6 +171,15 @@ int pl_train_pred_step(pl_handle *h, int n_rows, int n_frames, const float *cp, 
                        float beta1, float beta2, float eps, float *loss_out);
 /* Fresh torch.optim.Adam state for the parameters (moments = 0, step count = 0). */
 int pl_reset_pred_optimizer(pl_handle *h);
+/* Adam state of that optimiser, for saving / restoring / carrying it from one handle to the next (the reference's
+ * pred_optimizer lives as long as the Paule instance, paule/paule.py:284-287; docs/examples/minimal_example.py:51 saves it):
+ * which = 1 exp_avg, 2 exp_avg_sq; layer >= 0: the four LSTM tensors of that layer, layer = -1: post_linear (w_ih = weight,
+ * b_ih = bias, the other two ignored).  float32 device pointers, torch layout.  The step count is torch's state["step"]. */
+int pl_get_pred_optimizer_state(pl_handle *h, int layer, int which, float *w_ih, float *w_hh, float *b_ih, float *b_hh);
+int pl_set_pred_optimizer_state(pl_handle *h, int layer, int which, const float *w_ih, const float *w_hh, const float *b_ih,
+                                const float *b_hh);
+int64_t pl_get_pred_optimizer_step(const pl_handle *h);
+int pl_set_pred_optimizer_step(pl_handle *h, int64_t step);
 /* Current parameters in torch layout (the layouts of pl_set_lstm_weights / pl_set_linear), float32 device pointers:
  * how the host's torch module is brought back in sync after continued learning. */
 int pl_get_lstm_weights(pl_handle *h, int model_id, int layer, float *w_ih, float *w_hh, float *b_ih, float *b_hh);

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
     "pl_set_inverse_conv", "pl_inverse_forward",
+    "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
     "pl_last_error", "pl_version",
 )
 
@@ -93,6 +94,11 @@ def load_library(path: str | None = None):
     lib.pl_get_linear.argtypes = [vp, C.c_int, fp, fp]
     lib.pl_set_inverse_conv.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp]
     lib.pl_inverse_forward.argtypes = [vp, fp, C.c_int, fp, C.c_int]
+    lib.pl_get_pred_optimizer_state.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
+    lib.pl_set_pred_optimizer_state.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
+    lib.pl_get_pred_optimizer_step.restype = C.c_int64
+    lib.pl_get_pred_optimizer_step.argtypes = [vp]
+    lib.pl_set_pred_optimizer_step.argtypes = [vp, C.c_int64]
     lib.pl_device_bytes.restype = C.c_int64
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double
@@ -100,7 +106,8 @@ def load_library(path: str | None = None):
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
                  "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
-                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward"):
+                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward",
+                 "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_set_pred_optimizer_step"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib

@@ -1030,6 +1030,52 @@ int pl_reset_pred_optimizer(pl_handle* h) {
     return zero(p.p_blin);
 }
 
+// Adam state of the predictive model's optimiser (torch.optim.Adam state_dict: step, exp_avg, exp_avg_sq per parameter), so
+// that the reference's `pred_optimizer` -- which lives as long as the Paule instance (paule/paule.py:284-287) and is saved /
+// restored by its users (docs/examples/minimal_example.py:51, continue_planning.py:27) -- can outlive a handle.
+// which: 1 exp_avg, 2 exp_avg_sq.  layer >= 0: the four LSTM tensors of that layer; layer = -1: post_linear (w_ih = weight,
+// b_ih = bias; w_hh, b_hh ignored).  float32 device pointers in torch layout.
+namespace {
+int pred_state_io(pl_handle* h, bool set, int layer, int which, float* w_ih, float* w_hh, float* b_ih, float* b_hh, const char* who) {
+    if (!h || !w_ih || !b_ih || (layer >= 0 && (!w_hh || !b_hh))) return fail(PL_ERR_INVALID, std::string(who) + ": NULL argument");
+    if (which != 1 && which != 2) return fail(PL_ERR_INVALID, std::string(who) + ": which has to be 1 (exp_avg) or 2 (exp_avg_sq)");
+    Model& p = h->pred;
+    if (layer < -1 || layer >= p.L) return fail(PL_ERR_INVALID, std::string(who) + ": layer out of range");
+    DeviceGuard guard(h->cfg.device);
+    int rc = ensure_train_state(h, p);
+    if (rc) return rc;
+    auto io = [&](ParamState& ps, float* ptr) {
+        double* d = which == 1 ? ps.m : ps.v;
+        if (set) launch_f32_to_f64(h->stream, ptr, d, (int64_t)ps.n);
+        else launch_f64_to_f32(h->stream, d, ptr, (int64_t)ps.n);
+    };
+    if (layer >= 0) {
+        LstmLayer& ly = p.layers[layer];
+        io(ly.p_wih, w_ih); io(ly.p_whh, w_hh); io(ly.p_bih, b_ih); io(ly.p_bhh, b_hh);
+    } else {
+        io(p.p_wlin, w_ih); io(p.p_blin, b_ih);
+    }
+    rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(h->stream));
+    return PL_OK;
+}
+}  // namespace
+
+int pl_get_pred_optimizer_state(pl_handle* h, int layer, int which, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
+    return pred_state_io(h, false, layer, which, w_ih, w_hh, b_ih, b_hh, "pl_get_pred_optimizer_state");
+}
+int pl_set_pred_optimizer_state(pl_handle* h, int layer, int which, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh) {
+    return pred_state_io(h, true, layer, which, const_cast<float*>(w_ih), const_cast<float*>(w_hh), const_cast<float*>(b_ih),
+                         const_cast<float*>(b_hh), "pl_set_pred_optimizer_state");
+}
+int64_t pl_get_pred_optimizer_step(const pl_handle* h) { return h ? (int64_t)h->pred.train_steps : -1; }
+int pl_set_pred_optimizer_step(pl_handle* h, int64_t step) {
+    if (!h || step < 0) return fail(PL_ERR_INVALID, "pl_set_pred_optimizer_step: bad argument");
+    h->pred.train_steps = (long long)step;
+    return PL_OK;
+}
+
 int pl_get_lstm_weights(pl_handle* h, int model_id, int layer, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
     if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: NULL argument");
     if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: bad model_id");

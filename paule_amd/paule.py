@@ -80,6 +80,28 @@ def _rmse_rows(a, b):
     return np.sqrt((d * d).mean(axis=1))
 
 
+class PlannerAdam:
+    """Stand-in for the reference's ``pred_optimizer = torch.optim.Adam(pred_model.parameters(), lr=0.001)`` (paule/paule.py:287):
+    the moments live in the planner's handle on the device; this object carries them between plans and offers the two things
+    the reference's users touch -- ``param_groups[0]['lr']`` (:473-474) and ``state_dict()`` / ``load_state_dict()``
+    (docs/examples/minimal_example.py:51)."""
+
+    def __init__(self, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)]
+        self._state = {}
+
+    def state_dict(self):
+        n = len(self._state)
+        return {"state": self._state, "param_groups": [dict(self.param_groups[0], params=list(range(n)))]}
+
+    def load_state_dict(self, state_dict):
+        self._state = dict(state_dict.get("state", {}))
+        groups = state_dict.get("param_groups") or [{}]
+        for k in ("lr", "betas", "eps"):
+            if k in groups[0]:
+                self.param_groups[0][k] = groups[0][k]
+
+
 class Paule():
     """State of the Predictive Articulatory speech synthesis Using Lexical Embeddings planner
     (paule/paule.py:92-318), restricted to what the planning path needs."""
@@ -130,7 +152,7 @@ class Paule():
         self.inv_model = inv_model
         self.cp_gen_model = cp_gen_model
         self.mel_gen_model = mel_gen_model
-        self.pred_optimizer = pred_optimizer
+        self.pred_optimizer = pred_optimizer if pred_optimizer is not None else PlannerAdam(lr=0.001)   # paule/paule.py:284-287
         self.inv_optimizer = inv_optimizer
         self.continue_data = continue_data
         self.continue_data_limit = 1000   # max amount of training data stored in the instance (paule/paule.py:277)
@@ -238,6 +260,8 @@ class Paule():
         def padded(seqs, max_len):                                               # add_and_pad: repeat the last frame
             return np.stack([np.concatenate((x, np.tile(x[-1:], (max_len - len(x), 1))), axis=0) for x in seqs])
 
+        grp = self.pred_optimizer.param_groups[0] if self.pred_optimizer is not None else {}
+        lr = grp.get("lr", lr)
         losses = []
         for _ in range(n_epochs):
             by_len = {int(l): np.where(lens == l)[0] for l in np.unique(lens)}    # :1313-1319 (rebuilt: shuffled in place)
@@ -248,7 +272,7 @@ class Paule():
                 mel_b = padded([train_mels[i] for i in j], max(len(train_mels[i]) for i in j))
                 if mel_b.shape[1] != cp_b.shape[1] // 2:
                     raise ValueError("a training batch's mel length has to be half its cp length (ForwardModel halves the sequence)")
-                step_losses.append(planner.train_pred_step(cp_b, mel_b, lr=lr))
+                step_losses.append(planner.train_pred_step(cp_b, mel_b, lr=lr, betas=grp.get("betas", (0.9, 0.999)), eps=grp.get("eps", 1e-8)))
             losses.append(float(np.mean([float(x) for x in step_losses])))
         if self.continue_data is not None:                                        # :1439-1443
             vec = None if target_semvec is None else np.asarray(target_semvec)
@@ -264,6 +288,13 @@ class Paule():
                 if len(data) > self.continue_data_limit:
                     data = [data[i] for i in random.sample(range(len(data)), k=self.continue_data_limit)]
             self.continue_data = data
+        if self.pred_optimizer is not None and hasattr(planner, "get_pred_optimizer_state"):
+            sd = planner.get_pred_optimizer_state(lr=lr, betas=grp.get("betas", (0.9, 0.999)), eps=grp.get("eps", 1e-8))
+            try:
+                self.pred_optimizer.load_state_dict(sd)
+            except (ValueError, KeyError):   # a torch optimizer over different parameters: keep ours alongside
+                self.pred_optimizer = PlannerAdam(lr=lr)
+                self.pred_optimizer.load_state_dict(sd)
         if self.pred_model is not None:      # the reference trains self.pred_model in place: keep module / state dict in sync
             sd = planner.get_weights("pred")
             ref = self.pred_model.state_dict() if hasattr(self.pred_model, "state_dict") else self.pred_model
@@ -435,6 +466,8 @@ class Paule():
                                             dtype=self.compute_dtype, lr=learning_rate_planning, smiling=self.smiling,
                                             device=self.device)
         self.planner = planner
+        if continue_learning and hasattr(planner, "set_pred_optimizer_state"):   # the optimiser outlives a plan (paule/paule.py:284-287)
+            planner.set_pred_optimizer_state(self.pred_optimizer.state_dict())
         planner.set_cp(initial_cp)
         planner.reset_optimizer()                       # a fresh Adam per call (paule/paule.py:797)
         cls_w = cls_b = None

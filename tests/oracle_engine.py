@@ -37,14 +37,29 @@ class OracleEngine:
 
     # continued learning (OracleTrainer keeps its own model + optimizer; the planner is rebuilt on the new weights)
     def train_pred_step(self, cp, mel_target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
-        if getattr(self, "trainer", None) is None:
-            self.trainer = op.OracleTrainer(op.forward_model_from_state_dict(self.pred_sd), lr=lr, betas=betas, eps=eps)
+        self._ensure_trainer(lr, betas, eps)
         for grp in self.trainer.optimizer.param_groups:
             grp["lr"] = lr
         loss = self.trainer.train_pred_step(np.asarray(cp), np.asarray(mel_target))
         self.pred_sd = self.trainer.state_dict()
         self._build()
         return loss
+
+    def _ensure_trainer(self, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        if getattr(self, "trainer", None) is None:
+            self.trainer = op.OracleTrainer(op.forward_model_from_state_dict(self.pred_sd), lr=lr, betas=betas, eps=eps)
+
+    def get_pred_optimizer_state(self, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        self._ensure_trainer(lr, betas, eps)
+        return self.trainer.optimizer.state_dict()
+
+    def set_pred_optimizer_state(self, state_dict):
+        self._ensure_trainer()
+        if state_dict.get("state"):
+            sd = self.trainer.optimizer.state_dict()
+            sd["state"] = {i: {k: torch.as_tensor(v).double() if k != "step" else torch.as_tensor(float(v)) for k, v in st.items()}
+                           for i, st in state_dict["state"].items()}
+            self.trainer.optimizer.load_state_dict(sd)
 
     def get_weights(self, model="pred"):
         return dict(self.pred_sd if model == "pred" else self.emb_sd)

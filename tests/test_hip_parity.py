@@ -775,3 +775,28 @@ def test_plan_resynth_like_the_reference_test_on_the_gpu(golden_inverse):
     np.testing.assert_allclose(hip.planned_loss_steps, orc.planned_loss_steps, rtol=1e-4)
     np.testing.assert_allclose(hip.pred_model_loss, orc.pred_model_loss, rtol=1e-4)
     np.testing.assert_allclose(hip.pred_semvec, orc.pred_semvec, atol=1e-4, rtol=0)
+
+
+def test_pred_optimizer_state_round_trip(HipPlanner, golden_train):
+    """pl_get / pl_set_pred_optimizer_state: two training steps, export of parameters + Adam state (torch.optim.Adam.state_dict()
+    layout), a NEW handle loaded with them, two more steps == four steps on one handle (the export is float32: 1e-6)."""
+    g = golden_train
+    sd = state_dict_from(g, "pred")
+    j = g["batch_2"]
+    a, _ = _train_engine(HipPlanner, g, "f32")
+    for _ in range(4):
+        a.train_pred_step(g["cps"][j], g["prod_mel"][j])
+    b, _ = _train_engine(HipPlanner, g, "f32")
+    for _ in range(2):
+        b.train_pred_step(g["cps"][j], g["prod_mel"][j])
+    state = b.get_pred_optimizer_state()
+    assert float(state["state"][0]["step"]) == 2 and len(state["state"]) == len(sd)
+    c = HipPlanner(b.get_weights("pred"), None, batch=int(g["N"]), n_frames=int(g["T"]), objective="acoustic")
+    c.set_pred_optimizer_state(state)
+    for _ in range(2):
+        c.train_pred_step(g["cps"][j], g["prod_mel"][j])
+    wa, wc = a.get_weights("pred"), c.get_weights("pred")
+    for name in wa:
+        np.testing.assert_allclose(_n(wc[name]), _n(wa[name]), atol=1e-6, rtol=0, err_msg=name)
+    c.set_pred_optimizer_state({"state": {}})
+    assert c.get_pred_optimizer_state()["state"] == {}

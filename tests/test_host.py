@@ -191,6 +191,27 @@ def test_initialize_from_acoustic_on_the_planner(small, golden_inverse):
     np.testing.assert_allclose(res.initial_cp[:, 6:], golden_inverse["cp_clipped"][:2], atol=1e-12)
 
 
+def test_pred_optimizer_outlives_a_plan(small):
+    """The reference's pred_optimizer belongs to the Paule instance (paule/paule.py:284-287): its Adam state carries over from
+    one plan_resynth call to the next, `param_groups[0]['lr']` follows learning_rate_learning (:473-474), and state_dict() is
+    what docs/examples/minimal_example.py:51 saves."""
+    model = pp.Paule(pred_model={k: v.clone() for k, v in small.pred_sd.items()}, embedder=small.emb_sd, planner_factory=_factory,
+                     device=torch.device("cpu"), synthesizer=lambda cp: (np.zeros(100), 44100),
+                     mel_extractor=lambda sig, sr: np.full((12, 60), 0.25))
+    kw = dict(target_acoustic=small.target_mel.numpy(), initial_cp=small.cp0.numpy(), initialize_from=None, objective="acoustic",
+              n_outer=1, n_inner=2, log_ii=2, continue_learning=True, n_batches=1, batch_size=2, n_epochs=3, verbose=False)
+    assert model.pred_optimizer.state_dict()["state"] == {}
+    model.plan_resynth(learning_rate_learning=0.002, **kw)
+    sd = model.pred_optimizer.state_dict()
+    assert model.pred_optimizer.param_groups[0]["lr"] == 0.002
+    assert float(sd["state"][0]["step"]) == 3 and set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+    assert len(sd["state"]) == len(small.pred_sd)
+    model.plan_resynth(learning_rate_learning=0.002, **kw)
+    assert float(model.pred_optimizer.state_dict()["state"][0]["step"]) == 6     # continued, not restarted
+    import pickle
+    pickle.loads(pickle.dumps(model.pred_optimizer.state_dict()))
+
+
 def test_continue_learning_with_stored_training_data(small):
     """add_training_data_pred=True (paule/paule.py:1250-1287): half of every training batch comes from continue_data, whose
     samples may be shorter than the plan (padded to the batch's longest sample by repeating the last frame); the produced
