@@ -135,7 +135,28 @@ class Paule():
                     return None
                 raise FileNotFoundError(f"{what}: pretrained weights are not bundled (looked for {path}); pass {what}= (a module or "
                                         "state dict) or point PAULE_PRETRAINED_DIR at the reference's pretrained_models directory")
-            return torch.load(path, map_location="cpu", weights_only=True)
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+            # the reference keeps torch modules (its users call paule_model.pred_model.state_dict(), docs/examples/minimal_example.py:50)
+            from . import models as _m
+            n_layers = len([k for k in sd if k.startswith("lstm.weight_hh_l")])
+            if n_layers == 0:
+                return sd                                                           # the speech classifier: a plain state dict
+            hidden = int(sd["lstm.weight_hh_l0"].shape[1])
+            if what == "pred_model":
+                mod = _m.ForwardModel(input_size=int(sd["lstm.weight_ih_l0"].shape[1]), output_size=int(sd["post_linear.weight"].shape[0]),
+                                      hidden_size=hidden, num_lstm_layers=n_layers)
+            elif what == "embedder":
+                mod = _m.EmbeddingModel(input_size=int(sd["lstm.weight_ih_l0"].shape[1]), output_size=int(sd["linear_mapping.weight"].shape[0]),
+                                        hidden_size=hidden, num_lstm_layers=n_layers)
+            else:
+                mod = _m.InverseModelMelTimeSmoothResidual(
+                    input_size=int(sd["lstm.weight_ih_l0"].shape[1]) // 3, output_size=int(sd["post_linear.weight"].shape[0]),
+                    hidden_size=hidden, num_lstm_layers=n_layers,
+                    mel_smooth_layers=len({k.split(".")[1] for k in sd if k.startswith("MelBlocks.")}),
+                    resid_blocks=len({k.split(".")[1] for k in sd if k.startswith("ResidualConvBlocks.")}))
+            mod = mod.double()            # the reference's models are float64 (paule/paule.py:124, :146, :167)
+            mod.load_state_dict(sd)
+            return mod
 
         if use_speech_classifier and speech_classifier is None:
             speech_classifier = pretrained("speech_classifier/linear_model_rec_as_nonspeech.pt", "speech_classifier")

@@ -253,7 +253,8 @@ def test_default_models_from_pretrained_dir(small, golden_inverse, tmp_path, mon
         (tmp_path / rel).parent.mkdir(parents=True, exist_ok=True)
         torch.save({k: v.clone() for k, v in sd.items()}, tmp_path / rel)
     model = pp.Paule(planner_factory=_factory, device=torch.device("cpu"))
-    assert set(model.pred_model) == set(small.pred_sd) and set(model.inv_model) == set(files[list(files)[2]])
+    assert isinstance(model.pred_model, torch.nn.Module) and set(model.pred_model.state_dict()) == set(small.pred_sd)
+    assert set(model.inv_model.state_dict()) == set(files[list(files)[2]]) and set(model.embedder.state_dict()) == set(small.emb_sd)
     res = model.plan_resynth(target_acoustic=golden_inverse["mel"][:1], initialize_from="acoustic", objective="acoustic", n_outer=1,
                              n_inner=2, log_ii=2, continue_learning=False, verbose=False)
     np.testing.assert_allclose(res.initial_cp, golden_inverse["cp_clipped"][0], atol=1e-12)
