@@ -173,3 +173,27 @@ def test_inverse_model_vs_reference_fixture(golden_inverse):
     np.testing.assert_allclose(y.numpy(), g["cp_raw"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(y.clamp(-1, 1).numpy(), g["cp_clipped"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(y13.numpy(), g["cp_raw_13"], rtol=0, atol=1e-12)
+
+
+def test_torch_and_manual_oracles_agree_on_random_shapes():
+    """The two independent restatements -- torch autograd (oracle/planner.py) and numpy with explicit BPTT (oracle/manual.py:
+    the arithmetic the kernels implement) -- against each other on shapes no fixture holds (property test, hypothesis):
+    batch 1..4, T 14..31 (odd lengths drop the last frame), 1..3 layers, hidden 3..17, every objective, smiling on / off."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(B=st.integers(1, 4), T=st.integers(14, 31), Lp=st.integers(1, 3), Hp=st.integers(3, 17), Le=st.integers(1, 2),
+           He=st.integers(3, 13), objective=st.sampled_from(["acoustic", "acoustic_semvec", "semvec"]), smiling=st.booleans())
+    def check(B, T, Lp, Hp, Le, He, objective, smiling):
+        wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=Lp, hidden_size=Hp), emb=dict(num_lstm_layers=Le, hidden_size=He))
+        P = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                             objective=objective, smiling=smiling)
+        M = om.ManualPlanner(wl.pred_sd, wl.emb_sd, objective=objective, smiling=smiling)
+        for pl in (P, M):
+            pl.set_targets(wl.target_mel.numpy(), wl.target_semvec.numpy())
+            pl.set_cp(wl.cp0.numpy())
+        lp, lm = P.step(3), M.step(3)
+        _close(np.asarray(lm), lp.numpy() if hasattr(lp, "numpy") else np.asarray(lp), tol=1e-9)
+        _close(np.asarray(M.get_cp()), P.get_cp().numpy(), tol=1e-9)
+
+    check()
