@@ -800,3 +800,32 @@ def test_pred_optimizer_state_round_trip(HipPlanner, golden_train):
         np.testing.assert_allclose(_n(wc[name]), _n(wa[name]), atol=1e-6, rtol=0, err_msg=name)
     c.set_pred_optimizer_state({"state": {}})
     assert c.get_pred_optimizer_state()["state"] == {}
+
+
+def test_random_shapes_f32_vs_oracle(HipPlanner):
+    """Property test (hypothesis, derandomised): batch, length, layer counts, hidden sizes (padded to 32 inside the library), objective
+    and projection flags drawn at random -- the f32 HIP path against the float64 oracle at the f32 bar, 3 iterations each."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+    @given(B=st.integers(1, 40), T=st.integers(14, 70), Lp=st.integers(1, 3), Hp=st.sampled_from([5, 24, 33, 64, 100]),
+           Le=st.integers(1, 2), He=st.sampled_from([7, 32, 48]), objective=st.sampled_from(["acoustic", "acoustic_semvec", "semvec"]),
+           smiling=st.booleans(), with_past=st.booleans())
+    def check(B, T, Lp, Hp, Le, He, objective, smiling, with_past):
+        wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=Lp, hidden_size=Hp), emb=dict(num_lstm_layers=Le, hidden_size=He))
+        orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                               objective=objective, smiling=smiling)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective=objective, smiling=smiling)
+        past = (wl.cp0[0, :4] * 0.5).numpy() if with_past else None
+        for pl in (orc, eng):
+            pl.set_targets(wl.target_mel, wl.target_semvec)
+            pl.set_cp(wl.cp0)
+            if past is not None:
+                pl.set_past_cp(past)
+        lo, lh = _n(orc.step(3)), _n(eng.step(3))
+        eng.synchronize()
+        np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
+        np.testing.assert_allclose(_n(eng.get_cp()), _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+        eng.close()
+
+    check()
