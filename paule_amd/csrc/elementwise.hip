@@ -193,58 +193,67 @@ __device__ __forceinline__ double corr_sumsq(const double* __restrict__ x, int T
     return s;
 }
 
-__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
-    __shared__ double sh[256];
+// six sums at once (fixed order: deterministic): wave-level shuffle tree, then the four waves' partials through LDS
+__device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh)[6]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sh[wave][k] = v[k];
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += sh[w][k];
+        v[k] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a) {
+    __shared__ double sh[16][6];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     double* sc = a.scal + (size_t)b * 8;
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // mel SSE, semvec SSE, vel, jerk, ll, classifier logit sum
 
-    // RMSE over the utterance's T' x M mel frames (RMSELoss eps = 0, paule/util.py:570-572)
-    double s = 0.0;
+    // RMSE over the utterance's T' x M mel frames (RMSELoss eps = 0, paule/util.py:570-572) and, in the same pass, the speech
+    // classifier's logit: mean over time of Linear(60 -> 1) (paule/models.py:899-908)
     const int nm = a.Tp * a.M;
     const float* mel = a.mel + (size_t)b * nm;
     const float* tgt = a.target_mel + (size_t)b * nm;
     for (int e = tid; e < nm; e += nt) {
-        const double d = (double)mel[e] - (double)tgt[e];
-        s += d * d;
+        const double m = (double)mel[e], d = m - (double)tgt[e];
+        s[0] += d * d;
+        if (a.cls_wb) s[5] += (double)a.cls_wb[e % a.M] * m;
     }
-    s = block_sum(s, sh);
-    if (tid == 0) sc[0] = sqrt(s / nm);
-
-    // speech classifier logit: mean over time of Linear(60 -> 1) (paule/models.py:899-908)
-    if (a.cls_wb) {
-        s = 0.0;
-        for (int e = tid; e < nm; e += nt) s += (double)a.cls_wb[e % a.M] * (double)mel[e];
-        s = block_sum(s, sh);
-        if (tid == 0) sc[5] = s / a.Tp + (double)a.cls_wb[a.M];
-    } else if (tid == 0) {
-        sc[5] = 0.0;
-    }
-
-    if (a.sem) {
-        s = 0.0;
+    if (a.sem)
         for (int e = tid; e < a.S; e += nt) {
             const double d = (double)a.sem[(size_t)b * a.Sp + e] - (double)a.target_sem[(size_t)b * a.S + e];
-            s += d * d;
+            s[1] += d * d;
         }
-        s = block_sum(s, sh);
-        if (tid == 0) sc[1] = sqrt(s / a.S);
-    } else if (tid == 0) {
-        sc[1] = 0.0;
-    }
-
     const double* x = a.x + (size_t)b * a.T * a.C;
     const size_t per = (size_t)a.T * a.C;
     double* dws = a.dwork + (size_t)b * 3 * per;     // [vel | jerk | ll] correlations of this utterance
-    s = block_sum(corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws), sh);
-    if (tid == 0) sc[2] = s / ((double)(a.T - 4) * a.C);
-    s = block_sum(corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per), sh);
-    if (tid == 0) sc[3] = s / ((double)(a.T - 12) * a.C);
-    s = block_sum(corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per), sh);
-    if (tid == 0) sc[4] = s / ((double)(a.T - 2) * a.C);
+    s[2] = corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws);
+    s[3] = corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per);
+    s[4] = corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per);
+    block_sum6(s, sh);
+    if (tid == 0) {
+        sc[0] = sqrt(s[0] / nm);
+        sc[1] = a.sem ? sqrt(s[1] / a.S) : 0.0;
+        sc[2] = s[2] / ((double)(a.T - 4) * a.C);
+        sc[3] = s[3] / ((double)(a.T - 12) * a.C);
+        sc[4] = s[4] / ((double)(a.T - 2) * a.C);
+        sc[5] = a.cls_wb ? s[5] / a.Tp + (double)a.cls_wb[a.M] : 0.0;
+    }
 }
 
 void launch_loss_reduce(hipStream_t stream, const LossArgs& a) {
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(a.B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(a.B), dim3(1024), 0, stream, a);   // one workgroup per utterance, 16 waves
 }
 
 // weighted sub-losses, as the reference logs them (paule/paule.py:654-662, :942-945)
