@@ -386,20 +386,25 @@ void launch_total_grad(hipStream_t stream, const AdamArgs& a) {
 
 // torch.optim.Adam (no amsgrad / weight decay) on the CP tensor, then paule/paule.py:1201-1211.
 __global__ void adam_update_kernel(AdamArgs a) {
+    __shared__ double bias_corr[2];   // 1 - beta^k: two f64 pow() per workgroup instead of per element
+    if (threadIdx.x == 0) {
+        const int k = *a.step_count + 1;
+        bias_corr[0] = 1.0 - pow(a.beta1, (double)k);
+        bias_corr[1] = 1.0 - pow(a.beta2, (double)k);
+    }
+    __syncthreads();
     const int64_t n = (int64_t)a.B * a.T * a.C;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int c = (int)(idx % a.C);
     const int t = (int)((idx / a.C) % a.T);
     const int b = (int)(idx / ((int64_t)a.C * a.T));
-    const int k = *a.step_count + 1;
     const double g = a.grad[idx];
     const double m = a.beta1 * a.m[idx] + (1.0 - a.beta1) * g;
     const double v = a.beta2 * a.v[idx] + (1.0 - a.beta2) * g * g;
     a.m[idx] = m;
     a.v[idx] = v;
-    const double bc1 = 1.0 - pow(a.beta1, (double)k);
-    const double bc2 = 1.0 - pow(a.beta2, (double)k);
+    const double bc1 = bias_corr[0], bc2 = bias_corr[1];
     const double denom = sqrt(v) / sqrt(bc2) + a.eps;
     double x = a.x[idx] - (a.lr / bc1) * (m / denom);
     x = fmin(fmax(x, a.clamp_lo), a.clamp_hi);
