@@ -363,24 +363,58 @@ __device__ __forceinline__ double corr_grad(const double* __restrict__ dc, int T
     return g * (w * 2.0 / ((double)n * C));
 }
 
+// the same for TG consecutive frames t0 .. t0 + TG - 1 of one channel: the K + TG - 1 correlations are loaded once
+template <int K, int TG>
+__device__ __forceinline__ void corr_grad_run(const double* __restrict__ dc, int T, int C, const double* taps, int t0, double w,
+                                              double (&g)[TG]) {
+    const int n = T - K + 1;
+    double d[K + TG - 1];                       // d[i] = correlation at u = t0 - (K - 1) + i, zero outside [0, n)
+#pragma unroll
+    for (int i = 0; i < K + TG - 1; ++i) {
+        const int u = t0 - (K - 1) + i;
+        d[i] = (u >= 0 && u < n) ? dc[(size_t)u * C] : 0.0;
+    }
+    const double scale = w * 2.0 / ((double)n * C);
+#pragma unroll
+    for (int j = 0; j < TG; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += taps[k] * d[(K - 1) + j - k];   // u = t0 + j - k, same order of terms as corr_grad
+        g[j] += acc * scale;
+    }
+}
+
+constexpr int kGradRun = 4;   // frames per thread
+
 __global__ void total_grad_kernel(AdamArgs a) {
-    const int64_t n = (int64_t)a.B * a.T * a.C;
+    const int nrun = (a.T + kGradRun - 1) / kGradRun;
+    const int64_t n = (int64_t)a.B * nrun * a.C;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int c = (int)(idx % a.C);
-    const int t = (int)((idx / a.C) % a.T);
-    const int b = (int)(idx / ((int64_t)a.C * a.T));
+    const int t0 = (int)((idx / a.C) % nrun) * kGradRun;
+    const int b = (int)(idx / ((int64_t)a.C * nrun));
     const size_t per = (size_t)a.T * a.C;
     const double* dws = a.dwork + (size_t)b * 3 * per + c;   // channel c of utterance b, stride C over time
-    double g = (double)a.dX[((size_t)t * a.Bp + b) * a.Cp + c];
-    g += corr_grad<5>(dws, a.T, a.C, kVelTaps, t, (double)a.w_vel);
-    g += corr_grad<13>(dws + per, a.T, a.C, kJerkTaps, t, (double)a.w_jerk);
-    g += corr_grad<3>(dws + 2 * per, a.T, a.C, kLlTaps, t, (double)a.w_ll);
-    a.grad[idx] = g;
+    double gv[kGradRun] = {}, gj[kGradRun] = {}, gl[kGradRun] = {};
+    corr_grad_run<5, kGradRun>(dws, a.T, a.C, kVelTaps, t0, (double)a.w_vel, gv);
+    corr_grad_run<13, kGradRun>(dws + per, a.T, a.C, kJerkTaps, t0, (double)a.w_jerk, gj);
+    corr_grad_run<3, kGradRun>(dws + 2 * per, a.T, a.C, kLlTaps, t0, (double)a.w_ll, gl);
+#pragma unroll
+    for (int j = 0; j < kGradRun; ++j) {
+        const int t = t0 + j;
+        if (t < a.T) {
+            double g = (double)a.dX[((size_t)t * a.Bp + b) * a.Cp + c];
+            g += gv[j];
+            g += gj[j];
+            g += gl[j];
+            a.grad[((size_t)b * a.T + t) * a.C + c] = g;
+        }
+    }
 }
 
 void launch_total_grad(hipStream_t stream, const AdamArgs& a) {
-    const int64_t n = (int64_t)a.B * a.T * a.C;
+    const int64_t n = (int64_t)a.B * ((a.T + kGradRun - 1) / kGradRun) * a.C;
     hipLaunchKernelGGL(total_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a);
 }
 
