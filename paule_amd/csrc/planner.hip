@@ -148,8 +148,10 @@ struct pl_handle {
     float* loss_rows = nullptr;
     int loss_cap = 0;
     int* counters = nullptr;    // [0] Adam step count, [1] loss row of the running iteration
-    int* sweep_cnt = nullptr;   // arrival counters of the persistent LSTM sweeps [groups][T] (own allocation: memset target)
-    size_t sweep_cnt_bytes = 0;
+    int* sweep_cnt = nullptr;   // arrival flags of the persistent LSTM sweeps: n_sweep_slots slices of [groups][T][flag_stride] + XCD table
+    size_t sweep_cnt_bytes = 0; // bytes of ONE slice
+    int n_sweep_slots = 1;      // one slice per sweep of an iteration, so that ONE launch zeroes them all
+    int sweep_slot = -1;        // >= 0 while an iteration is being enqueued: next slice to use (already zeroed)
     int* sweep_status = nullptr;
     int n_cu = 0;
     int flag_stride = 16;
@@ -253,11 +255,24 @@ int alloc_model(pl_handle* h, Model& md, int L, int H, int in, int out, int Tl) 
 
 inline char* off(void* p, size_t elems, size_t esz) { return static_cast<char*>(p) + elems * esz; }
 
-void zero_sweep_counters(pl_handle* h, hipStream_t st) {
+// flags of the next sweep: inside an iteration the slices were zeroed together up front (zero_all_sweep_slots) and are handed
+// out in turn; elsewhere (forward-only calls, training, timing) slice 0 is zeroed right before the sweep
+int* take_sweep_slice(pl_handle* h, hipStream_t st) {
+    const size_t ints = h->sweep_cnt_bytes / sizeof(int);
+    if (h->sweep_slot >= 0 && h->sweep_slot < h->n_sweep_slots) return h->sweep_cnt + (size_t)(h->sweep_slot++) * ints;
     if (h->zero_mode == 1)
         (void)hipMemsetAsync(h->sweep_cnt, 0, h->sweep_cnt_bytes, st);
     else
-        launch_zero_counters(st, h->sweep_cnt, (int)(h->sweep_cnt_bytes / sizeof(int)));
+        launch_zero_counters(st, h->sweep_cnt, (int)ints);
+    return h->sweep_cnt;
+}
+void zero_all_sweep_slots(pl_handle* h, hipStream_t st) {
+    const size_t ints = h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots;
+    if (h->zero_mode == 1)
+        (void)hipMemsetAsync(h->sweep_cnt, 0, ints * sizeof(int), st);
+    else
+        launch_zero_counters(st, h->sweep_cnt, (int)ints);
+    h->sweep_slot = 0;
 }
 
 // persistent-sweep dispatch by arithmetic type: grid 0 = launch-per-step kernels
@@ -311,15 +326,14 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, 
             s.c = ly.c;
             if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
             s.stash_via_lds = h->stash_lds ? 1 : 0;
-            s.counters = h->sweep_cnt;
+            s.counters = take_sweep_slice(h, st);
             s.flag_stride = h->flag_stride;
-            s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
+            s.xcc_tab = s.counters + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
             // the forward same-XCD hand-off pays for the 16-row kernels (B = 8: 4.14 -> 4.02 ms, equal at B = 64), not for the 32-row ones
             s.xcd_fast = (h->xcd_fast & 1) | ((h->xcd_fast16 && (h->xcd_fast & 2) && use_sweep16(h, Hp, false)) ? 1 : 0);
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps;
-            zero_sweep_counters(h, st);
             launch_sweep(h, st, false, Hp, sweep_grid, s);
             cur_in = ly.h;
             continue;
@@ -365,15 +379,14 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.c = ly.c;
             s.dh_ext = sparse_top ? nullptr : md.dh_ext;
             s.dh_last = sparse_top ? dh_last : nullptr;
-            s.counters = h->sweep_cnt;
+            s.counters = take_sweep_slice(h, st);
             s.flag_stride = h->flag_stride;
-            s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
+            s.xcc_tab = s.counters + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
             s.xcd_fast = (h->xcd_fast >> 1) & 1;
             s.status = h->sweep_status;
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
             s.xchg = h->sweep_xchg;
-            zero_sweep_counters(h, st);
             launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
@@ -457,6 +470,7 @@ AdamArgs adam_args(pl_handle* h) {
 // one inner iteration: forward, criterion, backward-data, Adam + projection
 void enqueue_iteration(pl_handle* h, hipStream_t st) {
     const bool with_sem = h->need_emb_in_step();
+    zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
     pred_forward(h, st);
     if (with_sem) emb_forward(h, st, nullptr);
     LossArgs la = loss_args(h, with_sem);
@@ -479,6 +493,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     AdamArgs aa = adam_args(h);
     launch_total_grad(st, aa);
     launch_adam_update(st, aa);
+    h->sweep_slot = -1;
 }
 
 int check_launch() {
@@ -690,7 +705,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->flag_stride = (pmax + 15) / 16 * 16;
         const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
-        if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int)))) return bail(rc);
+        h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers);   // forward + backward sweep of every layer of an iteration
+        if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
 #ifdef PL_STAMPS
         if ((rc = dev_alloc(h, &h->sweep_stamps, 2 * 256 * 8))) return bail(rc);
@@ -1215,7 +1231,8 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         s.xchg = h->sweep_xchg;
         s.stash_via_lds = h->stash_lds ? 1 : 0;
         for (int i = 0; i < reps; ++i) {
-            zero_sweep_counters(h, h->stream);
+            s.counters = take_sweep_slice(h, h->stream);
+            s.xcc_tab = s.counters + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
             launch_sweep(h, h->stream, bwd, Hp, grid, s);
         }
         PL_HIP(hipEventRecord(e1, h->stream));
