@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
             // leave as ONE instruction's contiguous piece (4 lanes x 16 B): whole sectors, which the consumers' reads
             // of the shared L2 need (16-byte pieces from four different waves read back at half the rate)
             *reinterpret_cast<uint2*>(hst + bl * HRS + (8 * wave + 4 * hh) * 2) = pack_bf16x4(vh[0], vh[1], vh[2], vh[3]);
-            const bool stash_lds = a.stash_via_lds != 0;
+            const bool stash_lds = (a.stash_via_lds & 1) != 0;
             if (stash_lds) {   // the five stash arrays leave through LDS too: whole 64-byte row pieces instead of 8-byte scatters
                 unsigned char* o = hst + 32 * HRS + bl * HRS + (8 * wave + 4 * hh) * 2;
                 *reinterpret_cast<uint2*>(o) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);

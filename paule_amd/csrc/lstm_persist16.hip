@@ -355,6 +355,9 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
             uint4 bfr[4];
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) bfr[kc] = *reinterpret_cast<const uint4*>(da_img + lr * DRS + kc * 64 + kq * 16);
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            const bool own_store = (a.stash_via_lds & 2) != 0;   // every wave hands its own tiles over right behind their MFMAs
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
@@ -365,12 +368,21 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[i][kc]), __builtin_bit_cast(bf16x8, bfr[kc]), acc, 0, 0, 0);
                 // acc[r] = partial[n = 16 nt + 4 kq + r][batch lr] -> bf16 image [batch][n]
                 *reinterpret_cast<uint2*>(out_img + lr * ORS + (16 * nt + 4 * kq) * 2) = pack_bf16x4(acc[0], acc[1], acc[2], acc[3]);
+                if (own_store && lane < 32) {
+                    // the 16 x 16 tile is this wave's alone: read it back by rows (a wave's LDS operations are ordered) and store the
+                    // 32 16-byte chunks now; it is the (nt & 1) half of destination nt >> 1's [16 rows][32 columns] exchange tile
+                    const int r = lane >> 1, hc = lane & 1;
+                    const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (16 * nt + 8 * hc) * 2);
+                    u32x4 d;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + r * 32 + (nt & 1) * 16 + hc * 8) * 2);
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                }
             }
-            __syncthreads();
             PL_ST(4);
-            {   // hand-off: P tiles of [16 rows][32 columns], whole 16-byte chunks
-                bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
-                const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            if (!own_store) {   // hand-off after a barrier: P tiles of [16 rows][32 columns], whole 16-byte chunks
+                __syncthreads();
 #pragma unroll
                 for (int i = 0; i < NST; ++i) {
                     const int e = tid + 256 * i;      // chunk: destination e / 64, row (e % 64) / 4, quarter e % 4

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
                 bfr[ks] = *reinterpret_cast<const uint4*>(da_img + (lane & 31) * DRS + ks * 32 + (lane >> 5) * 16);
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            const bool own_store = (a.stash_via_lds & 2) != 0;   // A/B: every wave hands its own tiles over right behind their MFMAs
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
@@ -173,12 +176,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
                     *reinterpret_cast<uint2*>(orow + rg * 16) = pack_bf16x4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+                if (own_store) {
+                    // tile nt is this wave's alone: read it back by rows (LDS operations of a wave are ordered) and hand it over now,
+                    // under the MFMAs of the wave's next tile; 128 16-byte chunks = 2 per lane, the tile is 2 KB contiguous
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int cidx = lane + 64 * q, r = cidx >> 2, c4 = cidx & 3;
+                        const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (32 * nt + 8 * c4) * 2);
+                        u32x4 d;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        const unsigned off = (unsigned)(((size_t)nt * P * TILE + cidx * 8) * 2);
+                        if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                    }
+                }
             }
-            __syncthreads();
             PL_ST(4);   // MFMA + partial image
-            {   // hand-off: this workgroup's partial tile rows, whole 16-byte chunks, write-through
-                bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
-                const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            if (!own_store) {   // hand-off after a barrier: this workgroup's partial tile rows, whole 16-byte chunks, write-through
+                __syncthreads();
 #pragma unroll
                 for (int i = 0; i < NST; ++i) {
                     const int e = tid + 256 * i;      // 16-byte chunk: destination e / 128, row (e % 128) / 4, quarter e % 4
