@@ -14,9 +14,10 @@ from paule_amd import synthetic  # noqa: E402
 from paule_amd.engine import HipPlanner  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+DTYPE = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 OBJ = sys.argv[2] if len(sys.argv) > 2 else "acoustic_semvec"   # "acoustic": the last forward sweep is the predictive model's (fused input)
 wl = synthetic.make_workload(B, 300, "A")
-eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=300, objective=OBJ, dtype="bf16")
+eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=300, objective=OBJ, dtype=DTYPE)
 eng.set_targets(wl.target_mel, wl.target_semvec)
 eng.set_cp(wl.cp0)
 eng.step(3)
