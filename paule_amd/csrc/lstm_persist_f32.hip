@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
     constexpr int NT = (P + 3) / 4;              // N tiles per wave (wave w: tiles w, w + 4, ...)
     constexpr int DRS = 64 * 4 + 16;             // dA^T image [16 batch rows][64 local gate rows] f32
     __shared__ __attribute__((aligned(16))) unsigned char da_img[16 * DRS];
+    __shared__ __attribute__((aligned(16))) float red[4][16][16];   // per-wave sums of the partial tiles (wide ingest)
     __shared__ int lds_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,6 +272,30 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
                 PL_ST(1);
                 const float* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
                 const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 4));
+                if (a.stash_via_lds & 2) {
+                    // wide ingest: wave w sums the tiles of sources w * TPG .. with 16-byte loads (a wave instruction = one whole 1-KB
+                    // tile instead of a quarter of it: 46 instead of 184 load instructions per workgroup and step), the four waves'
+                    // sums meet in LDS.  Fixed order: deterministic.
+                    constexpr int TPG = (P + 3) / 4;
+                    const int r16 = lane >> 2, quad = lane & 3;
+                    uint4 pw[TPG];
+#pragma unroll
+                    for (int i = 0; i < TPG; ++i) {
+                        const int src = wave * TPG + i;
+                        pw[i] = src < P ? ld16_ho(rx, (unsigned)(src * TILE * 4 + (r16 * 16 + quad * 4) * 4), plain_handoff) : make_uint4(0, 0, 0, 0);
+                    }
+                    float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < TPG; ++i) {
+                        part.x += __builtin_bit_cast(float, pw[i].x);
+                        part.y += __builtin_bit_cast(float, pw[i].y);
+                        part.z += __builtin_bit_cast(float, pw[i].z);
+                        part.w += __builtin_bit_cast(float, pw[i].w);
+                    }
+                    *reinterpret_cast<float4*>(&red[wave][r16][quad * 4]) = part;
+                    __syncthreads();
+                    dh += (red[0][erow][eu] + red[1][erow][eu]) + (red[2][erow][eu] + red[3][erow][eu]);
+                } else {
                 const unsigned o0 = (unsigned)((erow * 16 + eu) * 4);
                 unsigned pv[P];
 #pragma unroll
@@ -279,6 +304,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
                                           : __builtin_amdgcn_raw_buffer_load_b32(rx, o0 + (unsigned)(s * TILE * 4), 0, kAuxSc1);
 #pragma unroll
                 for (int s = 0; s < P; ++s) dh += __builtin_bit_cast(float, pv[s]);
+                }
             }
             PL_ST(2);
 
