@@ -309,6 +309,39 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
                 PL_ST(1);
                 const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
                 const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+                if (a.stash_via_lds & 4) {
+                    // wide ingest: wave w sums the tiles of sources w * TPG .. with 16-byte loads (one wave instruction = one whole
+                    // 1-KB tile: 23 instead of 92 load instructions per workgroup and step), the four waves' f32 sums meet in LDS
+                    // (the partial image of the previous step is free by now).  Fixed order: deterministic.
+                    constexpr int TPG = (P + 3) / 4;
+                    uint4 pw[TPG];
+#pragma unroll
+                    for (int i = 0; i < TPG; ++i) {
+                        const int src = wave * TPG + i;
+                        pw[i] = src < P ? ld16_handoff(rx, (unsigned)(src * TILE * 2 + lane * 16), plain_handoff) : make_uint4(0, 0, 0, 0);
+                    }
+                    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < TPG; ++i) {
+                        float f[4];
+                        unpack_bf16x4(make_uint2(pw[i].x, pw[i].y), f);
+                        acc8[0] += f[0]; acc8[1] += f[1]; acc8[2] += f[2]; acc8[3] += f[3];
+                        unpack_bf16x4(make_uint2(pw[i].z, pw[i].w), f);
+                        acc8[4] += f[0]; acc8[5] += f[1]; acc8[6] += f[2]; acc8[7] += f[3];
+                    }
+                    float* redw = reinterpret_cast<float*>(out_img) + wave * (16 * 36);   // [wave][16 rows][32 + 4 pad] f32
+                    const int row = lane >> 2, c8 = lane & 3;
+                    *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8) = make_float4(acc8[0], acc8[1], acc8[2], acc8[3]);
+                    *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8 + 4) = make_float4(acc8[4], acc8[5], acc8[6], acc8[7]);
+                    __syncthreads();
+                    const float* rd = reinterpret_cast<const float*>(out_img) + erow * 36 + 2 * jq;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        dh[0] += rd[w * (16 * 36)];
+                        dh[1] += rd[w * (16 * 36) + 1];
+                    }
+                    __syncthreads();   // the image is written again by this step's epilogues
+                } else {
                 const unsigned o0 = (unsigned)((erow * 32 + 2 * jq) * 2);
                 unsigned pv[P];
 #pragma unroll
@@ -319,6 +352,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
                 for (int s = 0; s < P; ++s) {
                     dh[0] += bf16_to_f32((unsigned short)(pv[s] & 0xffffu));
                     dh[1] += bf16_to_f32((unsigned short)(pv[s] >> 16));
+                }
                 }
             }
             PL_ST(2);

@@ -169,6 +169,7 @@ struct pl_handle {
     bool xcd_fast16 = true;     // PAULE_HIP_XCD_FAST16: forward same-XCD hand-off for the 16-row kernels
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
     bool wide_ingest = true;    // PAULE_HIP_WIDE_INGEST: f32 backward sweep sums the partial tiles with 16-byte loads, wave by wave
+    bool wide_ingest16 = true;  // PAULE_HIP_WIDE_INGEST16: 16-row bf16 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool sweep16 = true;        // PAULE_HIP_SWEEP16: 16-row groups for bf16 batches of up to 128 rows (lstm_persist16.hip)
     bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
                                 // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
@@ -389,7 +390,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
             s.xchg = h->sweep_xchg;
-            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : (h->own_store ? 2 : 0);
+            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
             launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
@@ -681,6 +682,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_SMALL_GRID")) h->small_grid = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_SWEEP16")) h->sweep16 = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST16")) h->wide_ingest16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST")) h->wide_ingest = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_OWN_STORE")) h->own_store = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST16")) h->xcd_fast16 = std::atoi(z) != 0;
