@@ -84,15 +84,32 @@ static void launch_cfg(hipStream_t stream, const void* A, int lda, const void* W
                        K, nbn);
 }
 
+// Tile choice: the large tiles when they make enough workgroups, else smaller ones (the time chunks of the layer wavefront are
+// products of a few hundred rows: 128-row tiles would leave them on a handful of CUs).  Every configuration consumes K in the
+// same order, so an output element has the same bits whichever tile computes it.
 template <typename AT, typename OT>
 static void launch_typed(hipStream_t stream, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                          int ldc, int M, int N, int K) {
-    if (N <= 32)
-        launch_cfg<AT, OT, 256, 32, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
-    else if (N <= 64)
-        launch_cfg<AT, OT, 128, 64, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);   // 2 x 2 waves of 64 x 32
-    else
-        launch_cfg<AT, OT, 128, 128, 64, 64>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    constexpr long kEnough = 64;
+    if (N <= 32) {
+        if (blocks(256, 32) >= kEnough || M <= 64)
+            launch_cfg<AT, OT, 256, 32, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        else
+            launch_cfg<AT, OT, 64, 32, 16, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    } else if (N <= 64) {
+        if (blocks(128, 64) >= kEnough || M <= 32)
+            launch_cfg<AT, OT, 128, 64, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);   // 2 x 2 waves of 64 x 32
+        else
+            launch_cfg<AT, OT, 32, 64, 16, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    } else {
+        if (blocks(128, 128) >= kEnough || M <= 32)
+            launch_cfg<AT, OT, 128, 128, 64, 64>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        else if (blocks(64, 64) >= kEnough)
+            launch_cfg<AT, OT, 64, 64, 32, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        else
+            launch_cfg<AT, OT, 32, 64, 16, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    }
 }
 
 void launch_gemm_nt(hipStream_t stream, int dt, bool out_f32, const void* A, int lda, const void* W, int ldw,

@@ -60,6 +60,11 @@ struct LstmSweepArgs {
     const void* Wih;       // packed [4*Hp][in_p]
     const float* bias;     // b_ih + b_hh, [4*Hp]
     int in_p;
+    // time chunk (16-row bf16 and f32 kernels only): the launch runs steps t0 .. t1-1 of the T-step recurrence (t1 = 0: all
+    // T steps).  The flags / stashes of the neighbouring chunk are in place when the launch starts (stream order); the f32 cell
+    // state (forward: c, backward: dL/dc) crosses the chunk border through `carry` [Bp][Hp] f32.
+    int t0, t1;
+    float* carry;
     int stash_via_lds;     // forward, 32-row kernel: 1 = the five stash arrays leave through LDS as 64-byte row pieces
 };
 bool lstm_sweep_supported(int dt, int Hp);

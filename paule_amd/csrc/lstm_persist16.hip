@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int t_begin = a.t0, t_end = a.t1 > 0 ? a.t1 : T;   // time chunk of this launch
     const int gs = a.group_rows;                 // <= 16
     const int n_groups = (Bp + gs - 1) / gs;
     const bf16_t* __restrict__ W = static_cast<const bf16_t*>(a.W);
@@ -94,11 +95,15 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
         const bool ok = lr < gs && b < Bp;
         const int bc = ok ? b : Bp - 1;
         float c_state[2] = {0.f, 0.f};
+        if (t_begin > 0) {
+            c_state[0] = a.carry[(size_t)bc * Hp + 32 * p + ul[0]];
+            c_state[1] = a.carry[(size_t)bc * Hp + 32 * p + ul[1]];
+        }
         int* cnt = a.counters + (size_t)g * T * a.flag_stride;
         int* xtab = a.xcc_tab + (size_t)g * 64;
         bool plain_handoff = false;
 
-        for (int t = 0; t < T; ++t) {
+        for (int t = t_begin; t < t_end; ++t) {
             float gx[2][4];
             f32x4 acc[2];
             if constexpr (KSX > 0) {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
 #pragma unroll
                     for (int gate = 0; gate < 4; ++gate) gx[jt][gate] = 0.f;
                 }
-                if (t == 0) __syncthreads();
+                if (t == t_begin) __syncthreads();
             } else {
                 const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + 32 * p;
 #pragma unroll
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
             PL_ST(0);
             if (t > 0) {
                 if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
-                if (t == 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+                if (t == t_begin + 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t - 1) * slabH, (unsigned)(slabH * 2));
                 uint4 v[NLD];
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
                 }
             }
             PL_ST(3);
-            if (t == 0 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == t_begin && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // cell update (2 cells per lane) -> all six outputs into the staging image [array][row][unit]
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
@@ -221,6 +226,10 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
             publish<2>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
         }
+        if (t_end < T && ok) {
+            a.carry[(size_t)b * Hp + 32 * p + ul[0]] = c_state[0];
+            a.carry[(size_t)b * Hp + 32 * p + ul[1]] = c_state[1];
+        }
     }
     PL_ST_DUMP(a.stamps);
 }
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int t_begin = a.t0, t_end = a.t1 > 0 ? a.t1 : T;   // time chunk of this launch
     const int gs = a.group_rows;
     const int n_groups = (Bp + gs - 1) / gs;
     const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);   // Whh^T packed [Hp][4*Hp]
@@ -287,11 +297,15 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
         const bool ok = erow < gs && b < Bp;
         const int bc = ok ? b : Bp - 1;
         float dc_next[2] = {0.f, 0.f};
+        if (t_end < T) {
+            dc_next[0] = a.carry[(size_t)bc * Hp + j];
+            dc_next[1] = a.carry[(size_t)bc * Hp + j + 1];
+        }
         int* xtab = a.xcc_tab + (size_t)g * 64;
         bool plain_handoff = false;
         int* cnt = a.counters + (size_t)g * T * a.flag_stride;
 
-        for (int t = T - 1; t >= 0; --t) {
+        for (int t = t_end - 1; t >= t_begin; --t) {
             const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
             float gi[2], gf[2], gg[2], go[2], c[2], cp[2] = {0.f, 0.f}, dh[2] = {0.f, 0.f};
             ld2(g_row, gi);
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
             PL_ST(0);
             if (t + 1 < T) {
                 if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
-                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+                if (t == t_end - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
                 const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
                 *reinterpret_cast<unsigned*>(go_ + 3 * Hp) = po;
             }
             if (t == 0) break;   // nobody consumes the partials of step 0
-            if (t == T - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == t_end - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
                 unsigned char* drow = da_img + erow * DRS + jq * 4;
                 *reinterpret_cast<unsigned*>(drow) = pi;
@@ -434,6 +448,10 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
             PL_ST(5);
             publish<0>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
+        }
+        if (t_begin > 0 && ok) {
+            a.carry[(size_t)b * Hp + j] = dc_next[0];
+            a.carry[(size_t)b * Hp + j + 1] = dc_next[1];
         }
     }
     PL_ST_DUMP(a.stamps);

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int t_begin = a.t0, t_end = a.t1 > 0 ? a.t1 : T;   // time chunk of this launch
     const int n_groups = (Bp + 15) / 16;         // Bp is a multiple of 16: groups are whole
     const float* __restrict__ W = static_cast<const float*>(a.W);
     const int kq = lane >> 4;
@@ -94,12 +95,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
 
     for (int g = g_first; g < n_groups; g += n_res) {
         const int b = 16 * g + bl;
-        float c_state = 0.f;
+        float c_state = t_begin > 0 ? a.carry[(size_t)b * Hp + j] : 0.f;
         int* cnt = a.counters + (size_t)g * T * a.flag_stride;
         int* xtab = a.xcc_tab + (size_t)g * 64;
         bool plain_handoff = false;
 
-        for (int t = 0; t < T; ++t) {
+        for (int t = t_begin; t < t_end; ++t) {
             float gx[4] = {0.f, 0.f, 0.f, 0.f};
             f32x4 acc;
             if constexpr (KSX > 0) {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
                     *reinterpret_cast<uint4*>(ximg + row * XRS + c * 16) = xv;
                 }
                 acc = bias_r;
-                if (t == 0) __syncthreads();
+                if (t == t_begin) __syncthreads();
             } else {
                 const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
 #pragma unroll
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
             PL_ST(0);
             if (t > 0) {
                 if (!wait_arrivals(cnt + (size_t)(t - 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
-                if (t == 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+                if (t == t_begin + 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t - 1) * slabH, (unsigned)(slabH * 4));
                 uint4 v[NLD];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
             const float vg = tanhf(acc[2] + gx[2]), vo = sigmoid_f(acc[3] + gx[3]);
             c_state = vf * c_state + vi * vg;
             const float vh = vo * tanhf(c_state);
-            if (t == 0 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == t_begin && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // hand-off first: the workgroup's h tile (16 rows x 16 units) leaves as whole 64-byte row pieces
             {   // all six outputs leave through LDS as whole 64-byte row pieces (a lane's own values are single floats)
                 unsigned char* o = hst + bl * HRS + (4 * wave + kq) * 4;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
             publish<2>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
         }
+        if (t_end < T) a.carry[(size_t)b * Hp + j] = c_state;
     }
     PL_ST_DUMP(a.stamps);
 }
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int t_begin = a.t0, t_end = a.t1 > 0 ? a.t1 : T;   // time chunk of this launch
     const int n_groups = (Bp + 15) / 16;
     const float* __restrict__ WT = static_cast<const float*>(a.W);   // Whh^T packed [Hp][4*Hp]
     const int kq = lane >> 4;
@@ -252,12 +255,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
 
     for (int g = g_first; g < n_groups; g += n_res) {
         const int b = 16 * g + erow;
-        float dc_next = 0.f;
+        float dc_next = t_end < T ? a.carry[(size_t)b * Hp + j] : 0.f;
         int* cnt = a.counters + (size_t)g * T * a.flag_stride;
         int* xtab = a.xcc_tab + (size_t)g * 64;
         bool plain_handoff = false;
 
-        for (int t = T - 1; t >= 0; --t) {
+        for (int t = t_end - 1; t >= t_begin; --t) {
             const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
             const float gi = g_row[0], gf = g_row[Hp], gg = g_row[2 * Hp], go = g_row[3 * Hp];
             const float c = Cs[(size_t)t * slabH + (size_t)b * Hp + j];
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
             PL_ST(0);
             if (t + 1 < T) {
                 if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
-                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+                if (t == t_end - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const float* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
                 const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 4));
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
                 go_[3 * Hp] = dao;
             }
             if (t == 0) break;   // nobody consumes the partials of step 0
-            if (t == T - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == t_end - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 16 + unit]
                 float* drow = reinterpret_cast<float*>(da_img + erow * DRS) + eu;
                 drow[0] = dai;
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
             publish<0>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
         }
+        if (t_begin > 0) a.carry[(size_t)b * Hp + j] = dc_next;
     }
     PL_ST_DUMP(a.stamps);
 }

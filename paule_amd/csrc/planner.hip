@@ -86,6 +86,10 @@ struct LstmLayer {
     bool set = false;
     ParamState p_wih, p_whh, p_bih, p_bhh;           // masters (continued learning, pl_get_lstm_weights)
     float *gWih = nullptr, *gWhh = nullptr, *gb = nullptr;   // weight gradients in the padded compute layout
+    // layer wavefront (small batches): f32 cell state crossing a time-chunk border (forward c / backward dL/dc) and this
+    // layer's own reduce-scatter exchange (the layers' backward sweeps run side by side)
+    float *carry_f = nullptr, *carry_b = nullptr;
+    void* xchg = nullptr;
 };
 
 struct Model {
@@ -170,6 +174,15 @@ struct pl_handle {
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
     bool wide_ingest = true;    // PAULE_HIP_WIDE_INGEST: f32 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool wide_ingest16 = true;  // PAULE_HIP_WIDE_INGEST16: 16-row bf16 backward sweep sums the partial tiles with 16-byte loads, wave by wave
+    int wavefront = 4;          // PAULE_HIP_WAVEFRONT = time chunks (0 off): small sweeps run the layers of a model side by side, layer l + 1
+                                // on chunk c while layer l is on chunk c + 1 (model_forward_wavefront)
+    int wf_dirs = 3;            // PAULE_HIP_WF_DIRS: bit 0 forward, bit 1 backward (experiments)
+    std::vector<hipStream_t> wf_streams;   // layer streams: every wavefront region of an iteration takes its own (HIP's capture does not
+                                           // survive a stream that is forked, joined and forked again with others in one capture)
+    size_t wf_stream_next = 0;
+    bool wf_on = false;
+    std::vector<hipEvent_t> wf_pool;   // events of the (layer, chunk) dependencies: none is recorded twice inside one iteration
+    size_t wf_next = 0;
     bool sweep16 = true;        // PAULE_HIP_SWEEP16: 16-row groups for bf16 batches of up to 128 rows (lstm_persist16.hip)
     bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
                                 // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
@@ -305,12 +318,25 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
         launch_lstm_sweep(st, bwd, Hp, grid, s);
 }
 
+int wavefront_depth(pl_handle* h, const Model& md);
+int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb);
+void model_forward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl, int nc, int lb, int le);
+void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn, int Tl, int nc, int lb, int le);
+
 // stacked LSTM forward over all Tl steps; in_act = time-major [Tl][Bp][in_p]
 void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl_use = 0) {
     const int Bp = h->Bp, Hp = md.Hp, Tl = Tl_use > 0 ? Tl_use : md.Tl;
     const size_t a = h->act;
-    const void* cur_in = in_act;
+    const int wf_nc = (h->wf_dirs & 1) ? wavefront_chunks(h, md, Tl, 0) : 0;
+    const int wf_depth = wf_nc ? wavefront_depth(h, md) : 0;
     for (int l = 0; l < md.L; ++l) {
+        if (wf_nc && md.L - l >= 2) {   // a band of layers as a wavefront
+            const int le = l + wf_depth < md.L ? l + wf_depth : md.L;
+            model_forward_wavefront(h, st, md, in_act, Tl, wf_nc, l, le);
+            l = le - 1;
+            continue;
+        }
+        const void* cur_in = l == 0 ? in_act : md.layers[l - 1].h;
         LstmLayer& ly = md.layers[l];
         const int sweep_grid = sweep_grid_for(h, Hp);
         // narrow inputs (CP, mel): the persistent sweep computes W_ih x_t + b itself; otherwise one batched GEMM for all
@@ -338,7 +364,6 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, 
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps;
             launch_sweep(h, st, false, Hp, sweep_grid, s);
-            cur_in = ly.h;
             continue;
         }
         for (int t = 0; t < Tl; ++t) {
@@ -354,7 +379,6 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, 
             s.c_stash_t = off(ly.c, (size_t)t * Bp * Hp, a);
             launch_lstm_fwd_step(st, h->dt, s);
         }
-        cur_in = ly.h;
     }
 }
 
@@ -368,7 +392,15 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
                     const void* in_act = nullptr, int Tl_use = 0) {
     const int Bp = h->Bp, Hp = md.Hp, Tl = Tl_use > 0 ? Tl_use : md.Tl;
     const size_t a = h->act;
+    const int wf_nc = (h->wf_dirs & 2) ? wavefront_chunks(h, md, Tl, train_nb) : 0;
+    const int wf_depth = wf_nc ? wavefront_depth(h, md) : 0;
     for (int l = md.L - 1; l >= 0; --l) {
+        if (wf_nc && l >= 1) {   // a band of layers as a wavefront
+            const int lb = l + 1 - wf_depth > 0 ? l + 1 - wf_depth : 0;
+            model_backward_wavefront(h, st, md, dh_last, dIn, Tl, wf_nc, lb, l + 1);
+            l = lb;
+            continue;
+        }
         LstmLayer& ly = md.layers[l];
         const bool sparse_top = (l == md.L - 1) && dh_last;
         const int sweep_grid = sweep_grid_for(h, Hp, true);
@@ -427,6 +459,163 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
     }
 }
 
+// ---- layer wavefront -------------------------------------------------------------------------------------------
+// A batch of one 16-row group occupies 23 (bf16) / 46 (f32) of the 256 CUs, and a stacked model runs its layers one after
+// the other: L * T dependent steps.  Cut into time chunks the layers overlap -- layer l + 1 works on chunk c while layer l is
+// on chunk c + 1 -- and the chain shrinks to about (chunks + L - 1) / chunks * T steps.  Every (layer, chunk) is one launch of
+// the same sweep kernel on steps t0 .. t1-1 (flags and stashes of the chunk before are in place by stream order; the f32 cell
+// state crosses the border through `carry`), the batched projections between the layers run per chunk, each layer has its own
+// stream, events carry the (layer, chunk) dependencies, and the whole pattern is captured into the iteration's graph.
+// All persistent workgroups of the sweeps that run side by side must be co-resident -- per XCD: workgroup b of a launch goes
+// to XCD b % 8 and waits there for a free CU (these kernels take a CU each), so with two half-resident sweeps on one XCD
+// neither would ever complete.  A band of at most depth = (CUs of an XCD) / (workgroups one sweep keeps on an XCD) layers
+// forms one wavefront; a deeper model runs band after band.  H = 720 in bf16 pins a group's 23 workgroups to one XCD
+// (the 8-slot grid): no second sweep fits beside it, and spreading the group instead costs more than the overlap gains.
+int wavefront_depth(pl_handle* h, const Model& md) {
+    const int Hp = md.Hp;
+    if (md.L < 2 || sweep_grid_for(h, Hp, false) <= 0 || sweep_grid_for(h, Hp, true) <= 0) return 0;
+    const int groups = (h->Bp + 15) / 16;
+    int per_xcd;
+    if (h->dt == F32) {
+        const int P = Hp / 16, grid = lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu);
+        if (grid < groups * P) return 0;   // the groups take turns already
+        per_xcd = (grid + 7) / 8;
+    } else if (use_sweep16(h, Hp, false) && use_sweep16(h, Hp, true)) {
+        const int P = Hp / 32, slots = lstm_sweep16_grid(Hp, h->Bp, h->n_cu, h->small_grid) / P;
+        if (slots < groups) return 0;
+        per_xcd = slots % 8 == 0 ? (groups + 7) / 8 * P : (slots * P + 7) / 8;   // slot s sits on XCD s % 8 / spread
+    } else {
+        return 0;
+    }
+    int depth = (h->n_cu / 8) / per_xcd;
+    if (depth > md.L) depth = md.L;
+    if (depth > 8) depth = 8;
+    return depth >= 2 ? depth : 0;
+}
+
+int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb) {
+    if (h->wavefront <= 0 || h->sweep_slot < 0 || train_nb > 0 || !md.layers[0].carry_f) return 0;
+    if (wavefront_depth(h, md) < 2) return 0;
+    if (h->sweep_slot + md.L > h->n_sweep_slots) return 0;
+    int nc = h->wavefront < 32 ? h->wavefront : 32;
+    if (nc > Tl / 4) nc = Tl / 4;
+    return nc >= 2 ? nc : 0;
+}
+
+hipStream_t wavefront_stream(pl_handle* h) {
+    if (h->wf_stream_next == h->wf_streams.size()) {
+        hipStream_t q = nullptr;
+        (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+        h->wf_streams.push_back(q);
+    }
+    return h->wf_streams[h->wf_stream_next++];
+}
+
+hipEvent_t wavefront_event(pl_handle* h) {
+    if (h->wf_next == h->wf_pool.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->wf_pool.push_back(e);
+    }
+    return h->wf_pool[h->wf_next++];
+}
+
+void fill_sweep_common(pl_handle* h, LstmSweepArgs& s, int Tl, int* slice) {
+    s.Bp = h->Bp;
+    s.T = Tl;
+    s.group_rows = 16;
+    s.counters = slice;
+    s.flag_stride = h->flag_stride;
+    s.xcc_tab = slice + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
+    s.xcd_fast = 0;   // the XCD table of a slice is filled once, by the first chunk's workgroups: later launches may sit elsewhere
+    s.status = h->sweep_status;
+    s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
+    s.stamps = nullptr;
+}
+
+// layers lb .. le-1 (le - lb <= 8) of the model as one wavefront of nc time chunks
+void model_forward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl, int nc, int lb, int le) {
+    const int Bp = h->Bp, Hp = md.Hp;
+    const size_t a = h->act;
+    const int grid = sweep_grid_for(h, Hp);
+    int* slice[8];
+    hipEvent_t ev[8] = {};   // ev[i]: layer lb + i finished its latest chunk
+    hipStream_t ls[8];
+    for (int l = lb; l < le; ++l) {
+        slice[l - lb] = take_sweep_slice(h, st);
+        ls[l - lb] = l == lb ? st : wavefront_stream(h);
+    }
+    for (int c = 0; c < nc; ++c) {
+        const int t0 = (int)((long long)c * Tl / nc), t1 = (int)((long long)(c + 1) * Tl / nc);
+        for (int l = lb; l < le; ++l) {
+            LstmLayer& ly = md.layers[l];
+            hipStream_t sl = ls[l - lb];
+            if (l > lb) (void)hipStreamWaitEvent(sl, ev[l - 1 - lb], 0);
+            const void* cur_in = l == 0 ? in_act : md.layers[l - 1].h;
+            const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
+            if (!fuse_in)
+                launch_gemm_nt(sl, h->dt, false, off(const_cast<void*>(cur_in), (size_t)t0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p,
+                               ly.bias, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, (t1 - t0) * Bp, 4 * Hp, ly.in_p);
+            LstmSweepArgs s{};
+            fill_sweep_common(h, s, Tl, slice[l - lb]);
+            s.G = ly.G; s.W = ly.Whh; s.h = ly.h; s.c = ly.c;
+            if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
+            s.stash_via_lds = h->stash_lds ? 1 : 0;
+            s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
+            launch_sweep(h, sl, false, Hp, grid, s);
+            if (l < le - 1 || c == nc - 1) {
+                ev[l - lb] = wavefront_event(h);
+                (void)hipEventRecord(ev[l - lb], sl);
+            }
+        }
+    }
+    for (int l = lb + 1; l < le; ++l) (void)hipStreamWaitEvent(st, ev[l - lb], 0);   // join
+}
+
+void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn, int Tl, int nc, int lb, int le) {
+    const int Bp = h->Bp, Hp = md.Hp, top = le - 1;
+    const size_t a = h->act;
+    const int grid = sweep_grid_for(h, Hp, true);
+    int* slice[8];
+    hipEvent_t ev[8] = {};   // ev[i]: layer lb + i finished its latest chunk, projection included
+    hipStream_t ls[8];
+    for (int l = top; l >= lb; --l) {
+        slice[l - lb] = take_sweep_slice(h, st);
+        ls[l - lb] = l == top ? st : wavefront_stream(h);
+    }
+    for (int c = nc - 1; c >= 0; --c) {
+        const int t0 = (int)((long long)c * Tl / nc), t1 = (int)((long long)(c + 1) * Tl / nc);
+        for (int l = top; l >= lb; --l) {
+            LstmLayer& ly = md.layers[l];
+            hipStream_t sl = ls[l - lb];
+            if (l < top) (void)hipStreamWaitEvent(sl, ev[l + 1 - lb], 0);
+            const bool sparse_top = l == md.L - 1 && dh_last;
+            LstmSweepArgs s{};
+            fill_sweep_common(h, s, Tl, slice[l - lb]);
+            s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
+            s.dh_ext = sparse_top ? nullptr : md.dh_ext;
+            s.dh_last = sparse_top ? dh_last : nullptr;
+            s.xchg = ly.xchg;
+            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
+            s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
+            launch_sweep(h, sl, true, Hp, grid, s);
+            // dL/dh of the layer below (in place in md.dh_ext: the rows of chunk c are read by layer l before they are written
+            // for layer l - 1, both in this stream's order), or the model's input gradient
+            if (l > 0)
+                launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
+                               off(md.dh_ext, (size_t)t0 * Bp * Hp, a), Hp, (t1 - t0) * Bp, Hp, 4 * Hp);
+            else
+                launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
+                               dIn + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * Hp);
+            if (l > lb || c == 0) {
+                ev[l - lb] = wavefront_event(h);
+                (void)hipEventRecord(ev[l - lb], sl);
+            }
+        }
+    }
+    for (int l = lb; l < top; ++l) (void)hipStreamWaitEvent(st, ev[l - lb], 0);   // join
+}
+
 void pred_forward(pl_handle* h, hipStream_t st) {
     launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
     model_forward(h, st, h->pred, h->X0);
@@ -474,6 +663,8 @@ AdamArgs adam_args(pl_handle* h) {
 // one inner iteration: forward, criterion, backward-data, Adam + projection
 void enqueue_iteration(pl_handle* h, hipStream_t st) {
     const bool with_sem = h->need_emb_in_step();
+    h->wf_next = 0;
+    h->wf_stream_next = 0;
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
     pred_forward(h, st);
     if (with_sem) emb_forward(h, st, nullptr);
@@ -703,6 +894,33 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
         }
+        if (const char* z = std::getenv("PAULE_HIP_WAVEFRONT")) h->wavefront = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
+        if (h->wavefront > 0 && h->use_sweep) {
+            for (Model* md : {&h->pred, &h->emb}) {
+                if (md->L < 2 || wavefront_depth(h, *md) < 2) continue;
+                const size_t xb = h->dt == F32 ? (lstm_sweep_f32_supported(md->Hp) ? lstm_f32_exchange_bytes(md->Hp, h->Bp) : 0)
+                                               : (lstm_sweep_supported(h->dt, md->Hp) ? lstm_rs_exchange_bytes(md->Hp, h->Bp) : 0);
+                if (!xb) continue;
+                for (auto& ly : md->layers) {
+                    if ((rc = dev_alloc(h, &ly.carry_f, Bp * md->Hp))) return bail(rc);
+                    if ((rc = dev_alloc(h, &ly.carry_b, Bp * md->Hp))) return bail(rc);
+                    if ((rc = raw_alloc(h, &ly.xchg, xb))) return bail(rc);
+                }
+            }
+            h->wf_on = true;
+            // streams and events of an iteration up front (none is created while a capture is running)
+            size_t n_streams = 0, n_events = 0;
+            for (Model* md : {&h->pred, &h->emb})
+                if (md->L >= 2 && md->layers[0].carry_f) {
+                    n_streams += 2 * (size_t)(md->L - 1);
+                    n_events += 2 * (size_t)md->L * (size_t)(h->wavefront < 32 ? h->wavefront : 32);
+                }
+            for (size_t i = 0; i < n_streams; ++i) (void)wavefront_stream(h);
+            for (size_t i = 0; i < n_events; ++i) (void)wavefront_event(h);
+            h->wf_stream_next = 0;
+            h->wf_next = 0;
+        }
         if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
         const size_t n_groups_max = (Bp + 7) / 8;   // groups hold >= 8 rows
         const int slice = h->dt == F32 ? 16 : 32;   // hidden units per workgroup
@@ -732,6 +950,8 @@ int pl_destroy(pl_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     drop_graph(h);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (auto& ws : h->wf_streams) if (ws) (void)hipStreamDestroy(ws);
+    for (auto& ev : h->wf_pool) if (ev) (void)hipEventDestroy(ev);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return PL_OK;
@@ -908,10 +1128,12 @@ int pl_synchronize(pl_handle* h) {
         }
     }
 #endif
+    // on the handle's own stream: a copy on the legacy stream would collide with another handle's graph capture
     int st = 0;
-    PL_HIP(hipMemcpy(&st, h->sweep_status, sizeof(int), hipMemcpyDeviceToHost));
+    PL_HIP(hipMemcpyAsync(&st, h->sweep_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PL_HIP(hipStreamSynchronize(h->stream));
     if (st != 0) {
-        (void)hipMemset(h->sweep_status, 0, sizeof(int));
+        (void)hipMemsetAsync(h->sweep_status, 0, sizeof(int), h->stream);
         return fail(PL_ERR_HIP, "persistent LSTM sweep: a bounded in-kernel wait timed out (workgroups of one batch group were not "
                                 "co-resident?); results of the last pl_step are invalid");
     }

@@ -674,6 +674,31 @@ def test_bf16_sweep16_equals_sweep32(HipPlanner, golden_small, shape, monkeypatc
     assert d.max() <= 0.5 * 0.01 * 5 and d.mean() <= 1e-4, (d.max(), d.mean())
 
 
+@pytest.mark.parametrize("shape", [dict(B=2, T=64, set="A", dtype="f32", graph=True), dict(B=20, T=50, set="A", dtype="f32", graph=False),
+                                   dict(B=5, T=61, set="B", dtype="bf16", graph=True), dict(B=40, T=36, set="B", dtype="bf16", graph=False),
+                                   dict(B=140, T=24, set="B", dtype="bf16", graph=True), dict(B=3, T=37, set="B", dtype="f32", graph=True)])
+def test_layer_wavefront_is_bit_identical(HipPlanner, shape, monkeypatch):
+    """Stacked models whose sweeps leave CUs free run their layers as a wavefront over time chunks (planner.hip,
+    model_forward_wavefront): the same kernels on step ranges, the f32 cell state handed over through a carry buffer, the
+    projections between the layers per chunk.  Nothing about the arithmetic changes: losses and the planned CP are
+    bit-identical to the layer-after-layer schedule, for any number of chunks (uneven chunk lengths included), with and
+    without graph capture."""
+    wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
+    outs = []
+    for chunks in ("0", "4", "7"):
+        monkeypatch.setenv("PAULE_HIP_WAVEFRONT", chunks)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=shape["B"], n_frames=shape["T"], objective="acoustic_semvec", dtype=shape["dtype"],
+                         use_graph=shape["graph"])
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        loss = _n(eng.step(4))
+        eng.synchronize()
+        outs.append((loss, _n(eng.get_cp())) + tuple(_n(x) for x in eng.get_pred()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
     """Nonzero return code -> ValueError with the library's message (the reference's convention for its one C library,
     paule/util.py:33-34): call-sequence errors (PL_ERR_STATE) and bad arguments (PL_ERR_INVALID); nothing aborts, and the
