@@ -30,6 +30,7 @@ CONFIGS = {
     "cfg3": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
     "cfg3_setB": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="B"),
+    "cfg3_setC": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="C"),   # older embedder (8f rank 4)
     "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     # small enough for several ranks to share ONE GPU (two persistent sweeps side by side need all their workgroups resident):
     # used with --dist-backend gloo --device-index 0 to rehearse the multi-rank path on a one-GPU box

@@ -88,6 +88,14 @@ typedef struct pl_config {
     int32_t inv_layers, inv_hidden;
     int32_t inv_mel_blocks;   /* mel_smooth_layers, 3 */
     int32_t inv_res_blocks;   /* resid_blocks, 5 (0 also drops resid_weighting, paule/models.py:206, :240) */
+    /* embedder variants.  Both 0 = EmbeddingModel as Paule builds it (LSTM -> linear_mapping).
+     * emb_post_size > 0: the head is post_linear(H -> post) -> LeakyReLU(0.01) -> output mapping(post -> sem_dim):
+     *   EmbeddingModel(post_upsampling_size > 0) (paule/models.py:432-435, :443-446) and
+     *   MelEmbeddingModelMelSmoothResidualUpsampling (paule/models.py:387-389, :405-407; post 8192).
+     * emb_mel_blocks > 0: that many MelChannelConv1D(mel_dim, 3) blocks with residual connections in front of the LSTM
+     *   (paule/models.py:384-385, :393-401; Identity activation). */
+    int32_t emb_post_size;
+    int32_t emb_mel_blocks;
 } pl_config;
 
 /* Fills *cfg with the reference's defaults (weights, lr, betas, clamp, dims 30/60/300). */
@@ -138,6 +146,15 @@ int pl_get_pred(pl_handle *h, float *pred_mel_out, float *pred_semvec_out);
 /* EmbeddingModel.forward on an arbitrary mel [B, T/2, mel_dim] (paule/paule.py:533-535, :1131):
  * lens [B] int32 device pointer or NULL (= T/2 for every utterance, paule/paule.py:922-924). */
 int pl_embed_mel(pl_handle *h, const float *mel, const int32_t *lens, float *semvec_out);
+
+/* ---- embedder variants (pl_config.emb_post_size / emb_mel_blocks) --------------------------------------
+ * With emb_post_size > 0, pl_set_linear(PL_MODEL_EMBED) takes post_linear [post, H] (the linear that reads the LSTM output) and
+ * pl_set_embedder_output the mapping behind the LeakyReLU: linear_mapping.weight [sem_dim, post] of
+ * EmbeddingModel(post_upsampling_size > 0) / upsampling.weight of MelEmbeddingModelMelSmoothResidualUpsampling, bias [sem_dim].
+ * pl_set_embedder_conv: MelBlocks[block].ConvLayers[idx], w [mel_dim/3, 3, 5], b [mel_dim/3] (paule/models.py:148-150).
+ * The planning loop differentiates through all of it (head, LSTM stack, mel blocks) exactly as through the plain embedder. */
+int pl_set_embedder_output(pl_handle *h, const float *w, const float *b);
+int pl_set_embedder_conv(pl_handle *h, int block, int idx, const float *w, const float *b);
 
 /* ---- inverse model: initial CP from the target mel -------------------------------------------------
  * The LSTM stack and post_linear are uploaded with pl_set_lstm_weights / pl_set_linear and model_id PL_MODEL_INVERSE

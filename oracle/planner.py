@@ -55,18 +55,56 @@ class OracleForwardModel(torch.nn.Module):
         return out
 
 
-class OracleEmbeddingModel(torch.nn.Module):
-    """post_upsampling_size == 0 path only (what Paule instantiates, paule/paule.py:167)."""
+class _OracleMelConv(torch.nn.Module):
+    """MelChannelConv1D parameters (paule/models.py:142-150)."""
 
-    def __init__(self, input_size=60, output_size=300, hidden_size=720, num_lstm_layers=1):
+    def __init__(self, units, width):
         super().__init__()
+        self.ConvLayers = torch.nn.ModuleList([torch.nn.Conv1d(units, units // width, 5, padding=2, groups=units // width)
+                                               for _ in range(width)])
+
+
+def mel_blocks_forward(blocks, x):
+    """x (B, T', M) through residual MelChannelConv1D blocks with Identity activation (paule/models.py:152-169, :222-227,
+    :393-401): conv j of a block reads the input shifted by (j - 1) channels (zero filled) and writes channels 3g + j."""
+    B, T, M = x.shape
+    h = x.transpose(1, 2)                                                         # (B, M, T')
+    for blk in blocks:
+        zero = h.new_zeros(B, 1, T)
+        views = (torch.cat((zero, h[:, :-1]), dim=1), h, torch.cat((h[:, 1:], zero), dim=1))
+        outs = [conv(v) for conv, v in zip(blk.ConvLayers, views)]                # each (B, M/3, T')
+        h = h + torch.stack(outs, dim=2).reshape(B, M, T)
+    return h.transpose(1, 2)
+
+
+class OracleEmbeddingModel(torch.nn.Module):
+    """EmbeddingModel (paule/models.py:413-448) and MelEmbeddingModelMelSmoothResidualUpsampling (:362-409), same state-dict
+    keys: optional residual mel blocks, stacked LSTM, output at lens - 1, then ``linear_mapping`` (post_upsampling_size = 0,
+    what Paule instantiates, paule/paule.py:167) or post_linear -> LeakyReLU -> ``linear_mapping`` / ``upsampling``."""
+
+    def __init__(self, input_size=60, output_size=300, hidden_size=720, num_lstm_layers=1, post_upsampling_size=0,
+                 mel_smooth_layers=0, output_name="linear_mapping"):
+        super().__init__()
+        self.output_name = output_name
+        if mel_smooth_layers > 0:
+            self.MelBlocks = torch.nn.ModuleList([_OracleMelConv(input_size, 3) for _ in range(mel_smooth_layers)])
+        self.n_mel_blocks = mel_smooth_layers
         self.lstm = torch.nn.LSTM(input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
-        self.linear_mapping = torch.nn.Linear(hidden_size, output_size)
+        self.post_upsampling_size = post_upsampling_size
+        if post_upsampling_size > 0:
+            self.post_linear = torch.nn.Linear(hidden_size, post_upsampling_size)
+            setattr(self, output_name, torch.nn.Linear(post_upsampling_size, output_size))
+        else:
+            self.linear_mapping = torch.nn.Linear(hidden_size, output_size)
 
     def forward(self, x, lens, *args):
+        if self.n_mel_blocks > 0:
+            x = mel_blocks_forward(self.MelBlocks, x)
         out, _ = self.lstm(x)
         out = torch.stack([out[i, (last - 1).long(), :] for i, last in enumerate(lens)])
-        return self.linear_mapping(out)
+        if self.post_upsampling_size > 0:
+            out = torch.nn.functional.leaky_relu(self.post_linear(out), 0.01)     # torch.nn.LeakyReLU() default slope
+        return getattr(self, self.output_name)(out)
 
 
 def _lstm_dims(sd):
@@ -78,16 +116,20 @@ def _lstm_dims(sd):
 
 def forward_model_from_state_dict(sd, dtype=torch.float64):
     in_size, hidden, n_layers = _lstm_dims(sd)
-    m = OracleForwardModel(in_size, sd["post_linear.weight"].shape[0], hidden, n_layers)
-    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-    return m.to(dtype)
+    m = OracleForwardModel(in_size, sd["post_linear.weight"].shape[0], hidden, n_layers).to(dtype)   # cast first: no rounding through f32
+    m.load_state_dict({k: torch.as_tensor(v).to(dtype) for k, v in sd.items()})
+    return m
 
 
 def embedding_model_from_state_dict(sd, dtype=torch.float64):
     in_size, hidden, n_layers = _lstm_dims(sd)
-    m = OracleEmbeddingModel(in_size, sd["linear_mapping.weight"].shape[0], hidden, n_layers)
-    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-    return m.to(dtype)
+    out_name = "upsampling" if "upsampling.weight" in sd else "linear_mapping"
+    post = int(sd["post_linear.weight"].shape[0]) if "post_linear.weight" in sd else 0
+    n_mel = len({k.split(".")[1] for k in sd if k.startswith("MelBlocks.")})
+    m = OracleEmbeddingModel(in_size, sd[out_name + ".weight"].shape[0], hidden, n_layers, post_upsampling_size=post,
+                             mel_smooth_layers=n_mel, output_name=out_name).to(dtype)
+    m.load_state_dict({k: torch.as_tensor(v).to(dtype) for k, v in sd.items()})
+    return m
 
 
 # --------------------------------------------------------------------------------------
@@ -305,13 +347,6 @@ class OracleTrainer:
 # --------------------------------------------------------------------------------------
 # inverse model (initial CP from the target mel, paule/paule.py:550-556)
 # --------------------------------------------------------------------------------------
-class _OracleMelConv(torch.nn.Module):
-    def __init__(self, units, width):
-        super().__init__()
-        self.ConvLayers = torch.nn.ModuleList([torch.nn.Conv1d(units, units // width, 5, padding=2, groups=units // width)
-                                               for _ in range(width)])
-
-
 class _OracleTimeRes(torch.nn.Module):
     def __init__(self, units):
         super().__init__()
@@ -334,13 +369,7 @@ class OracleInverseModel(torch.nn.Module):
 
     def forward(self, x, *args):
         B, T, M = x.shape
-        h = x.transpose(1, 2)                                                     # (B, M, T')
-        for blk in self.MelBlocks:                                                # :222-227
-            zero = h.new_zeros(B, 1, T)
-            views = (torch.cat((zero, h[:, :-1]), dim=1), h, torch.cat((h[:, 1:], zero), dim=1))   # :152-158
-            outs = [conv(v) for conv, v in zip(blk.ConvLayers, views)]            # each (B, M/3, T')
-            h = h + torch.stack(outs, dim=2).reshape(B, M, T)                     # channel 3g + j <- conv j, group g (:165-166)
-        x = h.transpose(1, 2)
+        x = mel_blocks_forward(self.MelBlocks, x)                                 # :222-227
         vel = x[:, 1:] - x[:, :-1]                                                # :56-60
         acc = vel[:, 1:] - vel[:, :-1]
         z = x.new_zeros(B, 1, M)

@@ -17,7 +17,7 @@ def __getattr__(name):   # lazy: importing the package must not need torch.cuda
     if name == "HipPlanner":
         from .engine import HipPlanner
         return HipPlanner
-    if name in ("ForwardModel", "EmbeddingModel", "InverseModelMelTimeSmoothResidual"):
+    if name in ("ForwardModel", "EmbeddingModel", "InverseModelMelTimeSmoothResidual", "MelEmbeddingModelMelSmoothResidualUpsampling"):
         from . import models as _m
         return getattr(_m, name)
     raise AttributeError(name)

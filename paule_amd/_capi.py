@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
     "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
-    "pl_set_inverse_conv", "pl_inverse_forward",
+    "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
     "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
     "pl_last_error", "pl_version",
 )
@@ -45,6 +45,7 @@ class PlConfig(C.Structure):
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("smiling", C.c_int32), ("device", C.c_int32),
         ("use_graph", C.c_int32), ("stream", C.c_void_p),
         ("inv_layers", C.c_int32), ("inv_hidden", C.c_int32), ("inv_mel_blocks", C.c_int32), ("inv_res_blocks", C.c_int32),
+        ("emb_post_size", C.c_int32), ("emb_mel_blocks", C.c_int32),
     ]
 
 
@@ -94,6 +95,8 @@ def load_library(path: str | None = None):
     lib.pl_get_linear.argtypes = [vp, C.c_int, fp, fp]
     lib.pl_set_inverse_conv.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp]
     lib.pl_inverse_forward.argtypes = [vp, fp, C.c_int, fp, C.c_int]
+    lib.pl_set_embedder_output.argtypes = [vp, fp, fp]
+    lib.pl_set_embedder_conv.argtypes = [vp, C.c_int, C.c_int, fp, fp]
     lib.pl_get_pred_optimizer_state.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     lib.pl_set_pred_optimizer_state.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     lib.pl_get_pred_optimizer_step.restype = C.c_int64
@@ -106,7 +109,7 @@ def load_library(path: str | None = None):
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
                  "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
-                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward",
+                 "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
                  "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_set_pred_optimizer_step"):
         getattr(lib, name).restype = C.c_int
     if path is None:

@@ -113,6 +113,48 @@ __global__ void resid_weight_kernel(const float* __restrict__ zs, const float* _
     y[idx] = acc;
 }
 
+// backward-data of mel_block_kernel (embedder variants with mel smoothing in the planning loop, paule/models.py:393-401):
+// dx = dy + conv^T(dy).  Element (b, t, c) of the input / output sits at b * sb + t * st + c, so the same kernel reads the
+// LSTM's time-major input gradient ([Tp][Bp][Mp]: sb = Mp, st = Bp * Mp) and the batch-major intermediates.
+__global__ void mel_block_bwd_kernel(const float* __restrict__ dy, int64_t sb_in, int64_t st_in, int B, int Tp, int M,
+                                     const float* __restrict__ w, float* __restrict__ dx, int64_t sb_out, int64_t st_out) {
+    const int64_t n = (int64_t)B * Tp * M;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % M);
+    const int t = (int)((idx / M) % Tp);
+    const int bb = (int)(idx / ((int64_t)M * Tp));
+    const int G = M / 3;
+    const float* db = dy + (size_t)bb * sb_in;
+    float acc = db[(size_t)t * st_in + c];
+    for (int j = 0; j < 3; ++j) {                  // conv j read input channel c as its q-th tap of group g: 3g + q + (j - 1) = c
+        const int u = c - (j - 1);
+        if (u < 0 || u >= M) continue;
+        const int g = u / 3, q = u % 3;
+        const float* wj = w + ((size_t)j * G + g) * 15 + q * 5;
+        for (int k = 0; k < 5; ++k) {
+            const int ts = t - k + 2;              // output frame that read input frame t through tap k
+            if (ts >= 0 && ts < Tp) acc += wj[k] * db[(size_t)ts * st_in + 3 * g + j];
+        }
+    }
+    dx[(size_t)bb * sb_out + (size_t)t * st_out + c] = acc;
+}
+
+// LeakyReLU of the embedder head (post_activation, paule/models.py:374, :425): pre f32 -> activation type
+template <typename AT>
+__global__ void leaky_kernel(const float* __restrict__ pre, int64_t n, float slope, AT* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float v = pre[idx];
+    out[idx] = from_f32<AT>(v > 0.f ? v : slope * v);
+}
+template <typename AT>
+__global__ void leaky_bwd_kernel(const float* __restrict__ d, const float* __restrict__ pre, int64_t n, float slope, AT* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    out[idx] = from_f32<AT>(pre[idx] > 0.f ? d[idx] : slope * d[idx]);
+}
+
 __global__ void clip_copy_kernel(const float* __restrict__ x, int64_t n, int clip, float* __restrict__ y) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -124,6 +166,22 @@ __global__ void clip_copy_kernel(const float* __restrict__ x, int64_t n, int cli
 
 void launch_mel_block(hipStream_t st, const float* x, int B, int Tp, int M, const float* w, const float* b, float* y) {
     hipLaunchKernelGGL(mel_block_kernel, dim3(blocks256((int64_t)B * Tp * M)), dim3(256), 0, st, x, B, Tp, M, w, b, y);
+}
+
+void launch_mel_block_bwd(hipStream_t st, const float* dy, int64_t sb_in, int64_t st_in, int B, int Tp, int M, const float* w, float* dx,
+                          int64_t sb_out, int64_t st_out) {
+    hipLaunchKernelGGL(mel_block_bwd_kernel, dim3(blocks256((int64_t)B * Tp * M)), dim3(256), 0, st, dy, sb_in, st_in, B, Tp, M, w, dx,
+                       sb_out, st_out);
+}
+
+void launch_leaky(hipStream_t st, int dt, const float* pre, int64_t n, float slope, void* out) {
+    if (dt == BF16) hipLaunchKernelGGL(leaky_kernel<bf16_t>, dim3(blocks256(n)), dim3(256), 0, st, pre, n, slope, static_cast<bf16_t*>(out));
+    else hipLaunchKernelGGL(leaky_kernel<float>, dim3(blocks256(n)), dim3(256), 0, st, pre, n, slope, static_cast<float*>(out));
+}
+
+void launch_leaky_bwd(hipStream_t st, int dt, const float* d, const float* pre, int64_t n, float slope, void* out) {
+    if (dt == BF16) hipLaunchKernelGGL(leaky_bwd_kernel<bf16_t>, dim3(blocks256(n)), dim3(256), 0, st, d, pre, n, slope, static_cast<bf16_t*>(out));
+    else hipLaunchKernelGGL(leaky_bwd_kernel<float>, dim3(blocks256(n)), dim3(256), 0, st, d, pre, n, slope, static_cast<float*>(out));
 }
 
 void launch_vel_acc_pack(hipStream_t st, int dt, const float* x, int B, int Tp, int M, void* dst, int Bp, int in_p) {

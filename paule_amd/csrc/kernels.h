@@ -183,6 +183,12 @@ void launch_adam_bias(hipStream_t stream, const float* grad, int nblk, int R, in
 
 // ---- inverse model forward (inverse.hip; InverseModelMelTimeSmoothResidual, paule/models.py:177-247) ---------------
 void launch_mel_block(hipStream_t st, const float* x, int B, int Tp, int M, const float* w, const float* b, float* y);
+// backward-data of a mel block; element (b, t, c) at b * sb + t * st + c on either side (batch-major or time-major padded)
+void launch_mel_block_bwd(hipStream_t st, const float* dy, int64_t sb_in, int64_t st_in, int B, int Tp, int M, const float* w, float* dx,
+                          int64_t sb_out, int64_t st_out);
+// LeakyReLU of the embedder head and its backward (by the sign of the pre-activation)
+void launch_leaky(hipStream_t st, int dt, const float* pre, int64_t n, float slope, void* out);
+void launch_leaky_bwd(hipStream_t st, int dt, const float* d, const float* pre, int64_t n, float slope, void* out);
 void launch_vel_acc_pack(hipStream_t st, int dt, const float* x, int B, int Tp, int M, void* dst, int Bp, int in_p);
 void launch_double_seq(hipStream_t st, const float* Y, int B, int Tp, int C, int Bp, int Cp, float* z);
 void launch_time_conv5(hipStream_t st, const float* x, int B, int T, int C, const float* w, const float* b, const float* resid, float* y);

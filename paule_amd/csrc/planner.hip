@@ -129,6 +129,19 @@ struct pl_handle {
     void* inv_in = nullptr;                     // [Tp][Bp][pad32(3M)] LSTM input
     float* inv_Y = nullptr;                     // [Tp][Bp][Cp] post_linear output
     float* inv_z[3] = {nullptr, nullptr, nullptr};   // [B][2Tp][C]: lstm_output, smoothed, scratch
+    // embedder variants (pl_config.emb_post_size / emb_mel_blocks): head post_linear -> LeakyReLU -> output mapping, mel blocks in front
+    int emb_post = 0, emb_post_p = 0, emb_blocks = 0;
+    void *Wup = nullptr, *WupT = nullptr;       // output mapping [Sp][post_p] and its transpose [post_p][Sp]
+    float* bup = nullptr;
+    bool up_set = false;
+    float* emb_conv = nullptr;                  // mel blocks: [3][G][15] + [3][G] each
+    std::vector<char> emb_conv_set;
+    float* emb_x[2] = {nullptr, nullptr};       // [B][Tp][M] ping-pong of the mel blocks (forward and backward)
+    void* emb_in = nullptr;                     // [Tp][Bp][Mp] LSTM input behind the mel blocks
+    float* emb_din = nullptr;                   // [Tp][Bp][Mp] input gradient of the LSTM stack (time-major)
+    float* head_pre = nullptr;                  // [Bp][post_p] post_linear output (pre-activation)
+    void* head_act = nullptr;                   // [Bp][post_p] LeakyReLU(head_pre) / its gradient, activation type
+    float* head_d = nullptr;                    // [Bp][post_p] gradient w.r.t. the activation
     float* c_run[2] = {nullptr, nullptr};
     float* dc_run[2] = {nullptr, nullptr};
     void* X0 = nullptr;
@@ -624,11 +637,74 @@ void pred_forward(pl_handle* h, hipStream_t st) {
     launch_pool_mel(st, h->dt, h->Y, h->B, h->T, h->M, h->Bp, h->Mp, h->mel_bm, h->mel_tm);
 }
 
-void emb_forward(pl_handle* h, hipStream_t st, const int32_t* lens) {
+bool emb_ready(pl_handle* h) {
+    if (!h->emb.ready()) return false;
+    if (h->emb_post > 0 && !h->up_set) return false;
+    for (char c : h->emb_conv_set)
+        if (!c) return false;
+    return true;
+}
+
+constexpr float kLeakySlope = 0.01f;   // torch.nn.LeakyReLU() default (paule/models.py:374, :425)
+
+// mel_bm: the embedder's input batch-major [B][Tp][M] f32 (read by the mel blocks only); h->mel_tm holds the same time-major
+void emb_forward(pl_handle* h, hipStream_t st, const int32_t* lens, const float* mel_bm) {
     Model& e = h->emb;
-    model_forward(h, st, e, h->mel_tm);
+    const void* in_tm = h->mel_tm;
+    if (h->emb_blocks > 0) {   // x = x + MelChannelConv1D(x), emb_blocks times (paule/models.py:393-401)
+        const size_t G = h->M / 3, blk = 3 * G * 16;
+        const float* x = mel_bm;
+        for (int i = 0; i < h->emb_blocks; ++i) {
+            const float* w = h->emb_conv + i * blk;
+            launch_mel_block(st, x, h->B, h->Tp, h->M, w, w + 3 * G * 15, h->emb_x[i & 1]);
+            x = h->emb_x[i & 1];
+        }
+        launch_pack_mel(st, h->dt, x, h->B, h->Tp, h->M, h->emb_in, h->Bp, h->Mp);
+        in_tm = h->emb_in;
+    }
+    model_forward(h, st, e, in_tm);
     launch_gather_last(st, h->dt, e.layers[e.L - 1].h, lens, h->B, e.Tl, h->Bp, e.Hp, h->h_last);
-    launch_gemm_nt(st, h->dt, true, h->h_last, e.Hp, e.Wlin, e.Hp, e.blin, h->sem, h->Sp, h->Bp, h->Sp, e.Hp);
+    if (h->emb_post == 0) {
+        launch_gemm_nt(st, h->dt, true, h->h_last, e.Hp, e.Wlin, e.Hp, e.blin, h->sem, h->Sp, h->Bp, h->Sp, e.Hp);
+        return;
+    }
+    // post_linear -> LeakyReLU -> output mapping (paule/models.py:405-407, :443-446)
+    const int Pp = h->emb_post_p;
+    launch_gemm_nt(st, h->dt, true, h->h_last, e.Hp, e.Wlin, e.Hp, e.blin, h->head_pre, Pp, h->Bp, Pp, e.Hp);
+    launch_leaky(st, h->dt, h->head_pre, (int64_t)h->Bp * Pp, kLeakySlope, h->head_act);
+    launch_gemm_nt(st, h->dt, true, h->head_act, Pp, h->Wup, Pp, h->bup, h->sem, h->Sp, h->Bp, h->Sp, Pp);
+}
+
+// dL/dsem (h->dsem) back through the embedder to dL/dmel (h->dmel_e, time-major f32 [Tp][Bp][Mp])
+void emb_backward(pl_handle* h, hipStream_t st) {
+    Model& e = h->emb;
+    if (h->emb_post == 0) {
+        // dL/dh_last = dsem * W_m
+        launch_gemm_nt(st, h->dt, false, h->dsem, h->Sp, e.WlinT, h->Sp, nullptr, h->dv, e.Hp, h->Bp, e.Hp, h->Sp);
+    } else {
+        const int Pp = h->emb_post_p;
+        launch_gemm_nt(st, h->dt, true, h->dsem, h->Sp, h->WupT, h->Sp, nullptr, h->head_d, Pp, h->Bp, Pp, h->Sp);
+        launch_leaky_bwd(st, h->dt, h->head_d, h->head_pre, (int64_t)h->Bp * Pp, kLeakySlope, h->head_act);
+        launch_gemm_nt(st, h->dt, false, h->head_act, Pp, e.WlinT, Pp, nullptr, h->dv, e.Hp, h->Bp, e.Hp, Pp);
+    }
+    if (h->emb_blocks == 0) {
+        model_backward(h, st, e, h->dv, h->dmel_e);
+        return;
+    }
+    model_backward(h, st, e, h->dv, h->emb_din);
+    // back through the residual mel blocks, last block first: time-major in, batch-major in between, time-major out
+    const size_t G = h->M / 3, blk = 3 * G * 16;
+    const int64_t sb_tm = h->Mp, st_tm = (int64_t)h->Bp * h->Mp, sb_bm = (int64_t)h->Tp * h->M, st_bm = h->M;
+    const float* d = h->emb_din;
+    bool d_tm = true;
+    for (int i = h->emb_blocks - 1; i >= 0; --i) {
+        const bool out_tm = i == 0;
+        float* o = out_tm ? h->dmel_e : h->emb_x[i & 1];
+        launch_mel_block_bwd(st, d, d_tm ? sb_tm : sb_bm, d_tm ? st_tm : st_bm, h->B, h->Tp, h->M, h->emb_conv + i * blk, o,
+                             out_tm ? sb_tm : sb_bm, out_tm ? st_tm : st_bm);
+        d = o;
+        d_tm = out_tm;
+    }
 }
 
 LossArgs loss_args(pl_handle* h, bool with_sem) {
@@ -667,17 +743,14 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     h->wf_stream_next = 0;
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
     pred_forward(h, st);
-    if (with_sem) emb_forward(h, st, nullptr);
+    if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
     LossArgs la = loss_args(h, with_sem);
     launch_loss_reduce(st, la);
     launch_loss_finalize(st, la);
     const float* dmel_e = nullptr;
     if (with_sem) {
-        Model& e = h->emb;
         launch_dsem(st, h->dt, la, h->dsem);
-        // dL/dh_last = dsem * W_m
-        launch_gemm_nt(st, h->dt, false, h->dsem, h->Sp, e.WlinT, h->Sp, nullptr, h->dv, e.Hp, h->Bp, e.Hp, h->Sp);
-        model_backward(h, st, e, h->dv, h->dmel_e);
+        emb_backward(h, st);
         dmel_e = h->dmel_e;
     }
     launch_dy(st, h->dt, la, dmel_e, h->dY);
@@ -778,6 +851,10 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         return fail(PL_ERR_INVALID, "pl_create: n_frames must be >= 14 (jerk needs T - 12 >= 1 frames, mel needs T/2 >= 1)");
     if (cfg->pred_layers < 1 || cfg->pred_hidden < 1) return fail(PL_ERR_INVALID, "pl_create: predictive model needs >= 1 LSTM layer");
     if (cfg->emb_layers < 0 || (cfg->emb_layers > 0 && cfg->emb_hidden < 1)) return fail(PL_ERR_INVALID, "pl_create: bad embedder shape");
+    if (cfg->emb_post_size < 0 || cfg->emb_mel_blocks < 0 || cfg->emb_mel_blocks > 16 ||
+        (cfg->emb_layers == 0 && (cfg->emb_post_size > 0 || cfg->emb_mel_blocks > 0)))
+        return fail(PL_ERR_INVALID, "pl_create: bad embedder head / mel block shape");
+    if (cfg->emb_mel_blocks > 0 && cfg->mel_dim % 3 != 0) return fail(PL_ERR_INVALID, "pl_create: mel blocks need mel_dim divisible by 3");
     if (cfg->dtype != PL_F32 && cfg->dtype != PL_BF16) return fail(PL_ERR_INVALID, "pl_create: dtype must be PL_F32 or PL_BF16");
     if (cfg->objective < PL_OBJ_ACOUSTIC || cfg->objective > PL_OBJ_SEMVEC)
         return fail(PL_ERR_INVALID, "objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'");
@@ -809,7 +886,10 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if ((rc = alloc_model(h, h->pred, cfg->pred_layers, cfg->pred_hidden, h->C, h->M, h->T))) return bail(rc);
     int hmax = h->pred.Hp;
     if (cfg->emb_layers > 0) {
-        if ((rc = alloc_model(h, h->emb, cfg->emb_layers, cfg->emb_hidden, h->M, h->S, h->Tp))) return bail(rc);
+        h->emb_post = cfg->emb_post_size;
+        h->emb_post_p = pad32(cfg->emb_post_size);
+        h->emb_blocks = cfg->emb_mel_blocks;
+        if ((rc = alloc_model(h, h->emb, cfg->emb_layers, cfg->emb_hidden, h->M, h->emb_post > 0 ? h->emb_post : h->S, h->Tp))) return bail(rc);
         hmax = hmax > h->emb.Hp ? hmax : h->emb.Hp;
     }
     const size_t Bp = h->Bp, T = h->T, Tp = h->Tp, B = h->B;
@@ -840,6 +920,24 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if ((rc = alloc_act(h, &h->dY, T * Bp * h->Mp))) return bail(rc);
     if ((rc = dev_alloc(h, &h->dX, T * Bp * h->Cp))) return bail(rc);
     if (cfg->emb_layers > 0) {
+        if (h->emb_post > 0) {
+            const size_t Pp = h->emb_post_p;
+            if ((rc = alloc_act(h, &h->Wup, (size_t)h->Sp * Pp))) return bail(rc);
+            if ((rc = alloc_act(h, &h->WupT, Pp * h->Sp))) return bail(rc);
+            if ((rc = dev_alloc(h, &h->bup, h->Sp))) return bail(rc);
+            if ((rc = dev_alloc(h, &h->head_pre, Bp * Pp))) return bail(rc);
+            if ((rc = alloc_act(h, &h->head_act, Bp * Pp))) return bail(rc);
+            if ((rc = dev_alloc(h, &h->head_d, Bp * Pp))) return bail(rc);
+        }
+        if (h->emb_blocks > 0) {
+            const size_t G = h->M / 3;
+            if ((rc = dev_alloc(h, &h->emb_conv, (size_t)h->emb_blocks * 3 * G * 16))) return bail(rc);
+            h->emb_conv_set.assign((size_t)h->emb_blocks * 3, 0);
+            for (int i = 0; i < 2; ++i)
+                if ((rc = dev_alloc(h, &h->emb_x[i], B * Tp * h->M))) return bail(rc);
+            if ((rc = alloc_act(h, &h->emb_in, Tp * Bp * h->Mp))) return bail(rc);
+            if ((rc = dev_alloc(h, &h->emb_din, Tp * Bp * h->Mp))) return bail(rc);
+        }
         if ((rc = alloc_act(h, &h->h_last, Bp * h->emb.Hp))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sem, Bp * h->Sp))) return bail(rc);
         if ((rc = alloc_act(h, &h->dsem, Bp * h->Sp))) return bail(rc);
@@ -1076,7 +1174,7 @@ int pl_reset_optimizer(pl_handle* h) {
 
 static int check_ready(pl_handle* h, bool need_sem, const char* who) {
     if (!h->pred.ready()) return fail(PL_ERR_STATE, std::string(who) + ": predictive-model weights are not set");
-    if (need_sem && !h->emb.ready()) return fail(PL_ERR_STATE, std::string(who) + ": embedder weights are not set");
+    if (need_sem && !emb_ready(h)) return fail(PL_ERR_STATE, std::string(who) + ": embedder weights are not set");
     if (!h->have_cp) return fail(PL_ERR_STATE, std::string(who) + ": pl_set_cp has not been called");
     return PL_OK;
 }
@@ -1159,7 +1257,7 @@ int pl_get_pred(pl_handle* h, float* pred_mel_out, float* pred_semvec_out) {
     if (pred_mel_out)
         PL_HIP(hipMemcpyAsync(pred_mel_out, h->mel_bm, sizeof(float) * h->B * h->Tp * h->M, hipMemcpyDeviceToDevice, st));
     if (pred_semvec_out) {
-        emb_forward(h, st, nullptr);
+        emb_forward(h, st, nullptr, h->mel_bm);
         launch_unpad_rows(st, h->sem, h->B, h->S, h->Sp, pred_semvec_out);
     }
     return check_launch();
@@ -1168,12 +1266,12 @@ int pl_get_pred(pl_handle* h, float* pred_mel_out, float* pred_semvec_out) {
 int pl_embed_mel(pl_handle* h, const float* mel, const int32_t* lens, float* semvec_out) {
     if (!h || !mel || !semvec_out) return fail(PL_ERR_INVALID, "pl_embed_mel: NULL argument");
     if (h->emb.L == 0) return fail(PL_ERR_INVALID, "pl_embed_mel: the handle has no embedder");
-    if (!h->emb.ready()) return fail(PL_ERR_STATE, "pl_embed_mel: embedder weights are not set");
+    if (!emb_ready(h)) return fail(PL_ERR_STATE, "pl_embed_mel: embedder weights are not set");
     DeviceGuard guard(h->cfg.device);
     SweepChain chain(h->cfg.device, h->stream);
     hipStream_t st = h->stream;
     launch_pack_mel(st, h->dt, mel, h->B, h->Tp, h->M, h->mel_tm, h->Bp, h->Mp);
-    emb_forward(h, st, lens);
+    emb_forward(h, st, lens, mel);
     launch_unpad_rows(st, h->sem, h->B, h->S, h->Sp, semvec_out);
     return check_launch();
 }
@@ -1350,6 +1448,38 @@ int pl_get_linear(pl_handle* h, int model_id, float* w, float* b) {
     int rc = check_launch();
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
+    return PL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// embedder variants (paule/models.py:362-409, :432-446)
+// ---------------------------------------------------------------------------------------------------
+int pl_set_embedder_output(pl_handle* h, const float* w, const float* b) {
+    if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_set_embedder_output: NULL argument");
+    if (h->emb.L == 0 || h->emb_post == 0)
+        return fail(PL_ERR_INVALID, "pl_set_embedder_output: the handle's embedder has no post_linear head (pl_config.emb_post_size)");
+    DeviceGuard guard(h->cfg.device);
+    hipStream_t st = h->stream;
+    launch_pack_matrix(st, h->dt, w, 1, h->S, h->emb_post, h->Wup, h->Sp, h->emb_post_p, false);
+    launch_pack_matrix(st, h->dt, w, 1, h->S, h->emb_post, h->WupT, h->Sp, h->emb_post_p, true);
+    launch_pack_bias(st, b, nullptr, 1, h->S, h->bup, h->Sp);
+    h->up_set = true;
+    int rc = check_launch();
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(st));
+    return PL_OK;
+}
+
+int pl_set_embedder_conv(pl_handle* h, int block, int idx, const float* w, const float* b) {
+    if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_set_embedder_conv: NULL argument");
+    if (h->emb_blocks == 0) return fail(PL_ERR_INVALID, "pl_set_embedder_conv: the handle's embedder has no mel blocks (pl_config.emb_mel_blocks)");
+    if (block < 0 || block >= h->emb_blocks || idx < 0 || idx >= 3) return fail(PL_ERR_INVALID, "pl_set_embedder_conv: no such convolution");
+    const size_t G = h->M / 3, blk = 3 * G * 16;
+    DeviceGuard guard(h->cfg.device);
+    PL_HIP(hipMemcpyAsync(h->emb_conv + block * blk + idx * G * 15, w, sizeof(float) * G * 15, hipMemcpyDeviceToDevice, h->stream));
+    PL_HIP(hipMemcpyAsync(h->emb_conv + block * blk + 3 * G * 15 + idx * G, b, sizeof(float) * G, hipMemcpyDeviceToDevice, h->stream));
+    PL_HIP(hipStreamSynchronize(h->stream));
+    h->emb_conv_set[(size_t)block * 3 + idx] = 1;
     return PL_OK;
 }
 
@@ -1544,7 +1674,8 @@ double pl_flops_per_iteration(const pl_handle* h) {
     // forward + backward-data = 2 x forward; elementwise work excluded
     double f = (lstm_flops_per_step(h->pred.L, h->pred.H, h->C) + 2.0 * h->pred.H * h->M) * h->T;
     if (h->need_emb_in_step())
-        f += lstm_flops_per_step(h->emb.L, h->emb.H, h->M) * h->Tp + 2.0 * h->emb.H * h->S;
+        f += lstm_flops_per_step(h->emb.L, h->emb.H, h->M) * h->Tp +
+             (h->emb_post > 0 ? 2.0 * h->emb_post * (h->emb.H + h->S) : 2.0 * h->emb.H * h->S);
     return 2.0 * f * h->B;
 }
 

@@ -68,8 +68,18 @@ class HipPlanner:
             in_e, hid_e, lay_e = _lstm_dims(emb_sd)
             if in_e != self.M:
                 raise ValueError("embedder input size does not match the predictive model's output size")
-            self.S = int(emb_sd["linear_mapping.weight"].shape[0])
+            # embedder variants (paule/models.py:362-409, :432-446): post_linear -> LeakyReLU -> output mapping, mel blocks in front
+            self._emb_out = "upsampling" if "upsampling.weight" in emb_sd else "linear_mapping"
+            self._emb_post = int(emb_sd["post_linear.weight"].shape[0]) if "post_linear.weight" in emb_sd else 0
+            self._emb_blocks = len({k.split(".")[1] for k in emb_sd if k.startswith("MelBlocks.")})
+            if self._emb_post == 0 and self._emb_out != "linear_mapping":
+                raise ValueError("embedder state dict has an upsampling layer but no post_linear")
+            for k, v in emb_sd.items():
+                if k.startswith("MelBlocks.") and k.endswith("weight") and tuple(v.shape[1:]) != (3, 5):
+                    raise NotImplementedError("only the default mel smoothing (filter size 3 over channels, 5 over time) is supported")
+            self.S = int(emb_sd[self._emb_out + ".weight"].shape[0])
             cfg.emb_layers, cfg.emb_hidden, cfg.sem_dim = lay_e, hid_e, self.S
+            cfg.emb_post_size, cfg.emb_mel_blocks = self._emb_post, self._emb_blocks
         else:
             self.S = 0
             cfg.emb_layers, cfg.emb_hidden = 0, 0
@@ -103,7 +113,7 @@ class HipPlanner:
         self.has_embedder = emb_sd is not None
         self._dims = {"pred": (lay_p, hid_p, "post_linear"), "pred_in": in_p}
         if emb_sd is not None:
-            self._dims.update({"embedder": (lay_e, hid_e, "linear_mapping"), "embedder_in": self.M})
+            self._dims.update({"embedder": (lay_e, hid_e, "post_linear" if self._emb_post else "linear_mapping"), "embedder_in": self.M})
         self.set_weights(pred_sd, emb_sd)
         if inv_sd is not None:
             self._dims.update({"inverse": (lay_i, hid_i, "post_linear"), "inverse_in": 3 * self.M})
@@ -133,8 +143,9 @@ class HipPlanner:
 
     # ---- weights (re-upload after continued learning, paule/paule.py:1372-1377) ----------------
     def set_weights(self, pred_model=None, embedder=None):
+        emb_lin = "post_linear" if getattr(self, "_emb_post", 0) else "linear_mapping"
         for model_id, sd, lin in ((_capi.PL_MODEL_PRED, _state_dict(pred_model), "post_linear"),
-                                  (_capi.PL_MODEL_EMBED, _state_dict(embedder), "linear_mapping")):
+                                  (_capi.PL_MODEL_EMBED, _state_dict(embedder), emb_lin)):
             if sd is None:
                 continue
             _, _, n_layers = _lstm_dims(sd)
@@ -143,6 +154,15 @@ class HipPlanner:
                 self._call(self.lib.pl_set_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
             w, b = self._dev(sd[f"{lin}.weight"]), self._dev(sd[f"{lin}.bias"])
             self._call(self.lib.pl_set_linear, model_id, w.data_ptr(), b.data_ptr())
+            if model_id == _capi.PL_MODEL_EMBED:
+                if self._emb_post:
+                    w, b = self._dev(sd[self._emb_out + ".weight"], (self.S, self._emb_post)), self._dev(sd[self._emb_out + ".bias"])
+                    self._call(self.lib.pl_set_embedder_output, w.data_ptr(), b.data_ptr())
+                for i in range(self._emb_blocks):
+                    for j in range(3):
+                        key = f"MelBlocks.{i}.ConvLayers.{j}"
+                        w, b = self._dev(sd[key + ".weight"]), self._dev(sd[key + ".bias"])
+                        self._call(self.lib.pl_set_embedder_conv, i, j, w.data_ptr(), b.data_ptr())
 
     # ---- inverse model: initial CP from the target mel (paule/paule.py:550-556) ------------------
     def set_inverse_weights(self, inv_model):
@@ -195,7 +215,7 @@ class HipPlanner:
             self._call(self.lib.pl_get_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
             for k, t in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), ts):
                 sd[f"lstm.{k}_l{l}"] = t
-        out = self.M if pred else self.S
+        out = self.M if pred else (self._emb_post or self.S)   # the linear that reads the LSTM output
         w = torch.empty((out, H), dtype=torch.float32, device=self.device)
         b = torch.empty((out,), dtype=torch.float32, device=self.device)
         self._call(self.lib.pl_get_linear, model_id, w.data_ptr(), b.data_ptr())

@@ -21,6 +21,11 @@ def _require_gpu(x, who):
                               "paule_amd has no CPU execution path")
 
 
+def _check_leaky(act, what):
+    if not isinstance(act, torch.nn.LeakyReLU) or abs(act.negative_slope - 0.01) > 1e-12:
+        raise NotImplementedError(f"{what}: only torch.nn.LeakyReLU() (slope 0.01, the reference's default) runs on the HIP path")
+
+
 class _HipModule(torch.nn.Module):
     """Caches one forward-only engine handle per (batch, frames, device, dtype) and re-uploads the weights
     when any parameter changed (version counters), e.g. after continued learning."""
@@ -83,13 +88,16 @@ class EmbeddingModel(_HipModule):
     def __init__(self, input_size=60, output_size=300, hidden_size=720, num_lstm_layers=1,
                  post_activation=torch.nn.LeakyReLU(), post_upsampling_size=0, dropout=0):
         super().__init__()
-        if post_upsampling_size > 0:
-            raise NotImplementedError("post_upsampling_size > 0 is not on the planning path (SURVEY 8 a-2)")
         if dropout:
             raise NotImplementedError("dropout > 0 is not on the planning path (Paule uses dropout 0)")
+        _check_leaky(post_activation, "post_activation")
         self.post_upsampling_size = post_upsampling_size
         self.lstm = torch.nn.LSTM(input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True, dropout=dropout)
-        self.linear_mapping = torch.nn.Linear(hidden_size, output_size)
+        if post_upsampling_size > 0:      # paule/models.py:432-435: post_linear -> post_activation -> linear_mapping
+            self.post_linear = torch.nn.Linear(hidden_size, post_upsampling_size)
+            self.linear_mapping = torch.nn.Linear(post_upsampling_size, output_size)
+        else:
+            self.linear_mapping = torch.nn.Linear(hidden_size, output_size)
         self._pred_stub = None
 
     def _refresh(self, eng):
@@ -115,6 +123,31 @@ class EmbeddingModel(_HipModule):
         if len(lens) == 1 and B > 1:
             lens = lens * B
         return eng.embed_mel(x, lens).to(x.dtype)
+
+
+class MelEmbeddingModelMelSmoothResidualUpsampling(EmbeddingModel):
+    """The older embedder (paule/models.py:362-409): residual MelChannelConv1D blocks -> stacked LSTM, output at lens-1 ->
+    post_linear -> LeakyReLU -> upsampling.  Same state_dict keys as the reference (``MelBlocks.i.ConvLayers.j.*``, ``lstm.*``,
+    ``post_linear.*``, ``upsampling.*``); usable as ``Paule(embedder=...)``: the planning loop differentiates through it on
+    the device like through the default embedder."""
+
+    def __init__(self, input_size=60, output_size=300, hidden_size=180, num_lstm_layers=4, mel_smooth_layers=3,
+                 mel_smooth_filter_size=3, mel_resid_activation=torch.nn.Identity(), post_activation=torch.nn.LeakyReLU(),
+                 post_upsampling_size=8192):
+        _HipModule.__init__(self)
+        if mel_smooth_filter_size != 3:
+            raise NotImplementedError("only the default mel_smooth_filter_size = 3 is supported")
+        if not isinstance(mel_resid_activation, torch.nn.Identity):
+            raise NotImplementedError("only the default Identity mel_resid_activation is supported")
+        if post_upsampling_size <= 0:
+            raise ValueError("post_upsampling_size has to be positive")
+        _check_leaky(post_activation, "post_activation")
+        self.post_upsampling_size = post_upsampling_size
+        self.MelBlocks = torch.nn.ModuleList([_MelChannelConv1D(input_size, mel_smooth_filter_size) for _ in range(mel_smooth_layers)])
+        self.lstm = torch.nn.LSTM(input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
+        self.post_linear = torch.nn.Linear(hidden_size, post_upsampling_size)
+        self.upsampling = torch.nn.Linear(post_upsampling_size, output_size)
+        self._pred_stub = None
 
 
 def _stub_pred_sd(mel_dim, cp_dim=30):

@@ -19,6 +19,10 @@ SEED = 20200905   # the reference's own module-level seed (paule/paule.py:38)
 MODEL_SETS = {
     "A": dict(pred=dict(num_lstm_layers=1, hidden_size=720), emb=dict(num_lstm_layers=2, hidden_size=720)),
     "B": dict(pred=dict(num_lstm_layers=4, hidden_size=180), emb=dict(num_lstm_layers=1, hidden_size=720)),
+    # Paule's predictive model with the older embedder, class defaults (MelEmbeddingModelMelSmoothResidualUpsampling,
+    # paule/models.py:370-378): 3 residual mel blocks -> LSTM 4 x 180 -> post_linear 8192 -> LeakyReLU -> upsampling
+    "C": dict(pred=dict(num_lstm_layers=1, hidden_size=720),
+              emb=dict(num_lstm_layers=4, hidden_size=180, mel_smooth_layers=3, post_upsampling_size=8192)),
 }
 
 Workload = namedtuple("Workload", "pred_sd emb_sd target_mel target_semvec cp0 batch n_frames")
@@ -30,6 +34,21 @@ def _lstm_linear_state_dict(in_size, hidden, layers, out_size, lin_name, dtype):
     lin = torch.nn.Linear(hidden, out_size)
     sd = {f"lstm.{k}": v.detach().to(dtype) for k, v in lstm.state_dict().items()}
     sd.update({f"{lin_name}.{k}": v.detach().to(dtype) for k, v in lin.state_dict().items()})
+    return sd
+
+
+def _melsmooth_state_dict(in_size, hidden, layers, out_size, n_blocks, post, dtype):
+    """MelEmbeddingModelMelSmoothResidualUpsampling parameters, torch default init in the reference's creation order
+    (paule/models.py:384-389)."""
+    sd = {}
+    for i in range(n_blocks):
+        for j in range(3):
+            conv = torch.nn.Conv1d(in_size, in_size // 3, 5, padding=2, groups=in_size // 3)
+            sd.update({f"MelBlocks.{i}.ConvLayers.{j}.{k}": v.detach().to(dtype) for k, v in conv.state_dict().items()})
+    lstm = torch.nn.LSTM(in_size, hidden, num_layers=layers, batch_first=True)
+    sd.update({f"lstm.{k}": v.detach().to(dtype) for k, v in lstm.state_dict().items()})
+    for name, lin in (("post_linear", torch.nn.Linear(hidden, post)), ("upsampling", torch.nn.Linear(post, out_size))):
+        sd.update({f"{name}.{k}": v.detach().to(dtype) for k, v in lin.state_dict().items()})
     return sd
 
 
@@ -49,7 +68,10 @@ def make_models(model_set="A", *, pred=None, emb=None, cp_dim=30, mel_dim=60, se
         pred_sd = _lstm_linear_state_dict(cp_dim, pspec["hidden_size"], pspec["num_lstm_layers"], mel_dim,
                                           "post_linear", dtype)
         emb_sd = None
-        if with_embedder and espec:
+        if with_embedder and espec and espec.get("post_upsampling_size"):
+            emb_sd = _melsmooth_state_dict(mel_dim, espec["hidden_size"], espec["num_lstm_layers"], sem_dim,
+                                           espec.get("mel_smooth_layers", 3), espec["post_upsampling_size"], dtype)
+        elif with_embedder and espec:
             emb_sd = _lstm_linear_state_dict(mel_dim, espec["hidden_size"], espec["num_lstm_layers"], sem_dim,
                                              "linear_mapping", dtype)
     return pred_sd, emb_sd

@@ -40,6 +40,11 @@ def golden_inverse():
     return _load("inverse_small.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_embvar():
+    return _load("embedder_variants.npz")
+
+
 def state_dict_from(g, prefix):
     import torch
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}

@@ -326,6 +326,58 @@ def main():
         out["cp_raw_13"] = inv(mel[:, :13].clone()).numpy()                       # a shorter sequence through the same model
     np.savez_compressed(os.path.join(HERE, "inverse_small.npz"), **out)
     print("inverse_small.npz:", len(out), "arrays")
+
+    # ---- fixture 5: the embedder variants with a post_linear -> LeakyReLU -> mapping head (paule/models.py:362-409, :432-446) ----
+    # (a) MelEmbeddingModelMelSmoothResidualUpsampling: residual mel blocks in front of the LSTM, (b) EmbeddingModel with
+    # post_upsampling_size > 0.  Model outputs (ragged lens included) and planning trajectories through the reference loop.
+    pspec = dict(num_lstm_layers=2, hidden_size=24)
+    B, T = 3, 40
+    wl = synthetic.make_workload(B, T, None, pred=pspec, emb=dict(num_lstm_layers=1, hidden_size=8))
+    pm = ref_models.ForwardModel(**pspec).double()
+    pm.load_state_dict(wl.pred_sd)
+    out = dict(B=B, T=T, target_mel=wl.target_mel.numpy(), cp0=wl.cp0.numpy())
+    out.update(npz_state("pred", wl.pred_sd))
+    variants = {
+        "melsmooth": (ref_models.MelEmbeddingModelMelSmoothResidualUpsampling,
+                      dict(hidden_size=20, num_lstm_layers=2, post_upsampling_size=96, output_size=300)),
+        "upsampling": (ref_models.EmbeddingModel, dict(hidden_size=20, num_lstm_layers=1, post_upsampling_size=64, output_size=300)),
+    }
+    for vi, (vname, (cls, kw)) in enumerate(variants.items()):
+        torch.manual_seed(synthetic.SEED + 21 + vi)
+        em = cls(**kw).double()
+        with torch.no_grad():               # default init leaves the convolutions and the head tiny: scale them so every stage matters
+            for name, p_ in em.named_parameters():
+                if "MelBlocks" in name:
+                    p_.mul_(1.5)
+                if name.startswith(("post_linear", "upsampling", "linear_mapping")) and name.endswith("weight"):
+                    p_.mul_(2.0)
+        for p_ in em.parameters():
+            p_.requires_grad_(True)
+        out.update(npz_state(f"{vname}/emb", {k: v.detach().clone() for k, v in em.state_dict().items()}))
+        with torch.no_grad():
+            target_semvec = em(wl.target_mel.clone(), [torch.tensor(20)] * B) + 0.05     # a reachable, not identical target
+            out[f"{vname}/target_semvec"] = target_semvec.numpy()
+            out[f"{vname}/embed_lens"] = np.array([20, 13, 7])
+            out[f"{vname}/embed_semvec_lens"] = em(wl.target_mel.clone(), [torch.tensor(20), torch.tensor(13), torch.tensor(7)]).numpy()
+            out[f"{vname}/embed_semvec_full"] = em(wl.target_mel.clone(), [torch.tensor(20)] * B).numpy()
+        for objective in ("acoustic_semvec", "semvec"):
+            logs, cps, grads = [], {k: [] for k in SNAP}, {k: [] for k in SNAP}
+            fs = []
+            for b in range(B):
+                log, snaps, gr, _, fsem = ref_plan_one(ns, pm, em, objective, wl.cp0[b], wl.target_mel[b], target_semvec[b], 20,
+                                                       snapshots=SNAP)
+                logs.append(log)
+                fs.append(fsem)
+                for k in SNAP:
+                    cps[k].append(snaps[k])
+                    grads[k].append(gr[k])
+            out[f"{vname}/{objective}/loss_log"] = torch.stack(logs, dim=1).numpy()
+            out[f"{vname}/{objective}/final_pred_semvec"] = torch.stack(fs).numpy()
+            for k in SNAP:
+                out[f"{vname}/{objective}/cp_after_{k}"] = torch.stack(cps[k]).numpy()
+                out[f"{vname}/{objective}/grad_at_{k}"] = torch.stack(grads[k]).numpy()
+    np.savez_compressed(os.path.join(HERE, "embedder_variants.npz"), **out)
+    print("embedder_variants.npz:", len(out), "arrays")
     return 0
 
 

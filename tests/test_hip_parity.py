@@ -514,6 +514,29 @@ def test_inverse_model_module_default_shape_vs_oracle():
     np.testing.assert_allclose(_n(got), want, atol=2e-5, rtol=0)
 
 
+def test_paule_with_embedder_variant_hip_equals_oracle_engine(golden_embvar):
+    """Paule(embedder=MelEmbeddingModelMelSmoothResidualUpsampling(...)).plan_resynth on the device against the same host code
+    driving the CPU oracle: the planned CP, the logged semantic losses and the final predicted semantic vector."""
+    from oracle_engine import OracleEngine
+    from paule_amd import models
+    from paule_amd import paule as pp
+    g = golden_embvar
+    emb = models.MelEmbeddingModelMelSmoothResidualUpsampling(hidden_size=20, num_lstm_layers=2, post_upsampling_size=96).double()
+    emb.load_state_dict(state_dict_from(g, "melsmooth/emb"))
+    out = []
+    for factory in (None, lambda pm, em, **kw: OracleEngine(pm, em, **kw)):
+        model = pp.Paule(pred_model=state_dict_from(g, "pred"), embedder=emb, planner_factory=factory,
+                         device=torch.device("cuda" if factory is None else "cpu"))
+        res = model.plan_resynth(target_acoustic=g["target_mel"][:2], target_semvec=g["melsmooth/target_semvec"][:2],
+                                 initial_cp=g["cp0"][:2], initialize_from=None, objective="acoustic_semvec", n_outer=1, n_inner=6,
+                                 log_ii=2, continue_learning=False, verbose=False)
+        out.append((_n(res.planned_cp), np.asarray(res.pred_semvec_loss_steps, dtype=np.float64), _n(res.pred_semvec)))
+    (ch, lh, sh), (co, lo, so) = out
+    np.testing.assert_allclose(ch, co, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(lh, lo, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(sh, so, atol=2e-4, rtol=0)
+
+
 def test_paule_initialize_from_acoustic_hip(golden_inverse):
     """Paule.plan_resynth(initialize_from='acoustic') with the inverse model on the device: initial_cp equals the reference's
     clipped inverse output, and the plan starts from it."""
@@ -697,6 +720,82 @@ def test_layer_wavefront_is_bit_identical(HipPlanner, shape, monkeypatch):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert np.array_equal(a, b)
+
+
+def _variant_engine(HipPlanner, g, variant, objective, dtype="f32", **extra):
+    eng = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, f"{variant}/emb"), batch=int(g["B"]), n_frames=int(g["T"]),
+                     objective=objective, dtype=dtype, **extra)
+    eng.set_targets(g["target_mel"], g[f"{variant}/target_semvec"])
+    eng.set_cp(g["cp0"])
+    return eng
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("objective", ["acoustic_semvec", "semvec"])
+@pytest.mark.parametrize("variant", ["melsmooth", "upsampling"])
+def test_embedder_variants_f32_vs_reference_fixture(HipPlanner, golden_embvar, variant, objective, use_graph):
+    """MelEmbeddingModelMelSmoothResidualUpsampling (residual mel blocks -> LSTM -> post_linear -> LeakyReLU ->
+    upsampling, paule/models.py:362-409) and EmbeddingModel(post_upsampling_size > 0) (:432-446) as the embedder of the planning
+    loop: embedding of a mel (ragged lens), gradients, CP and losses of the reference loop run through the reference's classes,
+    same bars as the default embedder."""
+    g = golden_embvar
+    eng = _variant_engine(HipPlanner, g, variant, objective, use_graph=use_graph)
+    sem = eng.embed_mel(g["target_mel"], lens=g[f"{variant}/embed_lens"])
+    np.testing.assert_allclose(_n(sem), g[f"{variant}/embed_semvec_lens"], atol=FWD_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(_n(eng.embed_mel(g["target_mel"])), g[f"{variant}/embed_semvec_full"], atol=FWD_ATOL_F32, rtol=0)
+    logs, done = [], 0
+    for k in (1, 5, 20):
+        loss, grad = eng.step(k - done, return_grad=True)
+        logs.append(_n(loss))
+        done = k
+        np.testing.assert_allclose(_n(eng.get_cp()), g[f"{variant}/{objective}/cp_after_{k}"], atol=CP_ATOL_F32, rtol=0,
+                                   err_msg=f"cp after {k}")
+        ref_g = g[f"{variant}/{objective}/grad_at_{k}"]
+        np.testing.assert_allclose(_n(grad), ref_g, atol=1e-5 * max(1.0, np.abs(ref_g).max()), rtol=0, err_msg=f"grad at {k}")
+    np.testing.assert_allclose(np.concatenate(logs), g[f"{variant}/{objective}/loss_log"], rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(_n(eng.get_pred()[1]), g[f"{variant}/{objective}/final_pred_semvec"], atol=FWD_ATOL_F32, rtol=0)
+
+
+@pytest.mark.parametrize("variant", ["melsmooth", "upsampling"])
+def test_embedder_variants_bf16_against_oracle(HipPlanner, golden_embvar, variant):
+    g = golden_embvar
+    name = f"{variant}/acoustic_semvec"
+    eng = _variant_engine(HipPlanner, g, variant, "acoustic_semvec", dtype="bf16")
+    loss, grad = eng.step(1, return_grad=True)
+    assert _cos(grad, g[f"{name}/grad_at_1"]) >= COS_BF16
+    more = eng.step(19)
+    np.testing.assert_allclose(np.concatenate([_n(loss), _n(more)]), g[f"{name}/loss_log"], rtol=LOSS_RTOL_BF16, atol=1e-4)
+    np.testing.assert_allclose(_n(eng.get_cp()), g[f"{name}/cp_after_20"], atol=0.05 * 0.01 * 20, rtol=0)
+
+
+def test_embedder_variant_full_size_vs_oracle_rows(HipPlanner):
+    """The class-default MelEmbeddingModelMelSmoothResidualUpsampling (3 mel blocks, LSTM 4 x 180, head 8192) as the embedder
+    of a B = 40 x 60-frame plan, f32: five iterations against the CPU oracle on three of the utterances."""
+    from oracle import planner as op
+    from paule_amd import models
+    torch.manual_seed(5)
+    emb = models.MelEmbeddingModelMelSmoothResidualUpsampling()
+    wl = synthetic.make_workload(40, 60, "A")
+    emb_sd = {k: v.detach().clone() for k, v in emb.state_dict().items()}
+    with torch.no_grad():
+        for k in emb_sd:
+            if k.startswith("MelBlocks."):
+                emb_sd[k] = emb_sd[k] * 1.5
+    ora_e = op.embedding_model_from_state_dict(emb_sd, dtype=torch.float32)
+    with torch.no_grad():
+        target_sem = ora_e(wl.target_mel.float(), [torch.tensor(30)] * 40) + 0.02
+    eng = HipPlanner(wl.pred_sd, emb_sd, batch=40, n_frames=60, objective="acoustic_semvec")
+    eng.set_targets(wl.target_mel, target_sem)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(5))
+    rows = [0, 17, 39]
+    P = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, dtype=torch.float32), ora_e, objective="acoustic_semvec",
+                         dtype=torch.float32)
+    P.set_targets(wl.target_mel[rows], target_sem[rows])
+    P.set_cp(wl.cp0[rows])
+    want = P.step(5).numpy()
+    np.testing.assert_allclose(loss[:, rows, :6], want[:, :, :6], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(_n(eng.get_cp())[rows], _n(P.get_cp()), atol=2e-4, rtol=0)
 
 
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):

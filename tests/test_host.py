@@ -260,6 +260,31 @@ def test_default_models_from_pretrained_dir(small, golden_inverse, tmp_path, mon
     np.testing.assert_allclose(res.initial_cp, golden_inverse["cp_clipped"][0], atol=1e-12)
 
 
+def test_embedder_variant_containers_keep_the_reference_key_layout(golden_embvar):
+    """paule_amd.models.MelEmbeddingModelMelSmoothResidualUpsampling / EmbeddingModel(post_upsampling_size > 0) take the state
+    dicts of the reference's classes as they are (keys and shapes of the fixture come from the reference's modules); unsupported
+    constructor choices are refused instead of being computed differently."""
+    import torch
+    from paule_amd import models
+    g = golden_embvar
+    for variant, mod in (("melsmooth", models.MelEmbeddingModelMelSmoothResidualUpsampling(hidden_size=20, num_lstm_layers=2,
+                                                                                          post_upsampling_size=96)),
+                         ("upsampling", models.EmbeddingModel(hidden_size=20, num_lstm_layers=1, post_upsampling_size=64))):
+        sd = state_dict_from(g, f"{variant}/emb")
+        own = mod.state_dict()
+        assert list(own) == list(sd)
+        assert all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)
+        mod.double().load_state_dict(sd)
+    d = models.MelEmbeddingModelMelSmoothResidualUpsampling()
+    assert d.post_linear.out_features == 8192 and d.lstm.num_layers == 4 and d.lstm.hidden_size == 180 and len(d.MelBlocks) == 3
+    with pytest.raises(NotImplementedError):
+        models.MelEmbeddingModelMelSmoothResidualUpsampling(post_activation=torch.nn.ReLU())
+    with pytest.raises(NotImplementedError):
+        models.MelEmbeddingModelMelSmoothResidualUpsampling(mel_resid_activation=torch.nn.ReLU())
+    with pytest.raises(NotImplementedError):
+        models.EmbeddingModel(post_upsampling_size=16, post_activation=torch.nn.LeakyReLU(0.2))
+
+
 def test_speech_classifier_config(small):
     """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
     clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}

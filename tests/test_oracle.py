@@ -175,6 +175,32 @@ def test_inverse_model_vs_reference_fixture(golden_inverse):
     np.testing.assert_allclose(y13.numpy(), g["cp_raw_13"], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("variant", ["melsmooth", "upsampling"])
+def test_embedder_variants_vs_reference_fixture(golden_embvar, variant):
+    """OracleEmbeddingModel with a post_linear -> LeakyReLU -> mapping head, with and without residual mel blocks, against the
+    reference's MelEmbeddingModelMelSmoothResidualUpsampling (paule/models.py:362-409) and EmbeddingModel(post_upsampling_size
+    > 0) (:432-446): model outputs (ragged lens), and the planning trajectories of the reference loop through them."""
+    g = golden_embvar
+    pred_sd, emb_sd = state_dict_from(g, "pred"), state_dict_from(g, f"{variant}/emb")
+    em = op.embedding_model_from_state_dict(emb_sd)
+    mel = torch.from_numpy(g["target_mel"])
+    with torch.no_grad():
+        _close(em(mel, [torch.tensor(int(l)) for l in g[f"{variant}/embed_lens"]]), g[f"{variant}/embed_semvec_lens"])
+        _close(em(mel, [torch.tensor(20)] * 3), g[f"{variant}/embed_semvec_full"])
+    for objective in ("acoustic_semvec", "semvec"):
+        P = op.OraclePlanner(op.forward_model_from_state_dict(pred_sd), op.embedding_model_from_state_dict(emb_sd), objective=objective)
+        P.set_targets(g["target_mel"], g[f"{variant}/target_semvec"])
+        P.set_cp(g["cp0"])
+        logs, done = [], 0
+        for k in (1, 5, 20):
+            logs.append(P.step(k - done).numpy())
+            done = k
+            _close(P.get_cp(), g[f"{variant}/{objective}/cp_after_{k}"])
+            _close(P.last_grad, g[f"{variant}/{objective}/grad_at_{k}"], 1e-11)
+        _close(np.concatenate(logs), g[f"{variant}/{objective}/loss_log"])
+        _close(P.get_pred()[1], g[f"{variant}/{objective}/final_pred_semvec"])
+
+
 def test_torch_and_manual_oracles_agree_on_random_shapes():
     """The two independent restatements -- torch autograd (oracle/planner.py) and numpy with explicit BPTT (oracle/manual.py:
     the arithmetic the kernels implement) -- against each other on shapes no fixture holds (property test, hypothesis):
