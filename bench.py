@@ -31,6 +31,7 @@ CONFIGS = {
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
     "cfg3_setB": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="B"),
     "cfg3_setC": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="C"),   # older embedder (8f rank 4)
+    "cfg3_soma": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A", tube=True),   # + somatosensory path
     "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     # small enough for several ranks to share ONE GPU (two persistent sweeps side by side need all their workgroups resident):
     # used with --dist-backend gloo --device-index 0 to rehearse the multi-rank path on a one-GPU box
@@ -200,8 +201,9 @@ def main():
     if rank:
         wl_r = synthetic.make_workload(B, T, cfg["model_set"], seed=synthetic.SEED + 1000 * rank)
         wl = wl._replace(target_mel=wl_r.target_mel, target_semvec=wl_r.target_semvec, cp0=wl_r.cp0)
+    tube_kw = dict(tube_models=synthetic.make_tube_models()) if cfg.get("tube") else {}
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective=cfg["objective"], dtype=cfg["dtype"],
-                     device=device, use_graph=not args.no_graph)
+                     device=device, use_graph=not args.no_graph, **tube_kw)
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
 
@@ -283,6 +285,8 @@ def main():
         layers = [(spec["pred"]["hidden_size"], T)] * spec["pred"]["num_lstm_layers"]
         if cfg["objective"] != "acoustic":
             layers += [(spec["emb"]["hidden_size"], T // 2)] * spec["emb"]["num_lstm_layers"]
+        if cfg.get("tube"):
+            layers += [(sp["hidden_size"], T) for sp in synthetic.TUBE_SPECS.values() for _ in range(sp["num_lstm_layers"])]
         bytes_utt = 6 * T * 30 * 4 + (T // 2) * 60 * esz + 2 * esz * sum(6 * hl * tl for hl, tl in layers)
         out = {
             # cfg3 is the configuration BASELINE.json's metric is quoted on: its string verbatim

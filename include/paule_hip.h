@@ -52,7 +52,8 @@ enum { PL_OBJ_ACOUSTIC = 0, PL_OBJ_ACOUSTIC_SEMVEC = 1, PL_OBJ_SEMVEC = 2 };
 /* model ids for pl_set_lstm_weights / pl_set_linear */
 enum { PL_MODEL_PRED = 0 /* ForwardModel, paule/models.py:326 */,
        PL_MODEL_EMBED = 1 /* EmbeddingModel, paule/models.py:413 */,
-       PL_MODEL_INVERSE = 2 /* InverseModelMelTimeSmoothResidual, paule/models.py:177 (optional, pl_config.inv_layers) */ };
+       PL_MODEL_INVERSE = 2 /* InverseModelMelTimeSmoothResidual, paule/models.py:177 (optional, pl_config.inv_layers) */,
+       PL_MODEL_CP_TUBE = 3, PL_MODEL_TUBE_MEL = 4, PL_MODEL_TUBE_EMBED = 5 /* somatosensory feedback, pl_config.cp_tube_layers */ };
 
 /* columns of one loss_log row (weighted sub-losses as logged at paule/paule.py:942-945, :988-992) */
 enum { PL_LOSS_TOTAL = 0, PL_LOSS_MEL = 1, PL_LOSS_SEMVEC = 2, PL_LOSS_VEL = 3, PL_LOSS_JERK = 4,
@@ -96,6 +97,20 @@ typedef struct pl_config {
      *   (paule/models.py:384-385, :393-401; Identity activation). */
     int32_t emb_post_size;
     int32_t emb_mel_blocks;
+    /* somatosensory feedback (paule/paule.py:227-273, :916-929): three more models beside the acoustic path,
+     *   PL_MODEL_CP_TUBE    ForwardModel(cp_dim -> tube_dim, apply_half_sequence=False)  pred_tube      [B, T, tube_dim]
+     *   PL_MODEL_TUBE_MEL   ForwardModel(tube_dim -> mel_dim, apply_half_sequence=True)  pred_tube_mel  [B, T/2, mel_dim]
+     *   PL_MODEL_TUBE_EMBED EmbeddingModel(tube_dim -> sem_dim) on all T tube frames      pred_tube_semvec
+     * and two more loss terms, w_mel * RMSE(pred_tube_mel, target_mel) + w_sem * RMSE(pred_tube_semvec, target_semvec)
+     * (TUBE_MEL_WEIGHT = MEL_WEIGHT, TUBE_SEMANTIC_WEIGHT = SEMANTIC_WEIGHT, paule/paule.py:598-599, :631-642, :745-755), columns
+     * 6 and 7 of the loss log.  Objectives acoustic_semvec and semvec only (the reference's `acoustic` criterion with
+     * somatosensory feedback fails on an unassigned pred_tube_semvec, paule/paule.py:692).  cp_tube_layers = 0: off.
+     * The tube embedder runs without dropout: the reference's default one has dropout 0.7 and is switched to .train() inside
+     * the loop (paule/paule.py:266, :927), i.e. its loss is random there; a tube embedder with dropout 0 is deterministic. */
+    int32_t tube_dim;                          /* 10 */
+    int32_t cp_tube_layers, cp_tube_hidden;    /* 1, 360 */
+    int32_t tube_mel_layers, tube_mel_hidden;  /* 1, 360 */
+    int32_t tube_emb_layers, tube_emb_hidden;  /* 2, 720 */
 } pl_config;
 
 /* Fills *cfg with the reference's defaults (weights, lr, betas, clamp, dims 30/60/300). */
@@ -143,6 +158,12 @@ int pl_get_cp(pl_handle *h, float *cp_out);
 /* Forward only at the current CP (paule/paule.py:822-824, :1460-1464): pred_mel [B, T/2, mel_dim],
  * pred_semvec [B, sem_dim] (may be NULL; requires an embedder). */
 int pl_get_pred(pl_handle *h, float *pred_mel_out, float *pred_semvec_out);
+/* The same for the somatosensory path (paule/paule.py:916-929): pred_tube [B, T, tube_dim], pred_tube_mel [B, T/2, mel_dim],
+ * pred_tube_semvec [B, sem_dim]; any of them may be NULL. */
+int pl_get_tube_pred(pl_handle *h, float *pred_tube_out, float *pred_tube_mel_out, float *pred_tube_semvec_out);
+/* tube_mel_model(tube) and tube_embedder(tube, T) on an arbitrary tube [B, T, tube_dim], e.g. the one extracted from the synthesis
+ * (prod_tube_mel, prod_tube_semvec, paule/paule.py:1084, :1147-1150); either output may be NULL. */
+int pl_embed_tube(pl_handle *h, const float *tube, float *tube_mel_out, float *tube_semvec_out);
 /* EmbeddingModel.forward on an arbitrary mel [B, T/2, mel_dim] (paule/paule.py:533-535, :1131):
  * lens [B] int32 device pointer or NULL (= T/2 for every utterance, paule/paule.py:922-924). */
 int pl_embed_mel(pl_handle *h, const float *mel, const int32_t *lens, float *semvec_out);

@@ -114,9 +114,10 @@ def _lstm_dims(sd):
     return in_size, hidden, n_layers
 
 
-def forward_model_from_state_dict(sd, dtype=torch.float64):
+def forward_model_from_state_dict(sd, dtype=torch.float64, apply_half_sequence=True):
     in_size, hidden, n_layers = _lstm_dims(sd)
-    m = OracleForwardModel(in_size, sd["post_linear.weight"].shape[0], hidden, n_layers).to(dtype)   # cast first: no rounding through f32
+    m = OracleForwardModel(in_size, sd["post_linear.weight"].shape[0], hidden, n_layers,
+                           apply_half_sequence=apply_half_sequence).to(dtype)   # cast first: no rounding through f32
     m.load_state_dict({k: torch.as_tensor(v).to(dtype) for k, v in sd.items()})
     return m
 
@@ -168,12 +169,15 @@ def speech_classifier_logit(pred_mel, w, b):
     return (pred_mel @ w + b).mean(dim=1)
 
 
-def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_semvec=None, classifier=None):
+def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_semvec=None, classifier=None, tube=None):
     """Weighted per-utterance losses -> (loss_b (B,), sub (B, 8)) (paule/paule.py:647-662, :705-717, :760-773; with the
     speech classifier :604-622, :666-683, :723-738).
 
     In the 'semvec' objective the mel loss is evaluated for logging only
     (paule/paule.py:1021) and does not enter the objective.  classifier = (w (M,), b (), weight) or None.
+    tube = (pred_tube_mel, pred_tube_semvec) with somatosensory feedback (paule/paule.py:624-644, :739-757): two more terms
+    against the same targets with TUBE_MEL_WEIGHT = MEL_WEIGHT, TUBE_SEMANTIC_WEIGHT = SEMANTIC_WEIGHT (:598-599), columns 6, 7
+    (the speech classifier and somatosensory feedback exclude each other, :117).
     """
     vel, _, jerk = vel_acc_jerk(cps)                       # paule/paule.py:75-88 with loss=mse_loss
     vel_l = VELOCITY_WEIGHT * _mse_per_utt(vel)
@@ -198,7 +202,14 @@ def criterion(objective, cps, pred_mel, target_mel, pred_semvec=None, target_sem
         # bce_loss(logit, zeros) (paule/paule.py:610-612) = softplus(logit), per utterance
         cls_l = weight * torch.nn.functional.softplus(speech_classifier_logit(pred_mel, w, b))
         loss = loss + cls_l
-    sub = torch.stack([loss, mel_l, sem_l, vel_l, jerk_l, ll_l, cls_l, torch.zeros_like(mel_l)], dim=1)
+    col6, col7 = cls_l, torch.zeros_like(mel_l)
+    if tube is not None:
+        if objective == "acoustic":
+            raise ValueError("somatosensory feedback: the reference's acoustic criterion fails (paule/paule.py:692)")
+        col6 = MEL_WEIGHT * _rmse_per_utt(tube[0], target_mel)
+        col7 = SEMANTIC_WEIGHT * _rmse_per_utt(tube[1], target_semvec)
+        loss = loss + col6 + col7
+    sub = torch.stack([loss, mel_l, sem_l, vel_l, jerk_l, ll_l, col6, col7], dim=1)
     return loss, sub
 
 
@@ -214,14 +225,16 @@ class OraclePlanner:
 
     def __init__(self, pred_model, embedder=None, *, objective="acoustic", lr=0.01,
                  betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False,
-                 dtype=torch.float64):
+                 dtype=torch.float64, tube_models=None):
         if objective not in OBJECTIVES:
             raise ValueError("objective has to be one of 'acoustic_semvec', 'acoustic' or 'semvec'")
         self.objective = objective
         self.dtype = dtype
         self.pred_model = pred_model.to(dtype)
         self.embedder = embedder.to(dtype) if embedder is not None else None
-        for m in (self.pred_model, self.embedder):
+        # somatosensory feedback: (cp_tube_model, tube_mel_model, tube_embedder), paule/paule.py:229-273
+        self.tube_models = None if tube_models is None else tuple(m.to(dtype) for m in tube_models)
+        for m in (self.pred_model, self.embedder) + (self.tube_models or ()):
             if m is not None:
                 for p in m.parameters():
                     p.requires_grad_(False)   # planning needs dL/dCP only
@@ -274,6 +287,17 @@ class OraclePlanner:
             pred_semvec = self.embedder(pred_mel, lens)
         return pred_mel, pred_semvec
 
+    def _predict_tube(self, xx):
+        """pred_tube, pred_tube_mel, pred_tube_semvec (paule/paule.py:916-919, :926-929)."""
+        cp_tube, tube_mel, tube_emb = self.tube_models
+        pred_tube = cp_tube(xx)
+        lens = [torch.tensor(pred_tube.shape[1])] * pred_tube.shape[0]
+        return pred_tube, tube_mel(pred_tube), tube_emb(pred_tube, lens)
+
+    def get_tube_pred(self):
+        with torch.no_grad():
+            return self._predict_tube(self.xx)
+
     def get_pred(self):
         """Forward only at the current CP (paule/paule.py:1460-1464); semvec whenever an embedder exists."""
         with torch.no_grad():
@@ -294,8 +318,9 @@ class OraclePlanner:
         for _ in range(n_iters):
             self.optimizer.zero_grad()                                   # paule.py:911
             pred_mel, pred_semvec = self._predict(self.xx)               # :913, :921-925
+            tube = self._predict_tube(self.xx)[1:] if self.tube_models is not None else None
             loss_b, sub = criterion(self.objective, self.xx, pred_mel, self.target_mel,
-                                    pred_semvec, self.target_semvec, self.classifier)     # :939 / :986 / :1020
+                                    pred_semvec, self.target_semvec, self.classifier, tube)   # :939 / :986 / :1020
             loss_b.sum().backward()                                      # :1052
             self.last_grad = self.xx.grad.detach().clone()
             log.append(sub.detach().clone())

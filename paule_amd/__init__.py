@@ -11,7 +11,7 @@ __version__ = "0.1.0"
 
 
 def __getattr__(name):   # lazy: importing the package must not need torch.cuda
-    if name in ("Paule", "PlanningResults", "PlanningResultsWithSpeechClassifier"):
+    if name in ("Paule", "PlanningResults", "PlanningResultsWithSpeechClassifier", "PlanningResultsWithSomatosensory"):
         from . import paule as _p
         return getattr(_p, name)
     if name == "HipPlanner":

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaule_hip.so")
 PL_F32, PL_BF16 = 0, 1
 PL_OBJ = {"acoustic": 0, "acoustic_semvec": 1, "semvec": 2}
 PL_MODEL_PRED, PL_MODEL_EMBED, PL_MODEL_INVERSE = 0, 1, 2
+PL_MODEL_CP_TUBE, PL_MODEL_TUBE_MEL, PL_MODEL_TUBE_EMBED = 3, 4, 5
 PL_CONV_MEL, PL_CONV_RES, PL_CONV_RW = 0, 1, 2
 PL_LOSS_COLS = 8
 
@@ -23,7 +24,7 @@ PL_LOSS_COLS = 8
 EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
     "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
-    "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
+    "pl_get_pred", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
     "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
     "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
@@ -46,6 +47,8 @@ class PlConfig(C.Structure):
         ("use_graph", C.c_int32), ("stream", C.c_void_p),
         ("inv_layers", C.c_int32), ("inv_hidden", C.c_int32), ("inv_mel_blocks", C.c_int32), ("inv_res_blocks", C.c_int32),
         ("emb_post_size", C.c_int32), ("emb_mel_blocks", C.c_int32),
+        ("tube_dim", C.c_int32), ("cp_tube_layers", C.c_int32), ("cp_tube_hidden", C.c_int32), ("tube_mel_layers", C.c_int32),
+        ("tube_mel_hidden", C.c_int32), ("tube_emb_layers", C.c_int32), ("tube_emb_hidden", C.c_int32),
     ]
 
 
@@ -86,6 +89,8 @@ def load_library(path: str | None = None):
     lib.pl_synchronize.argtypes = [vp]
     lib.pl_get_cp.argtypes = [vp, fp]
     lib.pl_get_pred.argtypes = [vp, fp, fp]
+    lib.pl_get_tube_pred.argtypes = [vp, fp, fp, fp]
+    lib.pl_embed_tube.argtypes = [vp, fp, fp, fp]
     lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
     lib.pl_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_int64, C.POINTER(C.c_int64)]
     lib.pl_bench_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
@@ -108,7 +113,7 @@ def load_library(path: str | None = None):
     lib.pl_flops_per_iteration.argtypes = [vp]
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
-                 "pl_get_pred", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
+                 "pl_get_pred", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
                  "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
                  "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_set_pred_optimizer_step"):
         getattr(lib, name).restype = C.c_int

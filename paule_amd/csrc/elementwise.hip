@@ -193,32 +193,34 @@ __device__ __forceinline__ double corr_sumsq(const double* __restrict__ x, int T
     return s;
 }
 
-// six sums at once (fixed order: deterministic): wave-level shuffle tree, then the four waves' partials through LDS
-__device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh)[6]) {
+// N sums at once (fixed order: deterministic): wave-level shuffle tree, then the waves' partials through LDS
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double (*sh)[N]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < N; ++k) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
     }
     if (lane == 0)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sh[wave][k] = v[k];
+        for (int k = 0; k < N; ++k) sh[wave][k] = v[k];
     __syncthreads();
     const int nw = blockDim.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < N; ++k) {
         double t = 0.0;
         for (int w = 0; w < nw; ++w) t += sh[w][k];
         v[k] = t;
     }
 }
+__device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh)[6]) { block_sum_n<6>(v, sh); }
 
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a) {
-    __shared__ double sh[16][6];
+    __shared__ double sh[16][8];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     double* sc = a.scal + (size_t)b * 8;
-    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // mel SSE, semvec SSE, vel, jerk, ll, classifier logit sum
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // mel SSE, semvec SSE, vel, jerk, ll, classifier logit sum, tube mel SSE, tube semvec SSE
 
     // RMSE over the utterance's T' x M mel frames (RMSELoss eps = 0, paule/util.py:570-572) and, in the same pass, the speech
     // classifier's logit: mean over time of Linear(60 -> 1) (paule/models.py:899-908)
@@ -235,14 +237,28 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a) {
             const double d = (double)a.sem[(size_t)b * a.Sp + e] - (double)a.target_sem[(size_t)b * a.S + e];
             s[1] += d * d;
         }
+    if (a.mel2) {
+        const float* m2 = a.mel2 + (size_t)b * nm;
+        for (int e = tid; e < nm; e += nt) {
+            const double d = (double)m2[e] - (double)tgt[e];
+            s[6] += d * d;
+        }
+    }
+    if (a.sem2)
+        for (int e = tid; e < a.S; e += nt) {
+            const double d = (double)a.sem2[(size_t)b * a.Sp + e] - (double)a.target_sem[(size_t)b * a.S + e];
+            s[7] += d * d;
+        }
     const double* x = a.x + (size_t)b * a.T * a.C;
     const size_t per = (size_t)a.T * a.C;
     double* dws = a.dwork + (size_t)b * 3 * per;     // [vel | jerk | ll] correlations of this utterance
     s[2] = corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws);
     s[3] = corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per);
     s[4] = corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per);
-    block_sum6(s, sh);
+    block_sum_n<8>(s, sh);
     if (tid == 0) {
+        sc[6] = a.mel2 ? sqrt(s[6] / nm) : 0.0;
+        sc[7] = a.sem2 ? sqrt(s[7] / a.S) : 0.0;
         sc[0] = sqrt(s[0] / nm);
         sc[1] = a.sem ? sqrt(s[1] / a.S) : 0.0;
         sc[2] = s[2] / ((double)(a.T - 4) * a.C);
@@ -266,7 +282,9 @@ __global__ void loss_finalize_kernel(LossArgs a) {
     // BCEWithLogits(z, 0) = softplus(z) (paule/paule.py:610-612), numerically stable form
     const double z = sc[5];
     const double cls = a.cls_wb ? a.w_cls * (fmax(z, 0.0) + log1p(exp(-fabs(z)))) : 0.0;
-    double total = vel + jerk + ll + cls;
+    // somatosensory feedback: both tube terms enter whenever they are evaluated (paule/paule.py:642, :755)
+    const double tmel = a.mel2 ? a.w_mel * sc[6] : 0.0, tsem = a.sem2 ? a.w_sem * sc[7] : 0.0;
+    double total = vel + jerk + ll + cls + tmel + tsem;
     if (a.use_mel) total += mel;
     if (a.use_sem) total += sem;
     float* row = a.loss_rows + ((size_t)(*a.iter_slot) * a.B + b) * 8;
@@ -276,8 +294,8 @@ __global__ void loss_finalize_kernel(LossArgs a) {
     row[3] = (float)vel;
     row[4] = (float)jerk;
     row[5] = (float)ll;
-    row[6] = (float)cls;
-    row[7] = 0.f;
+    row[6] = (float)(a.mel2 ? tmel : cls);   // speech classifier and somatosensory feedback exclude each other (paule/paule.py:117)
+    row[7] = (float)tsem;
 }
 
 void launch_loss_finalize(hipStream_t stream, const LossArgs& a) {
@@ -287,31 +305,32 @@ void launch_loss_finalize(hipStream_t stream, const LossArgs& a) {
 // d(w_sem * rmse_sem)/d sem = w_sem (sem - tgt) / (S * rmse).  rmse == 0 (exact match) would be 0/0 in the
 // reference (RMSELoss eps = 0); the gradient is defined as 0 there instead of NaN.
 template <typename AT>
-__global__ void dsem_kernel(LossArgs a, AT* __restrict__ dsem) {
+__global__ void dsem_kernel(LossArgs a, AT* __restrict__ dsem, int tube) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.Bp * a.Sp) return;
     const int b = idx / a.Sp, s = idx % a.Sp;
+    const float* sem = tube ? a.sem2 : a.sem;
     float v = 0.f;
     if (b < a.B && s < a.S) {
-        const double rm = a.scal[(size_t)b * 8 + 1];
+        const double rm = a.scal[(size_t)b * 8 + (tube ? 7 : 1)];
         if (rm > 0.0)
-            v = (float)((double)a.w_sem * ((double)a.sem[(size_t)b * a.Sp + s] - (double)a.target_sem[(size_t)b * a.S + s]) /
+            v = (float)((double)a.w_sem * ((double)sem[(size_t)b * a.Sp + s] - (double)a.target_sem[(size_t)b * a.S + s]) /
                         ((double)a.S * rm));
     }
     dsem[idx] = from_f32<AT>(v);
 }
 
-void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem) {
+void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem, bool tube) {
     const int n = a.Bp * a.Sp;
     if (dt == BF16)
-        hipLaunchKernelGGL(dsem_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, static_cast<bf16_t*>(dsem));
+        hipLaunchKernelGGL(dsem_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, static_cast<bf16_t*>(dsem), tube ? 1 : 0);
     else
-        hipLaunchKernelGGL(dsem_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, static_cast<float*>(dsem));
+        hipLaunchKernelGGL(dsem_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, static_cast<float*>(dsem), tube ? 1 : 0);
 }
 
 // dL/dY (pre-pool linear output): each pooled frame's gradient goes half to each of its two frames.
 template <typename AT>
-__global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __restrict__ dY) {
+__global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __restrict__ dY, int tube) {
     const int64_t n = (int64_t)a.T * a.Bp * a.Mp;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -322,13 +341,17 @@ __global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __re
     float v = 0.f;
     if (b < a.B && m < a.M && tp < a.Tp) {
         double g = 0.0;
-        if (a.use_mel) {
+        if (tube) {
+            const double rm = a.scal[(size_t)b * 8 + 6];
+            const size_t e = ((size_t)b * a.Tp + tp) * a.M + m;
+            if (rm > 0.0) g = (double)a.w_mel * ((double)a.mel2[e] - (double)a.target_mel[e]) / ((double)a.Tp * a.M * rm);
+        } else if (a.use_mel) {
             const double rm = a.scal[(size_t)b * 8 + 0];
             const size_t e = ((size_t)b * a.Tp + tp) * a.M + m;
             if (rm > 0.0) g = (double)a.w_mel * ((double)a.mel[e] - (double)a.target_mel[e]) / ((double)a.Tp * a.M * rm);
         }
         if (dmel_e) g += (double)dmel_e[((size_t)tp * a.Bp + b) * a.Mp + m];
-        if (a.cls_wb) {   // d(w_cls softplus(z))/d mel = w_cls sigmoid(z) w[m] / T'
+        if (a.cls_wb && !tube) {   // d(w_cls softplus(z))/d mel = w_cls sigmoid(z) w[m] / T'
             const double z = a.scal[(size_t)b * 8 + 5];
             g += (double)a.w_cls / (1.0 + exp(-z)) * (double)a.cls_wb[m] / (double)a.Tp;
         }
@@ -337,12 +360,12 @@ __global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __re
     dY[idx] = from_f32<AT>(v);
 }
 
-void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY) {
+void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube) {
     const int64_t n = (int64_t)a.T * a.Bp * a.Mp;
     if (dt == BF16)
-        hipLaunchKernelGGL(dy_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<bf16_t*>(dY));
+        hipLaunchKernelGGL(dy_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<bf16_t*>(dY), tube ? 1 : 0);
     else
-        hipLaunchKernelGGL(dy_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<float*>(dY));
+        hipLaunchKernelGGL(dy_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<float*>(dY), tube ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,6 +428,7 @@ __global__ void total_grad_kernel(AdamArgs a) {
         const int t = t0 + j;
         if (t < a.T) {
             double g = (double)a.dX[((size_t)t * a.Bp + b) * a.Cp + c];
+            if (a.dX2) g += (double)a.dX2[((size_t)t * a.Bp + b) * a.Cp + c];
             g += gv[j];
             g += gj[j];
             g += gl[j];
@@ -475,6 +499,20 @@ __global__ void f32_to_f64_kernel(const float* __restrict__ s, double* __restric
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = (double)s[i];
 }
+// time-major padded f32 [T][Bp][Cp] -> batch-major [B][T][C]
+__global__ void tm_to_bm_kernel(const float* __restrict__ s, int B, int T, int C, int Bp, int Cp, float* __restrict__ d) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * T * C) return;
+    const int c = (int)(idx % C), t = (int)((idx / C) % T), b = (int)(idx / ((int64_t)C * T));
+    d[idx] = s[((size_t)t * Bp + b) * Cp + c];
+}
+
+template <typename AT>
+__global__ void add2_act_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, AT* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = from_f32<AT>(a[idx] + b[idx]);
+}
+
 template <typename AT>
 __global__ void act_to_f32_kernel(const AT* __restrict__ s, float* __restrict__ d, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,6 +536,15 @@ void launch_act_to_f32(hipStream_t stream, int dt, const void* src, float* dst, 
     else
         hipLaunchKernelGGL(act_to_f32_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream,
                            static_cast<const float*>(src), dst, n);
+}
+void launch_tm_to_bm(hipStream_t stream, const float* src, int B, int T, int C, int Bp, int Cp, float* dst) {
+    hipLaunchKernelGGL(tm_to_bm_kernel, dim3(blocks_for((int64_t)B * T * C)), dim3(256), 0, stream, src, B, T, C, Bp, Cp, dst);
+}
+void launch_add2_act(hipStream_t stream, int dt, const float* a, const float* b, int64_t n, void* out) {
+    if (dt == BF16)
+        hipLaunchKernelGGL(add2_act_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, b, n, static_cast<bf16_t*>(out));
+    else
+        hipLaunchKernelGGL(add2_act_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, b, n, static_cast<float*>(out));
 }
 void launch_unpad_rows(hipStream_t stream, const float* src, int B, int S, int Sp, float* dst) {
     hipLaunchKernelGGL(unpad_rows_kernel, dim3(blocks_for(B * S)), dim3(256), 0, stream, src, B, S, Sp, dst);

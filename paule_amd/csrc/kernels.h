@@ -115,9 +115,14 @@ struct LossArgs {
     const float* mel;                // pred mel batch-major [B][Tp][M]
     const float* target_mel;         // [B][Tp][M]
     const float* sem;                // pred semvec f32 [Bp][Sp] (null if not evaluated)
+    // somatosensory feedback (paule/paule.py:624-644, :739-757): the tube path's mel prediction [B][Tp][M] and semantic vector
+    // [Bp][Sp] against the SAME targets, weights w_mel / w_sem (TUBE_MEL_WEIGHT = MEL_WEIGHT, :598-599); null = term off
+    const float* mel2;
+    const float* sem2;
     const float* target_sem;         // [B][S]
     double* dwork;                   // [B][3][T][C] velocity / jerk / local-linear correlations (kept for the gradient)
-    double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse, 5 classifier logit
+    double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse, 5 classifier logit,
+                                     // 6 tube-mel rmse, 7 tube-semvec rmse
     const float* cls_wb;             // speech classifier: [M] weights then bias, or null (term off)
     float w_cls;                     // its loss weight (0.1)
     float* loss_rows;                // [cap][B][8] internal log
@@ -128,9 +133,15 @@ void launch_loss_reduce(hipStream_t stream, const LossArgs& a);
 // writes loss_rows[*iter_slot][b][0..7]
 void launch_loss_finalize(hipStream_t stream, const LossArgs& a);
 // dsem activation [Bp][Sp] = w_sem * (sem - target) / (S * rmse_sem)   (zero rows for b >= B, zero pad)
-void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem);
+// tube = true: the same for the tube embedder's vector (a.sem2, scalar slot 7)
+void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem, bool tube = false);
 // dY activation [T][Bp][Mp]: 0.5 * (use_mel * w_mel (mel - tgt)/(N rmse) + dmel_e[t/2][b][m]) ; dmel_e f32 [Tp][Bp][Mp] or null
-void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY);
+// tube = true: the tube-mel model's output gradient: w_mel (mel2 - tgt)/(N rmse2) only (always part of the objective)
+void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube = false);
+// out (activation type) = a + b (f32), n elements: the two gradient streams that meet at the predicted tube
+void launch_add2_act(hipStream_t stream, int dt, const float* a, const float* b, int64_t n, void* out);
+// time-major padded f32 [T][Bp][Cp] -> batch-major [B][T][C]
+void launch_tm_to_bm(hipStream_t stream, const float* src, int B, int T, int C, int Bp, int Cp, float* dst);
 
 struct AdamArgs {
     int B, T, C, Bp, Cp;
@@ -138,6 +149,7 @@ struct AdamArgs {
     float w_vel, w_jerk, w_ll;
     int smiling;
     const float* dX;       // model gradient f32 time-major [T][Bp][Cp]
+    const float* dX2;      // second model gradient (the CP -> tube model of the somatosensory path), same layout, or null
     double* x;             // CP master [B][T][C]
     double* m;
     double* v;

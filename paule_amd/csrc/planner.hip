@@ -129,6 +129,19 @@ struct pl_handle {
     void* inv_in = nullptr;                     // [Tp][Bp][pad32(3M)] LSTM input
     float* inv_Y = nullptr;                     // [Tp][Bp][Cp] post_linear output
     float* inv_z[3] = {nullptr, nullptr, nullptr};   // [B][2Tp][C]: lstm_output, smoothed, scratch
+    // somatosensory feedback (pl_config.cp_tube_layers > 0): CP -> tube, tube -> mel, tube -> semantic vector
+    Model tube, tmel, temb;
+    int U = 0, Up = 0;                 // tube_dim, padded
+    void* tube_tm = nullptr;           // pred_tube, time-major activation [T][Bp][Up]: input of tmel and temb
+    float* Y2 = nullptr;               // tube-mel post_linear output [T][Bp][Mp]
+    float* mel2_bm = nullptr;          // pooled pred_tube_mel [Bp][Tp][M]
+    void* mel2_tm = nullptr;           // (written by the pooling kernel, unused)
+    void* h_last2 = nullptr;
+    float* sem2 = nullptr;             // pred_tube_semvec [Bp][Sp]
+    void *dsem2 = nullptr, *dv2 = nullptr, *dY2 = nullptr, *dYt = nullptr;
+    float *dtube_a = nullptr, *dtube_b = nullptr;   // dL/dpred_tube through the tube embedder / the tube-mel model [T][Bp][Up]
+    float* dX2 = nullptr;              // dL/dCP through the CP -> tube model [T][Bp][Cp]
+    bool tube_on() const { return tube.L > 0; }
     // embedder variants (pl_config.emb_post_size / emb_mel_blocks): head post_linear -> LeakyReLU -> output mapping, mel blocks in front
     int emb_post = 0, emb_post_p = 0, emb_blocks = 0;
     void *Wup = nullptr, *WupT = nullptr;       // output mapping [Sp][post_p] and its transpose [post_p][Sp]
@@ -645,6 +658,20 @@ bool emb_ready(pl_handle* h) {
     return true;
 }
 
+Model* model_by_id(pl_handle* h, int model_id) {
+    switch (model_id) {
+        case PL_MODEL_PRED: return &h->pred;
+        case PL_MODEL_EMBED: return &h->emb;
+        case PL_MODEL_INVERSE: return &h->inv;
+        case PL_MODEL_CP_TUBE: return &h->tube;
+        case PL_MODEL_TUBE_MEL: return &h->tmel;
+        case PL_MODEL_TUBE_EMBED: return &h->temb;
+        default: return nullptr;
+    }
+}
+
+bool tube_ready(pl_handle* h) { return h->tube.ready() && h->tmel.ready() && h->temb.ready(); }
+
 constexpr float kLeakySlope = 0.01f;   // torch.nn.LeakyReLU() default (paule/models.py:374, :425)
 
 // mel_bm: the embedder's input batch-major [B][Tp][M] f32 (read by the mel blocks only); h->mel_tm holds the same time-major
@@ -707,6 +734,40 @@ void emb_backward(pl_handle* h, hipStream_t st) {
     }
 }
 
+// somatosensory path, forward (paule/paule.py:916-919, :926-929): pred_tube = cp_tube_model(cp), pred_tube_mel =
+// tube_mel_model(pred_tube) (pooled by two), pred_tube_semvec = tube_embedder(pred_tube, T)
+void tube_heads_forward(pl_handle* h, hipStream_t st);
+void tube_forward(pl_handle* h, hipStream_t st) {
+    Model& u = h->tube;
+    model_forward(h, st, u, h->X0);
+    launch_gemm_nt(st, h->dt, false, u.layers[u.L - 1].h, u.Hp, u.Wlin, u.Hp, u.blin, h->tube_tm, h->Up, h->T * h->Bp, h->Up, u.Hp);
+    tube_heads_forward(h, st);
+}
+// tube (h->tube_tm) -> pred_tube_mel (h->mel2_bm), pred_tube_semvec (h->sem2)
+void tube_heads_forward(pl_handle* h, hipStream_t st) {
+    Model &m = h->tmel, &e = h->temb;
+    model_forward(h, st, m, h->tube_tm);
+    launch_gemm_nt(st, h->dt, true, m.layers[m.L - 1].h, m.Hp, m.Wlin, m.Hp, m.blin, h->Y2, h->Mp, h->T * h->Bp, h->Mp, m.Hp);
+    launch_pool_mel(st, h->dt, h->Y2, h->B, h->T, h->M, h->Bp, h->Mp, h->mel2_bm, h->mel2_tm);
+    model_forward(h, st, e, h->tube_tm);
+    launch_gather_last(st, h->dt, e.layers[e.L - 1].h, nullptr, h->B, e.Tl, h->Bp, e.Hp, h->h_last2);
+    launch_gemm_nt(st, h->dt, true, h->h_last2, e.Hp, e.Wlin, e.Hp, e.blin, h->sem2, h->Sp, h->Bp, h->Sp, e.Hp);
+}
+
+// ... and backward: the two tube terms' gradients meet at pred_tube and go through the CP -> tube model into dX2
+void tube_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
+    Model &u = h->tube, &m = h->tmel, &e = h->temb;
+    launch_dsem(st, h->dt, la, h->dsem2, true);
+    launch_gemm_nt(st, h->dt, false, h->dsem2, h->Sp, e.WlinT, h->Sp, nullptr, h->dv2, e.Hp, h->Bp, e.Hp, h->Sp);
+    model_backward(h, st, e, h->dv2, h->dtube_a);
+    launch_dy(st, h->dt, la, nullptr, h->dY2, true);
+    launch_gemm_nt(st, h->dt, false, h->dY2, h->Mp, m.WlinT, h->Mp, nullptr, m.dh_ext, m.Hp, h->T * h->Bp, m.Hp, h->Mp);
+    model_backward(h, st, m, nullptr, h->dtube_b);
+    launch_add2_act(st, h->dt, h->dtube_a, h->dtube_b, (int64_t)h->T * h->Bp * h->Up, h->dYt);
+    launch_gemm_nt(st, h->dt, false, h->dYt, h->Up, u.WlinT, h->Up, nullptr, u.dh_ext, u.Hp, h->T * h->Bp, u.Hp, h->Up);
+    model_backward(h, st, u, nullptr, h->dX2);
+}
+
 LossArgs loss_args(pl_handle* h, bool with_sem) {
     LossArgs a{};
     a.B = h->B; a.T = h->T; a.Tp = h->Tp; a.C = h->C; a.M = h->M; a.S = h->S;
@@ -716,6 +777,8 @@ LossArgs loss_args(pl_handle* h, bool with_sem) {
     a.use_sem = with_sem ? 1 : 0;
     a.x = h->x; a.mel = h->mel_bm; a.target_mel = h->target_mel;
     a.sem = with_sem ? h->sem : nullptr;
+    a.mel2 = h->tube_on() ? h->mel2_bm : nullptr;
+    a.sem2 = h->tube_on() ? h->sem2 : nullptr;
     a.target_sem = h->target_sem;
     a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1; a.dwork = h->dwork;
     a.cls_wb = h->cls_on ? h->cls_wb : nullptr; a.w_cls = h->w_cls;
@@ -729,7 +792,7 @@ AdamArgs adam_args(pl_handle* h) {
     a.clamp_lo = h->cfg.clamp_lo; a.clamp_hi = h->cfg.clamp_hi;
     a.w_vel = h->cfg.w_vel; a.w_jerk = h->cfg.w_jerk; a.w_ll = h->cfg.w_ll;
     a.smiling = h->cfg.smiling;
-    a.dX = h->dX; a.x = h->x; a.m = h->m; a.v = h->v; a.grad = h->grad; a.dwork = h->dwork;
+    a.dX = h->dX; a.dX2 = h->tube_on() ? h->dX2 : nullptr; a.x = h->x; a.m = h->m; a.v = h->v; a.grad = h->grad; a.dwork = h->dwork;
     a.step_count = h->counters; a.iter_slot = h->counters + 1;
     a.past = h->past_len > 0 ? h->past : nullptr;
     a.past_len = h->past_len; a.past_per_utt = h->past_per_utt;
@@ -744,6 +807,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
     pred_forward(h, st);
     if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
+    if (h->tube_on()) tube_forward(h, st);
     LossArgs la = loss_args(h, with_sem);
     launch_loss_reduce(st, la);
     launch_loss_finalize(st, la);
@@ -758,6 +822,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     // dL/dh_top(t) = dY_t * W_p
     launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, h->T * h->Bp, p.Hp, h->Mp);
     model_backward(h, st, p, nullptr, h->dX);
+    if (h->tube_on()) tube_backward(h, st, la);
     AdamArgs aa = adam_args(h);
     launch_total_grad(st, aa);
     launch_adam_update(st, aa);
@@ -854,6 +919,15 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if (cfg->emb_post_size < 0 || cfg->emb_mel_blocks < 0 || cfg->emb_mel_blocks > 16 ||
         (cfg->emb_layers == 0 && (cfg->emb_post_size > 0 || cfg->emb_mel_blocks > 0)))
         return fail(PL_ERR_INVALID, "pl_create: bad embedder head / mel block shape");
+    if (cfg->cp_tube_layers < 0 || cfg->tube_mel_layers < 0 || cfg->tube_emb_layers < 0) return fail(PL_ERR_INVALID, "pl_create: bad tube model shape");
+    if (cfg->cp_tube_layers > 0) {
+        if (cfg->tube_dim < 1 || cfg->cp_tube_hidden < 1 || cfg->tube_mel_layers < 1 || cfg->tube_mel_hidden < 1 || cfg->tube_emb_layers < 1 ||
+            cfg->tube_emb_hidden < 1)
+            return fail(PL_ERR_INVALID, "pl_create: somatosensory feedback needs all three tube models (cp_tube, tube_mel, tube_emb)");
+        if (cfg->emb_layers == 0 || cfg->objective == PL_OBJ_ACOUSTIC)
+            return fail(PL_ERR_INVALID, "pl_create: somatosensory feedback runs with the objectives acoustic_semvec and semvec only (the "
+                                        "reference's acoustic criterion fails there, paule/paule.py:692)");
+    }
     if (cfg->emb_mel_blocks > 0 && cfg->mel_dim % 3 != 0) return fail(PL_ERR_INVALID, "pl_create: mel blocks need mel_dim divisible by 3");
     if (cfg->dtype != PL_F32 && cfg->dtype != PL_BF16) return fail(PL_ERR_INVALID, "pl_create: dtype must be PL_F32 or PL_BF16");
     if (cfg->objective < PL_OBJ_ACOUSTIC || cfg->objective > PL_OBJ_SEMVEC)
@@ -893,6 +967,28 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         hmax = hmax > h->emb.Hp ? hmax : h->emb.Hp;
     }
     const size_t Bp = h->Bp, T = h->T, Tp = h->Tp, B = h->B;
+    if (cfg->cp_tube_layers > 0) {
+        h->U = cfg->tube_dim;
+        h->Up = pad32(cfg->tube_dim);
+        if ((rc = alloc_model(h, h->tube, cfg->cp_tube_layers, cfg->cp_tube_hidden, h->C, h->U, h->T))) return bail(rc);
+        if ((rc = alloc_model(h, h->tmel, cfg->tube_mel_layers, cfg->tube_mel_hidden, h->U, h->M, h->T))) return bail(rc);
+        if ((rc = alloc_model(h, h->temb, cfg->tube_emb_layers, cfg->tube_emb_hidden, h->U, h->S, h->T))) return bail(rc);
+        for (Model* md : {&h->tube, &h->tmel, &h->temb}) hmax = hmax > md->Hp ? hmax : md->Hp;
+        const size_t Up = h->Up;
+        if ((rc = alloc_act(h, &h->tube_tm, T * Bp * Up))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->Y2, T * Bp * h->Mp))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->mel2_bm, Bp * Tp * h->M))) return bail(rc);
+        if ((rc = alloc_act(h, &h->mel2_tm, Tp * Bp * h->Mp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->h_last2, Bp * h->temb.Hp))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->sem2, Bp * h->Sp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->dsem2, Bp * h->Sp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->dv2, Bp * h->temb.Hp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->dY2, T * Bp * h->Mp))) return bail(rc);
+        if ((rc = alloc_act(h, &h->dYt, T * Bp * Up))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->dtube_a, T * Bp * Up))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->dtube_b, T * Bp * Up))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->dX2, T * Bp * h->Cp))) return bail(rc);
+    }
     if (cfg->inv_layers > 0) {
         if ((rc = alloc_model(h, h->inv, cfg->inv_layers, cfg->inv_hidden, 3 * h->M, h->C, h->Tp))) return bail(rc);
         hmax = hmax > h->inv.Hp ? hmax : h->inv.Hp;
@@ -977,25 +1073,27 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST16")) h->xcd_fast16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_STASH_LDS")) h->stash_lds = std::atoi(z) != 0;
         if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
-            size_t xb = lstm_sweep_f32_supported(h->pred.Hp) ? lstm_f32_exchange_bytes(h->pred.Hp, h->Bp) : 0;
-            if (cfg->emb_layers > 0 && lstm_sweep_f32_supported(h->emb.Hp)) {
-                const size_t xe = lstm_f32_exchange_bytes(h->emb.Hp, h->Bp);
-                xb = xb > xe ? xb : xe;
-            }
+            size_t xb = 0;
+            for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb})
+                if (md->L > 0 && lstm_sweep_f32_supported(md->Hp)) {
+                    const size_t xe = lstm_f32_exchange_bytes(md->Hp, h->Bp);
+                    xb = xb > xe ? xb : xe;
+                }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
         }
         if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1) {
-            size_t xb = lstm_sweep_supported(h->dt, h->pred.Hp) ? lstm_rs_exchange_bytes(h->pred.Hp, h->Bp) : 0;
-            if (cfg->emb_layers > 0 && lstm_sweep_supported(h->dt, h->emb.Hp)) {
-                const size_t xe = lstm_rs_exchange_bytes(h->emb.Hp, h->Bp);
-                xb = xb > xe ? xb : xe;
-            }
+            size_t xb = 0;
+            for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb})
+                if (md->L > 0 && lstm_sweep_supported(h->dt, md->Hp)) {
+                    const size_t xe = lstm_rs_exchange_bytes(md->Hp, h->Bp);
+                    xb = xb > xe ? xb : xe;
+                }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
         }
         if (const char* z = std::getenv("PAULE_HIP_WAVEFRONT")) h->wavefront = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
         if (h->wavefront > 0 && h->use_sweep) {
-            for (Model* md : {&h->pred, &h->emb}) {
+            for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
                 if (md->L < 2 || wavefront_depth(h, *md) < 2) continue;
                 const size_t xb = h->dt == F32 ? (lstm_sweep_f32_supported(md->Hp) ? lstm_f32_exchange_bytes(md->Hp, h->Bp) : 0)
                                                : (lstm_sweep_supported(h->dt, md->Hp) ? lstm_rs_exchange_bytes(md->Hp, h->Bp) : 0);
@@ -1009,7 +1107,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             h->wf_on = true;
             // streams and events of an iteration up front (none is created while a capture is running)
             size_t n_streams = 0, n_events = 0;
-            for (Model* md : {&h->pred, &h->emb})
+            for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb})
                 if (md->L >= 2 && md->layers[0].carry_f) {
                     n_streams += 2 * (size_t)(md->L - 1);
                     n_events += 2 * (size_t)md->L * (size_t)(h->wavefront < 32 ? h->wavefront : 32);
@@ -1025,10 +1123,12 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         int pmax = h->pred.Hp / slice;
         if (cfg->emb_layers > 0 && h->emb.Hp / slice > pmax) pmax = h->emb.Hp / slice;
         if (cfg->inv_layers > 0 && h->inv.Hp / slice > pmax) pmax = h->inv.Hp / slice;
+        for (Model* md : {&h->tube, &h->tmel, &h->temb})
+            if (md->L > 0 && md->Hp / slice > pmax) pmax = md->Hp / slice;
         h->flag_stride = (pmax + 15) / 16 * 16;
         const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
-        h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers);   // forward + backward sweep of every layer of an iteration
+        h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers);   // forward + backward sweep of every layer of an iteration
         if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
 #ifdef PL_STAMPS
@@ -1058,8 +1158,8 @@ int pl_destroy(pl_handle* h) {
 int pl_set_lstm_weights(pl_handle* h, int model_id, int layer, const float* w_ih, const float* w_hh, const float* b_ih,
                         const float* b_hh) {
     if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: NULL argument");
-    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_TUBE_EMBED) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: bad model_id");
+    Model& md = *model_by_id(h, model_id);
     if (layer < 0 || layer >= md.L) return fail(PL_ERR_INVALID, "pl_set_lstm_weights: layer out of range for this model");
     DeviceGuard guard(h->cfg.device);
     LstmLayer& ly = md.layers[layer];
@@ -1082,8 +1182,8 @@ int pl_set_lstm_weights(pl_handle* h, int model_id, int layer, const float* w_ih
 
 int pl_set_linear(pl_handle* h, int model_id, const float* w, const float* b) {
     if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_set_linear: NULL argument");
-    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_set_linear: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_TUBE_EMBED) return fail(PL_ERR_INVALID, "pl_set_linear: bad model_id");
+    Model& md = *model_by_id(h, model_id);
     if (md.L == 0) return fail(PL_ERR_INVALID, "pl_set_linear: this handle has no such model");
     DeviceGuard guard(h->cfg.device);
     hipStream_t st = h->stream;
@@ -1175,6 +1275,7 @@ int pl_reset_optimizer(pl_handle* h) {
 static int check_ready(pl_handle* h, bool need_sem, const char* who) {
     if (!h->pred.ready()) return fail(PL_ERR_STATE, std::string(who) + ": predictive-model weights are not set");
     if (need_sem && !emb_ready(h)) return fail(PL_ERR_STATE, std::string(who) + ": embedder weights are not set");
+    if (h->tube_on() && !tube_ready(h)) return fail(PL_ERR_STATE, std::string(who) + ": weights of the somatosensory models are not set");
     if (!h->have_cp) return fail(PL_ERR_STATE, std::string(who) + ": pl_set_cp has not been called");
     return PL_OK;
 }
@@ -1260,6 +1361,41 @@ int pl_get_pred(pl_handle* h, float* pred_mel_out, float* pred_semvec_out) {
         emb_forward(h, st, nullptr, h->mel_bm);
         launch_unpad_rows(st, h->sem, h->B, h->S, h->Sp, pred_semvec_out);
     }
+    return check_launch();
+}
+
+int pl_get_tube_pred(pl_handle* h, float* pred_tube_out, float* pred_tube_mel_out, float* pred_tube_semvec_out) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_get_tube_pred: NULL handle");
+    if (!h->tube_on()) return fail(PL_ERR_INVALID, "pl_get_tube_pred: the handle has no somatosensory models (pl_config.cp_tube_layers)");
+    int rc = check_ready(h, false, "pl_get_tube_pred");
+    if (rc) return rc;
+    DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
+    hipStream_t st = h->stream;
+    launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
+    tube_forward(h, st);
+    if (pred_tube_out) {   // time-major activation [T][Bp][Up] -> [B][T][U] f32 (Y2 is free again: reuse it as the f32 staging)
+        launch_act_to_f32(st, h->dt, h->tube_tm, h->Y2, (int64_t)h->T * h->Bp * h->Up);
+        launch_tm_to_bm(st, h->Y2, h->B, h->T, h->U, h->Bp, h->Up, pred_tube_out);
+    }
+    if (pred_tube_mel_out)
+        PL_HIP(hipMemcpyAsync(pred_tube_mel_out, h->mel2_bm, sizeof(float) * h->B * h->Tp * h->M, hipMemcpyDeviceToDevice, st));
+    if (pred_tube_semvec_out) launch_unpad_rows(st, h->sem2, h->B, h->S, h->Sp, pred_tube_semvec_out);
+    return check_launch();
+}
+
+int pl_embed_tube(pl_handle* h, const float* tube, float* tube_mel_out, float* tube_semvec_out) {
+    if (!h || !tube) return fail(PL_ERR_INVALID, "pl_embed_tube: NULL argument");
+    if (!h->tube_on()) return fail(PL_ERR_INVALID, "pl_embed_tube: the handle has no somatosensory models (pl_config.cp_tube_layers)");
+    if (!tube_ready(h)) return fail(PL_ERR_STATE, "pl_embed_tube: weights of the somatosensory models are not set");
+    DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
+    hipStream_t st = h->stream;
+    launch_pack_mel(st, h->dt, tube, h->B, h->T, h->U, h->tube_tm, h->Bp, h->Up);
+    tube_heads_forward(h, st);
+    if (tube_mel_out)
+        PL_HIP(hipMemcpyAsync(tube_mel_out, h->mel2_bm, sizeof(float) * h->B * h->Tp * h->M, hipMemcpyDeviceToDevice, st));
+    if (tube_semvec_out) launch_unpad_rows(st, h->sem2, h->B, h->S, h->Sp, tube_semvec_out);
     return check_launch();
 }
 
@@ -1421,8 +1557,8 @@ int pl_set_pred_optimizer_step(pl_handle* h, int64_t step) {
 
 int pl_get_lstm_weights(pl_handle* h, int model_id, int layer, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
     if (!h || !w_ih || !w_hh || !b_ih || !b_hh) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: NULL argument");
-    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_TUBE_EMBED) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: bad model_id");
+    Model& md = *model_by_id(h, model_id);
     if (layer < 0 || layer >= md.L) return fail(PL_ERR_INVALID, "pl_get_lstm_weights: layer out of range for this model");
     LstmLayer& ly = md.layers[layer];
     if (!ly.set) return fail(PL_ERR_STATE, "pl_get_lstm_weights: the layer's weights are not set");
@@ -1439,8 +1575,8 @@ int pl_get_lstm_weights(pl_handle* h, int model_id, int layer, float* w_ih, floa
 
 int pl_get_linear(pl_handle* h, int model_id, float* w, float* b) {
     if (!h || !w || !b) return fail(PL_ERR_INVALID, "pl_get_linear: NULL argument");
-    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_INVERSE) return fail(PL_ERR_INVALID, "pl_get_linear: bad model_id");
-    Model& md = model_id == PL_MODEL_PRED ? h->pred : model_id == PL_MODEL_EMBED ? h->emb : h->inv;
+    if (model_id < PL_MODEL_PRED || model_id > PL_MODEL_TUBE_EMBED) return fail(PL_ERR_INVALID, "pl_get_linear: bad model_id");
+    Model& md = *model_by_id(h, model_id);
     if (md.L == 0 || !md.lin_set) return fail(PL_ERR_STATE, "pl_get_linear: the output layer's weights are not set");
     DeviceGuard guard(h->cfg.device);
     launch_f64_to_f32(h->stream, md.p_wlin.x, w, (int64_t)md.p_wlin.n);
@@ -1676,6 +1812,10 @@ double pl_flops_per_iteration(const pl_handle* h) {
     if (h->need_emb_in_step())
         f += lstm_flops_per_step(h->emb.L, h->emb.H, h->M) * h->Tp +
              (h->emb_post > 0 ? 2.0 * h->emb_post * (h->emb.H + h->S) : 2.0 * h->emb.H * h->S);
+    if (h->tube_on())
+        f += (lstm_flops_per_step(h->tube.L, h->tube.H, h->C) + 2.0 * h->tube.H * h->U) * h->T +
+             (lstm_flops_per_step(h->tmel.L, h->tmel.H, h->U) + 2.0 * h->tmel.H * h->M) * h->T +
+             lstm_flops_per_step(h->temb.L, h->temb.H, h->U) * h->T + 2.0 * h->temb.H * h->S;
     return 2.0 * f * h->B;
 }
 

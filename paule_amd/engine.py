@@ -40,7 +40,7 @@ class HipPlanner:
 
     def __init__(self, pred_model, embedder=None, *, batch, n_frames, objective="acoustic", dtype="f32",
                  lr=0.01, betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False,
-                 weights=None, device=None, use_graph=True, inv_model=None):
+                 weights=None, device=None, use_graph=True, inv_model=None, tube_models=None):
         self.lib = _capi.load_library()          # raises HipLibraryError when the extension is missing
         if not torch.cuda.is_available():
             raise _capi.HipLibraryError("no HIP device visible: paule_amd runs on MI355X only (no CPU fallback)")
@@ -98,6 +98,30 @@ class HipPlanner:
                     raise NotImplementedError("only the default filter sizes (mel 3 / time 5) are supported")
             cfg.inv_layers, cfg.inv_hidden, cfg.inv_mel_blocks, cfg.inv_res_blocks = lay_i, hid_i, n_mel, n_res
             self._inv_blocks = (n_mel, n_res)
+        # somatosensory feedback (paule/paule.py:227-273): (cp_tube_model, tube_mel_model, tube_embedder)
+        self.has_tube = tube_models is not None
+        if self.has_tube:
+            if emb_sd is None or objective == "acoustic":
+                raise ValueError("somatosensory feedback needs an embedder and the objective 'acoustic_semvec' or 'semvec' (the "
+                                 "reference's acoustic criterion fails there, paule/paule.py:692)")
+            tube_sds = [_state_dict(m) for m in tube_models]
+            if len(tube_sds) != 3:
+                raise ValueError("tube_models has to be (cp_tube_model, tube_mel_model, tube_embedder)")
+            for m in tube_models:
+                if getattr(getattr(m, "lstm", None), "dropout", 0):
+                    raise NotImplementedError("a tube model with dropout > 0 makes the planning loss random in the reference (it runs in "
+                                              ".train() mode inside the loop, paule/paule.py:927); only dropout 0 is supported")
+            (in_u, hid_u, lay_u), (in_m, hid_m, lay_m), (in_e2, hid_e2, lay_e2) = [_lstm_dims(sd) for sd in tube_sds]
+            self.U = int(tube_sds[0]["post_linear.weight"].shape[0])
+            if in_u != self.C or in_m != self.U or in_e2 != self.U or int(tube_sds[1]["post_linear.weight"].shape[0]) != self.M:
+                raise ValueError("tube models have to map cp_dim -> tube_dim, tube_dim -> mel_dim and tube_dim -> sem_dim")
+            if "linear_mapping.weight" not in tube_sds[2] or "post_linear.weight" in tube_sds[2] or \
+                    int(tube_sds[2]["linear_mapping.weight"].shape[0]) != self.S:
+                raise ValueError("the tube embedder has to be an EmbeddingModel(post_upsampling_size=0) with sem_dim outputs")
+            cfg.tube_dim = self.U
+            cfg.cp_tube_layers, cfg.cp_tube_hidden = lay_u, hid_u
+            cfg.tube_mel_layers, cfg.tube_mel_hidden = lay_m, hid_m
+            cfg.tube_emb_layers, cfg.tube_emb_hidden = lay_e2, hid_e2
         cfg.dtype, cfg.objective = DTYPES[dtype], _capi.PL_OBJ[objective]
         if weights:
             for k in ("w_mel", "w_sem", "w_vel", "w_jerk", "w_ll"):
@@ -115,6 +139,8 @@ class HipPlanner:
         if emb_sd is not None:
             self._dims.update({"embedder": (lay_e, hid_e, "post_linear" if self._emb_post else "linear_mapping"), "embedder_in": self.M})
         self.set_weights(pred_sd, emb_sd)
+        if self.has_tube:
+            self.set_tube_weights(*tube_sds)
         if inv_sd is not None:
             self._dims.update({"inverse": (lay_i, hid_i, "post_linear"), "inverse_in": 3 * self.M})
             self.set_inverse_weights(inv_sd)
@@ -163,6 +189,41 @@ class HipPlanner:
                         key = f"MelBlocks.{i}.ConvLayers.{j}"
                         w, b = self._dev(sd[key + ".weight"]), self._dev(sd[key + ".bias"])
                         self._call(self.lib.pl_set_embedder_conv, i, j, w.data_ptr(), b.data_ptr())
+
+    def set_tube_weights(self, cp_tube_model=None, tube_mel_model=None, tube_embedder=None):
+        for model_id, sd, lin in ((_capi.PL_MODEL_CP_TUBE, _state_dict(cp_tube_model), "post_linear"),
+                                  (_capi.PL_MODEL_TUBE_MEL, _state_dict(tube_mel_model), "post_linear"),
+                                  (_capi.PL_MODEL_TUBE_EMBED, _state_dict(tube_embedder), "linear_mapping")):
+            if sd is None:
+                continue
+            _, _, n_layers = _lstm_dims(sd)
+            for l in range(n_layers):
+                ts = [self._dev(sd[f"lstm.{k}_l{l}"]) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                self._call(self.lib.pl_set_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
+            w, b = self._dev(sd[f"{lin}.weight"]), self._dev(sd[f"{lin}.bias"])
+            self._call(self.lib.pl_set_linear, model_id, w.data_ptr(), b.data_ptr())
+
+    def get_tube_pred(self):
+        """pred_tube (B, T, tube_dim), pred_tube_mel (B, T/2, mel_dim), pred_tube_semvec (B, sem_dim) at the current CP
+        (paule/paule.py:916-919, :926-929)."""
+        if not self.has_tube:
+            raise ValueError("this engine was built without tube_models=")
+        tube = torch.empty((self.B, self.T, self.U), dtype=torch.float32, device=self.device)
+        mel = torch.empty((self.B, self.Tp, self.M), dtype=torch.float32, device=self.device)
+        sem = torch.empty((self.B, self.S), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_get_tube_pred, tube.data_ptr(), mel.data_ptr(), sem.data_ptr())
+        return tube, mel, sem
+
+    def embed_tube(self, tube):
+        """``tube_mel_model(tube)``, ``tube_embedder(tube, T)`` for a tube (B, T, tube_dim), e.g. the one extracted from the
+        synthesis (paule/paule.py:1084, :1147-1150)."""
+        if not self.has_tube:
+            raise ValueError("this engine was built without tube_models=")
+        t = self._dev(tube, (self.B, self.T, self.U))
+        mel = torch.empty((self.B, self.Tp, self.M), dtype=torch.float32, device=self.device)
+        sem = torch.empty((self.B, self.S), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_embed_tube, t.data_ptr(), mel.data_ptr(), sem.data_ptr())
+        return mel, sem
 
     # ---- inverse model: initial CP from the target mel (paule/paule.py:550-556) ------------------
     def set_inverse_weights(self, inv_model):

@@ -47,6 +47,22 @@ PlanningResultsWithSpeechClassifier = namedtuple(
     "prod_speech_classifier_loss_steps, cp_steps, pred_semvec_steps, prod_semvec_steps, grad_steps, sig_steps, "
     "prod_mel_steps, pred_mel_steps, pred_model_loss, inv_model_loss")   # paule/paule.py:58
 
+PlanningResultsWithSomatosensory = namedtuple(
+    "PlanningResultsWithSomatosensory",
+    "planned_cp, initial_cp, initial_sig, initial_sr, initial_prod_mel,initial_pred_mel, initial_prod_tube, initial_pred_tube, "
+    "initial_prod_tube_mel, initial_pred_tube_mel, target_sig, target_sr, target_mel, prod_sig, prod_sr, prod_mel, pred_mel, "
+    "prod_tube, pred_tube, prod_tube_mel, pred_tube_mel, initial_prod_semvec, initial_pred_semvec, initial_prod_tube_semvec, "
+    "initial_pred_tube_semvec, prod_semvec, pred_semvec, prod_tube_semvec, pred_tube_semvec, prod_loss_steps, planned_loss_steps, "
+    "planned_mel_loss_steps, vel_loss_steps, jerk_loss_steps, pred_semvec_loss_steps, prod_semvec_loss_steps, prod_tube_loss_steps, "
+    "pred_tube_mel_loss_steps,prod_tube_mel_loss_steps, pred_tube_semvec_loss_steps, prod_tube_semvec_loss_steps, cp_steps, "
+    "pred_semvec_steps, prod_semvec_steps, grad_steps, sig_steps, prod_mel_steps, pred_mel_steps, prod_tube_steps, pred_tube_steps, "
+    "prod_tube_mel_steps, pred_tube_mel_steps, prod_tube_semvec_steps, pred_tube_semvec_steps, pred_model_loss, inv_model_loss, "
+    "tube_model_loss, tube_mel_model_loss")   # paule/paule.py:59
+
+BestSynthesisSomatosensory = namedtuple(
+    "BestSynthesisSomatosensory", "tube_loss, tube_mel_loss, tube_semvec_loss, planned_cp, prod_sig, prod_tube, pred_tube, "
+    "prod_tube_mel, pred_tube_mel, prod_tube_semvec, pred_tube_semvec")   # paule/paule.py:64
+
 BestSynthesisAcoustic = namedtuple("BestSynthesisAcoustic", "mel_loss, planned_cp, prod_sig, prod_mel, pred_mel")
 BestSynthesisSemantic = namedtuple("BestSynthesisSemantic", "semvec_loss, planned_cp, prod_sig, prod_semvec, pred_semvec")
 
@@ -58,7 +74,7 @@ SEMANTIC_WEIGHT = 10.0
 SPEECH_CLASSIFIER_WEIGHT = 0.1
 LOCAL_LINEAR_WEIGHT = 100_000
 
-_COL = dict(total=0, mel=1, semvec=2, vel=3, jerk=4, ll=5, cls=6)
+_COL = dict(total=0, mel=1, semvec=2, vel=3, jerk=4, ll=5, cls=6, tube_mel=6, tube_semvec=7)
 
 
 def _default_planner_factory(pred_model, embedder, **kw):
@@ -114,14 +130,30 @@ class Paule():
                  use_speech_classifier=False, speech_classifier=None,
                  speech_classifier_optimizer=None,
                  compute_dtype="f32", synthesizer=None, mel_extractor=None, planner_factory=None,
-                 continue_learning_hook=None):
+                 continue_learning_hook=None, tube_extractor=None):
         self.device = device
         self.smiling = smiling
         if use_somatosensory_feedback and use_speech_classifier:   # paule/paule.py:117-118
             raise NotImplementedError("at the moment you have to choose either to use `use_somatosenrosry_feedback=True` OR to use `use_speech_classifier=True` or none")
-        if use_somatosensory_feedback:
-            raise NotImplementedError("use_somatosensory_feedback is not on the MI355X planning path (SURVEY.md 8f rank 4)")
-        self.use_somatosensory_feedback = False
+        # somatosensory feedback (paule/paule.py:227-273, :916-929): cp -> tube, tube -> mel, tube -> semantic vector beside the
+        # acoustic path.  The three models have to be given: the reference's default tube embedder is built with dropout 0.7 and
+        # switched to .train() inside the loop (:266, :927), which makes its planning loss random; the device path runs a tube
+        # embedder without dropout (EmbeddingModel(input_size=10, ..., dropout=0) with the same weights is deterministic).
+        self.use_somatosensory_feedback = bool(use_somatosensory_feedback)
+        self.cp_tube_model, self.tube_mel_model, self.tube_embedder = cp_tube_model, tube_mel_model, tube_embedder
+        self.tube_optimizer, self.tube_mel_optimizer = tube_optimizer, tube_mel_optimizer
+        # tube_extractor(cp (B, T, 30) normalised) -> normalised tube (B, T, 10): the reference's
+        # speak_and_extract_tube_information + get_area_info_within_oral_cavity + normalize_tube (paule/paule.py:1070-1078, VTL)
+        self.tube_extractor = tube_extractor
+        self.best_synthesis_somatosensory = None
+        if self.use_somatosensory_feedback:
+            if cp_tube_model is None or tube_mel_model is None or tube_embedder is None:
+                raise NotImplementedError("use_somatosensory_feedback=True needs cp_tube_model=, tube_mel_model= and tube_embedder= (the "
+                                          "reference's default tube embedder has dropout 0.7 and runs in .train() mode inside the "
+                                          "loop: its loss is random; pass one built with dropout=0)")
+            for m in (cp_tube_model, tube_mel_model, tube_embedder):
+                if getattr(getattr(m, "lstm", None), "dropout", 0):
+                    raise NotImplementedError("tube models with dropout > 0 are not supported (random planning loss in the reference)")
         self.use_speech_classifier = use_speech_classifier
         # default models: the reference loads its pretrained weights from paule/pretrained_models/ next to the module
         # (paule/paule.py:121-127, :146-150, :167-171, :215-222; a 200 MB download, paule/util.py:936-955).  Same file names, looked
@@ -422,6 +454,14 @@ class Paule():
 
         # ---- initial cp (paule/paule.py:550-573) ----
         planner = None
+        tube_kw = {}
+        if self.use_somatosensory_feedback:
+            if objective == "acoustic":
+                raise NotImplementedError("use_somatosensory_feedback with objective='acoustic': the reference's criterion fails there "
+                                          "(unassigned pred_tube_semvec, paule/paule.py:692); use 'acoustic_semvec' or 'semvec'")
+            if continue_learning_tube:
+                raise NotImplementedError("continue_learning_tube is not on the MI355X planning path")
+            tube_kw = dict(tube_models=(self.cp_tube_model, self.tube_mel_model, self.tube_embedder))
         if initial_cp is None:
             if initialize_from == "acoustic":
                 if self.inv_model is None:
@@ -435,7 +475,7 @@ class Paule():
                     n_past = 0 if past_cp is None else np.asarray(_np(past_cp)).shape[0]
                     planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=n_past + 2 * target_mel.shape[1],
                                                     objective=objective, dtype=self.compute_dtype, lr=learning_rate_planning,
-                                                    smiling=self.smiling, device=self.device, inv_model=inv_sd)
+                                                    smiling=self.smiling, device=self.device, inv_model=inv_sd, **tube_kw)
                     initial_cp = _np(planner.inverse_forward(target_mel, clip=True))
                 else:
                     with torch.no_grad():
@@ -485,7 +525,7 @@ class Paule():
         if planner is None:
             planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=T, objective=objective,
                                             dtype=self.compute_dtype, lr=learning_rate_planning, smiling=self.smiling,
-                                            device=self.device)
+                                            device=self.device, **tube_kw)
         self.planner = planner
         if continue_learning and hasattr(planner, "set_pred_optimizer_state"):   # the optimiser outlives a plan (paule/paule.py:284-287)
             planner.set_pred_optimizer_state(self.pred_optimizer.state_dict())
@@ -525,6 +565,22 @@ class Paule():
         if initial_prod_mel is not None:
             initial_prod_semvec = _np(planner.embed_mel(initial_prod_mel))
 
+        soma = self.use_somatosensory_feedback
+        initial_pred_tube = initial_pred_tube_mel = initial_pred_tube_semvec = None
+        initial_prod_tube = initial_prod_tube_mel = initial_prod_tube_semvec = None
+        if soma:                                        # paule/paule.py:826-862
+            initial_pred_tube, initial_pred_tube_mel, initial_pred_tube_semvec = [_np(a) for a in planner.get_tube_pred()]
+            if self.tube_extractor is not None:
+                initial_prod_tube = np.asarray(self.tube_extractor(initial_cp), dtype=np.float64).reshape(initial_pred_tube.shape)
+                initial_prod_tube_mel, initial_prod_tube_semvec = [_np(a) for a in planner.embed_tube(initial_prod_tube)]
+            self.best_synthesis_somatosensory = BestSynthesisSomatosensory(
+                np.inf, np.inf, np.inf, initial_cp, initial_sig, initial_prod_tube, initial_pred_tube, initial_prod_tube_mel,
+                initial_pred_tube_mel, initial_prod_tube_semvec, initial_pred_tube_semvec)
+        prod_tube_loss_steps, pred_tube_mel_loss_steps, prod_tube_mel_loss_steps = [], [], []
+        pred_tube_semvec_loss_steps, prod_tube_semvec_loss_steps = [], []
+        prod_tube_steps, pred_tube_steps, prod_tube_mel_steps, pred_tube_mel_steps = [], [], [], []
+        prod_tube_semvec_steps, pred_tube_semvec_steps, tube_model_loss, tube_mel_model_loss = [], [], [], []
+        prod_tube = prod_tube_mel = prod_tube_semvec = None
         self.best_synthesis_acoustic = BestSynthesisAcoustic(np.inf, initial_cp, initial_sig, initial_prod_mel, initial_pred_mel)
         self.best_synthesis_semantic = BestSynthesisSemantic(np.inf, initial_cp, initial_sig, initial_prod_semvec, initial_pred_semvec)
 
@@ -552,6 +608,9 @@ class Paule():
                     print("Semvec Loss: ", _scalar_or_vec(row[:, _COL["semvec"]]))
                 if self.use_speech_classifier:
                     print("Speech Classifier Loss: ", _scalar_or_vec(row[:, _COL["cls"]]))
+                if self.use_somatosensory_feedback:
+                    print("Tube Mel Loss: ", _scalar_or_vec(row[:, _COL["tube_mel"]]))
+                    print("Tube Semvec Loss: ", _scalar_or_vec(row[:, _COL["tube_semvec"]]))
 
         def run(n, first_ii):
             """n plain iterations (no log step inside)"""
@@ -569,6 +628,8 @@ class Paule():
         for ii_outer in range(n_outer):                                        # paule/paule.py:894
             pred_mel_steps_ii, prod_mel_steps_ii, cp_steps_ii = [], [], []
             pred_semvec_steps_ii, prod_semvec_steps_ii = [], []
+            pred_tube_steps_ii, prod_tube_steps_ii, pred_tube_mel_steps_ii, prod_tube_mel_steps_ii = [], [], [], []
+            pred_tube_semvec_steps_ii, prod_tube_semvec_steps_ii = [], []
             ii = 0
             while ii < n_inner:
                 to_log = log_ii - 1 - (ii % log_ii)            # plain iterations before the next log step
@@ -582,6 +643,8 @@ class Paule():
                 pm, ps = planner.get_pred(with_semvec=(objective != "acoustic" or log_semantics))
                 pred_mel = _np(pm)
                 pred_semvec = _np(ps) if ps is not None else None
+                if soma:                                   # predictions of the tube path at the pre-step CP (paule/paule.py:1081-1086)
+                    pred_tube, pred_tube_mel, pred_tube_semvec = [_np(a) for a in planner.get_tube_pred()]
                 if log_gradients:
                     loss, grad = planner.step(1, return_grad=True)
                     grad_steps.append(grad.detach().clone())
@@ -595,6 +658,31 @@ class Paule():
                 jerk_loss_steps.append(_scalar_or_vec(row[:, _COL["jerk"]]))
                 if self.use_speech_classifier:
                     pred_speech_classifier_loss_steps.append(_scalar_or_vec(row[:, _COL["cls"]]))
+                if soma:                                   # paule/paule.py:947-949, :995-997
+                    pred_tube_mel_loss_steps.append(_scalar_or_vec(row[:, _COL["tube_mel"]]))
+                    pred_tube_semvec_loss_steps.append(_scalar_or_vec(row[:, _COL["tube_semvec"]]))
+                    pred_tube_steps_ii.append(squeeze(pred_tube))
+                    pred_tube_mel_steps_ii.append(squeeze(pred_tube_mel))
+                    pred_tube_semvec_steps_ii.append(squeeze(pred_tube_semvec))
+                    if self.tube_extractor is not None:    # production side (paule/paule.py:1069-1095, :1147-1160)
+                        prod_tube = np.asarray(self.tube_extractor(xx_pre), dtype=np.float64).reshape(pred_tube.shape)
+                        prod_tube_mel, prod_tube_semvec = [_np(a) for a in planner.embed_tube(prod_tube)]
+                        prod_tube_steps_ii.append(squeeze(prod_tube))
+                        prod_tube_mel_steps_ii.append(squeeze(prod_tube_mel))
+                        prod_tube_semvec_steps_ii.append(squeeze(prod_tube_semvec))
+                        prod_tube_loss = _rmse_rows(pred_tube, prod_tube)
+                        prod_tube_mel_loss = MEL_WEIGHT * _rmse_rows(prod_tube_mel, target_mel)
+                        prod_tube_semvec_loss = SEMANTIC_WEIGHT * _rmse_rows(prod_tube_semvec, target_semvec)
+                        prod_tube_loss_steps.append(_scalar_or_vec(prod_tube_loss))
+                        prod_tube_mel_loss_steps.append(_scalar_or_vec(prod_tube_mel_loss))
+                        prod_tube_semvec_loss_steps.append(_scalar_or_vec(prod_tube_semvec_loss))
+                        if verbose:
+                            print("Produced Tube Loss: ", _scalar_or_vec(prod_tube_loss))
+                        new_so = BestSynthesisSomatosensory(float(prod_tube_loss.mean()), float(prod_tube_mel_loss.mean()),
+                                                            float(prod_tube_semvec_loss.mean()), xx_pre, None, prod_tube, pred_tube,
+                                                            prod_tube_mel, pred_tube_mel, prod_tube_semvec, pred_tube_semvec)
+                        if self.best_synthesis_somatosensory.tube_loss > new_so.tube_loss:
+                            self.best_synthesis_somatosensory = new_so
                 if objective != "acoustic":
                     pred_semvec_loss_steps.append(_scalar_or_vec(row[:, _COL["semvec"]]))
                 elif log_semantics and pred_semvec is not None:
@@ -638,6 +726,13 @@ class Paule():
             pred_mel_steps.append(pred_mel_steps_ii)
             pred_semvec_steps.append(pred_semvec_steps_ii)
             prod_semvec_steps.append(prod_semvec_steps_ii)
+            if soma:
+                prod_tube_steps.append(prod_tube_steps_ii)
+                pred_tube_steps.append(pred_tube_steps_ii)
+                prod_tube_mel_steps.append(prod_tube_mel_steps_ii)
+                pred_tube_mel_steps.append(pred_tube_mel_steps_ii)
+                prod_tube_semvec_steps.append(prod_tube_semvec_steps_ii)
+                pred_tube_semvec_steps.append(pred_tube_semvec_steps_ii)
 
             # execute and continue learning (paule/paule.py:1243-1454).  The predictive model's mini-batch steps
             # (:1353-1379) run on the device through the planner (pl_train_pred_step); a hook may replace them.
@@ -667,6 +762,21 @@ class Paule():
         prod_semvec = _np(planner.embed_mel(prod_mel)) if prod_mel is not None else None
         sq = (lambda a: None if a is None else a[-1]) if B == 1 else (lambda a: a)
         sqs = (lambda s: None if s is None else s[0]) if B == 1 else (lambda s: s)
+        if soma:                                        # paule/paule.py:1466-1470, :1534-1541
+            pred_tube, pred_tube_mel, pred_tube_semvec = [_np(a) for a in planner.get_tube_pred()]
+            return PlanningResultsWithSomatosensory(
+                sq(planned_cp), sq(initial_cp), sqs(initial_sig), initial_sr, sq(initial_prod_mel), sq(initial_pred_mel),
+                sq(initial_prod_tube), sq(initial_pred_tube), sq(initial_prod_tube_mel), sq(initial_pred_tube_mel),
+                target_sig, target_sr, sq(target_mel), sqs(sig), sr, sq(prod_mel), sq(pred_mel),
+                sq(prod_tube), sq(pred_tube), sq(prod_tube_mel), sq(pred_tube_mel),
+                sq(initial_prod_semvec), sq(initial_pred_semvec), sq(initial_prod_tube_semvec), sq(initial_pred_tube_semvec),
+                sq(prod_semvec), sq(pred_semvec), sq(prod_tube_semvec), sq(pred_tube_semvec),
+                prod_loss_steps, planned_loss_steps, planned_mel_loss_steps, vel_loss_steps, jerk_loss_steps,
+                pred_semvec_loss_steps, prod_semvec_loss_steps, prod_tube_loss_steps, pred_tube_mel_loss_steps,
+                prod_tube_mel_loss_steps, pred_tube_semvec_loss_steps, prod_tube_semvec_loss_steps, cp_steps,
+                pred_semvec_steps, prod_semvec_steps, grad_steps, sig_steps, prod_mel_steps, pred_mel_steps,
+                prod_tube_steps, pred_tube_steps, prod_tube_mel_steps, pred_tube_mel_steps, prod_tube_semvec_steps,
+                pred_tube_semvec_steps, pred_model_loss, inv_model_loss, tube_model_loss, tube_mel_model_loss)
         if self.use_speech_classifier:
             return PlanningResultsWithSpeechClassifier(
                 sq(planned_cp), sq(initial_cp), sqs(initial_sig), initial_sr, sq(initial_prod_mel), sq(initial_pred_mel),

@@ -27,6 +27,20 @@ MODEL_SETS = {
 
 Workload = namedtuple("Workload", "pred_sd emb_sd target_mel target_semvec cp0 batch n_frames")
 
+# the somatosensory models as Paule builds them (paule/paule.py:233-237, :248-252, :263-267; the tube embedder without dropout)
+TUBE_SPECS = dict(cp_tube=dict(num_lstm_layers=1, hidden_size=360), tube_mel=dict(num_lstm_layers=1, hidden_size=360),
+                  tube_emb=dict(num_lstm_layers=2, hidden_size=720))
+
+
+def make_tube_models(cp_dim=30, tube_dim=10, mel_dim=60, sem_dim=300, dtype=torch.float64, seed=SEED, specs=None):
+    """State dicts of (cp_tube_model, tube_mel_model, tube_embedder) with default torch init under ``seed + 2``."""
+    sp = specs or TUBE_SPECS
+    with torch.random.fork_rng():
+        torch.manual_seed(seed + 2)
+        return (_lstm_linear_state_dict(cp_dim, sp["cp_tube"]["hidden_size"], sp["cp_tube"]["num_lstm_layers"], tube_dim, "post_linear", dtype),
+                _lstm_linear_state_dict(tube_dim, sp["tube_mel"]["hidden_size"], sp["tube_mel"]["num_lstm_layers"], mel_dim, "post_linear", dtype),
+                _lstm_linear_state_dict(tube_dim, sp["tube_emb"]["hidden_size"], sp["tube_emb"]["num_lstm_layers"], sem_dim, "linear_mapping", dtype))
+
 
 def _lstm_linear_state_dict(in_size, hidden, layers, out_size, lin_name, dtype):
     """torch default init (U(-1/sqrt(H), 1/sqrt(H))) in the reference's parameter-creation order."""

@@ -45,6 +45,11 @@ def golden_embvar():
     return _load("embedder_variants.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_soma():
+    return _load("somatosensory_small.npz")
+
+
 def state_dict_from(g, prefix):
     import torch
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}

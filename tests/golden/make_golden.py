@@ -62,7 +62,7 @@ SPEECH_CLASSIFIER_WEIGHT = 0.1
 bce_loss = torch.nn.BCEWithLogitsLoss()   # paule/paule.py:71
 
 
-def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, cps, pred_speech_classifier=None):
+def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, cps, pred_speech_classifier=None, tube=None):
     """The criterion closures (paule/paule.py:647-662, :705-717, :760-773; with the speech classifier :604-622,
     :666-683) on ONE utterance."""
     rmse_loss, mse_loss = ns["rmse_loss"], ns["mse_loss"]
@@ -87,12 +87,17 @@ def ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semve
         speech_classifier_loss = SPEECH_CLASSIFIER_WEIGHT * bce_loss(
             pred_speech_classifier, torch.zeros_like(pred_speech_classifier, dtype=pred_speech_classifier.dtype))
         loss = loss + speech_classifier_loss
-    return loss, torch.stack([loss, mel_loss, semvec_loss, velocity_loss, jerk_loss, local_linear_loss,
-                              speech_classifier_loss, torch.zeros((), dtype=cps.dtype)])
+    col6, col7 = speech_classifier_loss, torch.zeros((), dtype=cps.dtype)
+    if tube is not None:                                                  # paule/paule.py:598-599, :631-642, :745-755
+        pred_tube_mel, pred_tube_semvec = tube
+        col6 = MEL_WEIGHT * rmse_loss(pred_tube_mel, target_mel)          # TUBE_MEL_WEIGHT = MEL_WEIGHT
+        col7 = SEMANTIC_WEIGHT * rmse_loss(pred_tube_semvec, target_semvec)   # TUBE_SEMANTIC_WEIGHT = SEMANTIC_WEIGHT
+        loss = loss + col6 + col7
+    return loss, torch.stack([loss, mel_loss, semvec_loss, velocity_loss, jerk_loss, local_linear_loss, col6, col7])
 
 
 def ref_plan_one(ns, pred_model, embedder, objective, cp0, target_mel, target_semvec, n_iters, lr=0.01,
-                 smiling=False, past_cp=None, snapshots=(), speech_classifier=None):
+                 smiling=False, past_cp=None, snapshots=(), speech_classifier=None, tube_models=None):
     """Inner loop for ONE utterance exactly as the reference runs it (batch 1, paule/paule.py:585-588)."""
     xx_new = cp0.clone().view(1, *cp0.shape).requires_grad_()          # :585-590
     target_mel = target_mel.view(1, *target_mel.shape)
@@ -108,8 +113,17 @@ def ref_plan_one(ns, pred_model, embedder, objective, cp0, target_mel, target_se
             embedder = embedder.train()
             pred_semvec = embedder(pred_mel, (torch.tensor(seq_length),))
         pred_speech_classifier = speech_classifier(pred_mel) if speech_classifier is not None else None   # :914-915
+        tube = None
+        if tube_models is not None:                                     # :916-919, :926-929
+            cp_tube_model, tube_mel_model, tube_embedder = tube_models
+            pred_tube = cp_tube_model(xx_new)
+            pred_tube.retain_grad()
+            pred_tube_mel = tube_mel_model(pred_tube)
+            tube_embedder = tube_embedder.train()
+            pred_tube_semvec = tube_embedder(pred_tube, (torch.tensor(pred_tube.shape[1]),))
+            tube = (pred_tube_mel, pred_tube_semvec)
         discrepancy, sub = ref_criterion(ns, objective, pred_mel, target_mel, pred_semvec, target_semvec, xx_new,
-                                         pred_speech_classifier)
+                                         pred_speech_classifier, tube)
         log.append(sub.detach().clone())
         discrepancy.backward()                                          # :1052
         if ii + 1 in snapshots:
@@ -378,6 +392,52 @@ def main():
                 out[f"{vname}/{objective}/grad_at_{k}"] = torch.stack(grads[k]).numpy()
     np.savez_compressed(os.path.join(HERE, "embedder_variants.npz"), **out)
     print("embedder_variants.npz:", len(out), "arrays")
+
+    # ---- fixture 6: somatosensory feedback (paule/paule.py:227-273, :624-644, :739-757, :916-929) ------------------------
+    # cp -> tube (ForwardModel, no half sequence), tube -> mel (ForwardModel), tube -> semvec (EmbeddingModel, dropout 0: the
+    # reference's default tube embedder has dropout 0.7 and runs in .train() mode inside the loop, which makes its loss random;
+    # with dropout 0 the loop is deterministic).  Small random-init models of the reference's classes.
+    pspec, espec = dict(num_lstm_layers=2, hidden_size=24), dict(num_lstm_layers=2, hidden_size=20)
+    B, T = 3, 40
+    wl = synthetic.make_workload(B, T, None, pred=pspec, emb=espec)
+    pm, em = build_ref_models(ref_models, pspec, espec, wl.pred_sd, wl.emb_sd)
+    torch.manual_seed(synthetic.SEED + 31)
+    cp_tube = ref_models.ForwardModel(num_lstm_layers=1, hidden_size=16, output_size=10, input_size=30, apply_half_sequence=False).double()
+    tube_mel = ref_models.ForwardModel(num_lstm_layers=1, hidden_size=18, output_size=60, input_size=10, apply_half_sequence=True).double()
+    tube_emb = ref_models.EmbeddingModel(input_size=10, num_lstm_layers=2, hidden_size=14, dropout=0, post_upsampling_size=0).double()
+    with torch.no_grad():
+        for m_ in (cp_tube, tube_mel, tube_emb):      # default init gives tiny outputs for such small layers: scale the output maps
+            for name, p_ in m_.named_parameters():
+                if name.startswith(("post_linear", "linear_mapping")) and name.endswith("weight"):
+                    p_.mul_(3.0)
+    for m_ in (cp_tube, tube_mel, tube_emb):
+        for p_ in m_.parameters():
+            p_.requires_grad_(True)
+    out = dict(B=B, T=T, target_mel=wl.target_mel.numpy(), target_semvec=wl.target_semvec.numpy(), cp0=wl.cp0.numpy())
+    out.update(npz_state("pred", wl.pred_sd))
+    out.update(npz_state("emb", wl.emb_sd))
+    for prefix, m_ in (("cp_tube", cp_tube), ("tube_mel", tube_mel), ("tube_emb", tube_emb)):
+        out.update(npz_state(prefix, {k: v.detach().clone() for k, v in m_.state_dict().items()}))
+    with torch.no_grad():
+        pred_tube = cp_tube(wl.cp0)
+        out["fwd/pred_tube"] = pred_tube.numpy()
+        out["fwd/pred_tube_mel"] = tube_mel(pred_tube).numpy()
+        out["fwd/pred_tube_semvec"] = tube_emb.eval()(pred_tube, [torch.tensor(T)] * B).numpy()
+    for objective in ("acoustic_semvec", "semvec"):
+        logs, cps, grads = [], {k: [] for k in SNAP}, {k: [] for k in SNAP}
+        for b in range(B):
+            log, snaps, gr, _, _ = ref_plan_one(ns, pm, em, objective, wl.cp0[b], wl.target_mel[b], wl.target_semvec[b], 20,
+                                                snapshots=SNAP, tube_models=(cp_tube, tube_mel, tube_emb))
+            logs.append(log)
+            for k in SNAP:
+                cps[k].append(snaps[k])
+                grads[k].append(gr[k])
+        out[f"{objective}/loss_log"] = torch.stack(logs, dim=1).numpy()
+        for k in SNAP:
+            out[f"{objective}/cp_after_{k}"] = torch.stack(cps[k]).numpy()
+            out[f"{objective}/grad_at_{k}"] = torch.stack(grads[k]).numpy()
+    np.savez_compressed(os.path.join(HERE, "somatosensory_small.npz"), **out)
+    print("somatosensory_small.npz:", len(out), "arrays")
     return 0
 
 

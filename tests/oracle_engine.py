@@ -9,7 +9,7 @@ from oracle import planner as op
 class OracleEngine:
     def __init__(self, pred_model, embedder=None, *, batch, n_frames, objective="acoustic", dtype="f32", lr=0.01,
                  betas=(0.9, 0.999), eps=1e-8, clamp=(-1.05, 1.05), smiling=False, weights=None, device=None,
-                 use_graph=True, inv_model=None):
+                 use_graph=True, inv_model=None, tube_models=None):
         sd = lambda m: m.state_dict() if hasattr(m, "state_dict") else m
         self.pred_sd, self.emb_sd = sd(pred_model), sd(embedder) if embedder is not None else None
         self.B, self.T, self.Tp = batch, n_frames, n_frames // 2
@@ -18,17 +18,32 @@ class OracleEngine:
         self.has_embedder = self.emb_sd is not None
         self.inv = op.inverse_model_from_state_dict(sd(inv_model)) if inv_model is not None else None
         self.has_inverse = self.inv is not None
+        self.tube_sds = None if tube_models is None else [sd(m) for m in tube_models]
+        self.has_tube = tube_models is not None
         self._build()
 
     def _build(self):
         pm = op.forward_model_from_state_dict(self.pred_sd)
         em = op.embedding_model_from_state_dict(self.emb_sd) if self.emb_sd is not None else None
         old = getattr(self, "p", None)
-        self.p = op.OraclePlanner(pm, em, **self.kw)
+        tube = None
+        if self.tube_sds is not None:
+            tube = (op.forward_model_from_state_dict(self.tube_sds[0], apply_half_sequence=False),
+                    op.forward_model_from_state_dict(self.tube_sds[1]), op.embedding_model_from_state_dict(self.tube_sds[2]))
+        self.p = op.OraclePlanner(pm, em, tube_models=tube, **self.kw)
         if old is not None:
             self.p.xx, self.p.optimizer = old.xx, old.optimizer
             self.p.target_mel, self.p.target_semvec, self.p.past_cp = old.target_mel, old.target_semvec, old.past_cp
             self.p.classifier = old.classifier
+
+    def get_tube_pred(self):
+        return self.p.get_tube_pred()
+
+    def embed_tube(self, tube):
+        _, tube_mel, tube_emb = self.p.tube_models
+        with torch.no_grad():
+            t = torch.as_tensor(np.asarray(tube), dtype=torch.float64)
+            return tube_mel(t), tube_emb(t, [torch.tensor(t.shape[1])] * t.shape[0])
 
     def inverse_forward(self, mel, clip=True):
         with torch.no_grad():

@@ -537,6 +537,30 @@ def test_paule_with_embedder_variant_hip_equals_oracle_engine(golden_embvar):
     np.testing.assert_allclose(sh, so, atol=2e-4, rtol=0)
 
 
+def test_paule_somatosensory_hip_equals_oracle_engine(golden_soma):
+    """Paule(use_somatosensory_feedback=True, ...).plan_resynth on the device against the same host code on the CPU oracle:
+    planned CP, the logged tube losses and the final tube predictions."""
+    from oracle_engine import OracleEngine
+    from paule_amd import paule as pp
+    g = golden_soma
+    sdf = state_dict_from
+    out = []
+    for factory in (None, lambda pm, em, **kw: OracleEngine(pm, em, **kw)):
+        model = pp.Paule(pred_model=sdf(g, "pred"), embedder=sdf(g, "emb"), use_somatosensory_feedback=True,
+                         cp_tube_model=sdf(g, "cp_tube"), tube_mel_model=sdf(g, "tube_mel"), tube_embedder=sdf(g, "tube_emb"),
+                         tube_extractor=lambda cp: np.full(cp.shape[:2] + (10,), 0.1), planner_factory=factory,
+                         device=torch.device("cuda" if factory is None else "cpu"))
+        res = model.plan_resynth(target_acoustic=g["target_mel"][:2], target_semvec=g["target_semvec"][:2], initial_cp=g["cp0"][:2],
+                                 initialize_from=None, objective="semvec", n_outer=1, n_inner=6, log_ii=3, continue_learning=False,
+                                 verbose=False)
+        out.append([_n(res.planned_cp), np.asarray(res.pred_tube_mel_loss_steps, dtype=np.float64),
+                    np.asarray(res.pred_tube_semvec_loss_steps, dtype=np.float64), _n(res.pred_tube), _n(res.pred_tube_mel),
+                    _n(res.pred_tube_semvec), _n(res.prod_tube_mel), _n(res.prod_tube_semvec),
+                    np.asarray(res.prod_tube_mel_loss_steps, dtype=np.float64)])
+    for a, b in zip(*out):
+        np.testing.assert_allclose(a, b, atol=2e-4, rtol=2e-4)
+
+
 def test_paule_initialize_from_acoustic_hip(golden_inverse):
     """Paule.plan_resynth(initialize_from='acoustic') with the inverse model on the device: initial_cp equals the reference's
     clipped inverse output, and the plan starts from it."""
@@ -796,6 +820,51 @@ def test_embedder_variant_full_size_vs_oracle_rows(HipPlanner):
     want = P.step(5).numpy()
     np.testing.assert_allclose(loss[:, rows, :6], want[:, :, :6], rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(_n(eng.get_cp())[rows], _n(P.get_cp()), atol=2e-4, rtol=0)
+
+
+def _soma_engine(HipPlanner, g, objective, dtype="f32", **extra):
+    eng = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, "emb"), batch=int(g["B"]), n_frames=int(g["T"]), objective=objective,
+                     dtype=dtype, tube_models=(state_dict_from(g, "cp_tube"), state_dict_from(g, "tube_mel"), state_dict_from(g, "tube_emb")),
+                     **extra)
+    eng.set_targets(g["target_mel"], g["target_semvec"])
+    eng.set_cp(g["cp0"])
+    return eng
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("objective", ["acoustic_semvec", "semvec"])
+def test_somatosensory_feedback_f32_vs_reference_fixture(HipPlanner, golden_soma, objective, use_graph):
+    """the somatosensory path of the loop (cp -> tube -> mel and tube -> semantic vector, two more loss terms,
+    paule/paule.py:916-929, :624-644) on the device against the reference's classes run through the reference loop: tube
+    predictions, gradients, CP and all eight loss columns, same bars as the acoustic path."""
+    g = golden_soma
+    eng = _soma_engine(HipPlanner, g, objective, use_graph=use_graph)
+    tube, tmel, tsem = eng.get_tube_pred()
+    np.testing.assert_allclose(_n(tube), g["fwd/pred_tube"], atol=FWD_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(_n(tmel), g["fwd/pred_tube_mel"], atol=FWD_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(_n(tsem), g["fwd/pred_tube_semvec"], atol=FWD_ATOL_F32, rtol=0)
+    logs, done = [], 0
+    for k in (1, 5, 20):
+        loss, grad = eng.step(k - done, return_grad=True)
+        logs.append(_n(loss))
+        done = k
+        np.testing.assert_allclose(_n(eng.get_cp()), g[f"{objective}/cp_after_{k}"], atol=CP_ATOL_F32, rtol=0, err_msg=f"cp after {k}")
+        ref_g = g[f"{objective}/grad_at_{k}"]
+        np.testing.assert_allclose(_n(grad), ref_g, atol=1e-5 * max(1.0, np.abs(ref_g).max()), rtol=0, err_msg=f"grad at {k}")
+    np.testing.assert_allclose(np.concatenate(logs), g[f"{objective}/loss_log"], rtol=LOSS_RTOL_F32, atol=1e-7)
+
+
+def test_somatosensory_feedback_bf16_and_errors(HipPlanner, golden_soma):
+    g = golden_soma
+    name = "acoustic_semvec"
+    eng = _soma_engine(HipPlanner, g, name, dtype="bf16")
+    loss, grad = eng.step(1, return_grad=True)
+    assert _cos(grad, g[f"{name}/grad_at_1"]) >= COS_BF16
+    more = eng.step(19)
+    np.testing.assert_allclose(np.concatenate([_n(loss), _n(more)]), g[f"{name}/loss_log"], rtol=LOSS_RTOL_BF16, atol=1e-4)
+    np.testing.assert_allclose(_n(eng.get_cp()), g[f"{name}/cp_after_20"], atol=0.05 * 0.01 * 20, rtol=0)
+    with pytest.raises(ValueError, match="acoustic_semvec"):
+        _soma_engine(HipPlanner, g, "acoustic")
 
 
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):

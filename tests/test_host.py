@@ -285,6 +285,57 @@ def test_embedder_variant_containers_keep_the_reference_key_layout(golden_embvar
         models.EmbeddingModel(post_upsampling_size=16, post_activation=torch.nn.LeakyReLU(0.2))
 
 
+def _soma_paule(g, factory, device, **kw):
+    from conftest import state_dict_from as sdf
+    return pp.Paule(pred_model=sdf(g, "pred"), embedder=sdf(g, "emb"), use_somatosensory_feedback=True,
+                    cp_tube_model=sdf(g, "cp_tube"), tube_mel_model=sdf(g, "tube_mel"), tube_embedder=sdf(g, "tube_emb"),
+                    planner_factory=factory, device=device, **kw)
+
+
+def test_somatosensory_feedback_on_the_planner(golden_soma):
+    """Paule(use_somatosensory_feedback=True, cp_tube_model=..., tube_mel_model=..., tube_embedder=...): the host code around
+    the planner (here the CPU oracle behind the planner interface) -- result type and fields of the reference
+    (paule/paule.py:59, :1534-1541), logged tube losses = columns 6 / 7 of the reference loop's loss log (fixture), the
+    production side through the tube_extractor hook, and the refusals."""
+    g = golden_soma
+    factory = lambda pm, em, **kw: OracleEngine(pm, em, **kw)
+    calls = []
+
+    def tube_extractor(cp):
+        calls.append(cp.shape)
+        return np.full(cp.shape[:2] + (10,), 0.1)
+
+    model = _soma_paule(g, factory, torch.device("cpu"), tube_extractor=tube_extractor)
+    res = model.plan_resynth(target_acoustic=g["target_mel"], target_semvec=g["target_semvec"], initial_cp=g["cp0"],
+                             initialize_from=None, objective="acoustic_semvec", n_outer=1, n_inner=20, log_ii=5,
+                             continue_learning=False, log_cps=True, verbose=False)
+    assert type(res).__name__ == "PlanningResultsWithSomatosensory" and len(res._fields) == 58
+    np.testing.assert_allclose(res.planned_cp, g["acoustic_semvec/cp_after_20"], atol=1e-12, rtol=0)
+    log = g["acoustic_semvec/loss_log"]                     # (20, B, 8); log steps are iterations 5, 10, 15, 20 (1-based)
+    np.testing.assert_allclose(np.asarray(res.pred_tube_mel_loss_steps), log[[4, 9, 14, 19], :, 6], rtol=1e-12)
+    np.testing.assert_allclose(np.asarray(res.pred_tube_semvec_loss_steps), log[[4, 9, 14, 19], :, 7], rtol=1e-12)
+    np.testing.assert_allclose(np.asarray(res.planned_loss_steps), log[[4, 9, 14, 19], :, 0], rtol=1e-12)
+    np.testing.assert_allclose(res.initial_pred_tube, g["fwd/pred_tube"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(res.initial_pred_tube_mel, g["fwd/pred_tube_mel"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(res.initial_pred_tube_semvec, g["fwd/pred_tube_semvec"], atol=1e-12, rtol=0)
+    assert res.pred_tube.shape == (3, 40, 10) and res.pred_tube_mel.shape == (3, 20, 60) and res.pred_tube_semvec.shape == (3, 300)
+    assert len(calls) == 1 + 4 and len(res.prod_tube_loss_steps) == 4 and len(res.prod_tube_steps[0]) == 4
+    assert res.prod_tube.shape == (3, 40, 10) and res.prod_tube_mel.shape == (3, 20, 60)
+    assert model.best_synthesis_somatosensory.tube_loss < np.inf
+    with pytest.raises(NotImplementedError, match="acoustic"):
+        model.plan_resynth(target_acoustic=g["target_mel"], initial_cp=g["cp0"], initialize_from=None, objective="acoustic",
+                           n_outer=1, n_inner=1, continue_learning=False, verbose=False)
+    with pytest.raises(NotImplementedError, match="tube_embedder"):
+        pp.Paule(pred_model=g, embedder=g, use_somatosensory_feedback=True, planner_factory=factory, device=torch.device("cpu"))
+    drop = torch.nn.Module()
+    drop.lstm = torch.nn.LSTM(10, 4, num_layers=2, dropout=0.7)
+    with pytest.raises(NotImplementedError, match="dropout"):
+        pp.Paule(pred_model=g, embedder=g, use_somatosensory_feedback=True, cp_tube_model=g, tube_mel_model=g, tube_embedder=drop,
+                 planner_factory=factory, device=torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        pp.Paule(pred_model=g, embedder=g, use_somatosensory_feedback=True, use_speech_classifier=True, planner_factory=factory)
+
+
 def test_speech_classifier_config(small):
     """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
     clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}

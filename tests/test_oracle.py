@@ -201,6 +201,43 @@ def test_embedder_variants_vs_reference_fixture(golden_embvar, variant):
         _close(P.get_pred()[1], g[f"{variant}/{objective}/final_pred_semvec"])
 
 
+def _soma_models(g, dtype=torch.float64):
+    return (op.forward_model_from_state_dict(state_dict_from(g, "cp_tube"), dtype, apply_half_sequence=False),
+            op.forward_model_from_state_dict(state_dict_from(g, "tube_mel"), dtype),
+            op.embedding_model_from_state_dict(state_dict_from(g, "tube_emb"), dtype))
+
+
+@pytest.mark.parametrize("objective", ["acoustic_semvec", "semvec"])
+def test_somatosensory_feedback_vs_reference_fixture(golden_soma, objective):
+    """The somatosensory path of the loop (paule/paule.py:916-929, criterion :624-644 / :739-757) through the reference's
+    ForwardModel / EmbeddingModel classes as cp_tube_model, tube_mel_model and tube_embedder (dropout 0): model outputs,
+    gradients, CP and the eight loss columns (6, 7 = tube mel, tube semvec)."""
+    g = golden_soma
+    cp_tube, tube_mel, tube_emb = _soma_models(g)
+    with torch.no_grad():
+        pt = cp_tube(torch.from_numpy(g["cp0"]))
+        _close(pt, g["fwd/pred_tube"])
+        _close(tube_mel(pt), g["fwd/pred_tube_mel"])
+        _close(tube_emb(pt, [torch.tensor(pt.shape[1])] * pt.shape[0]), g["fwd/pred_tube_semvec"])
+    P = op.OraclePlanner(op.forward_model_from_state_dict(state_dict_from(g, "pred")),
+                         op.embedding_model_from_state_dict(state_dict_from(g, "emb")), objective=objective,
+                         tube_models=_soma_models(g))
+    P.set_targets(g["target_mel"], g["target_semvec"])
+    P.set_cp(g["cp0"])
+    logs, done = [], 0
+    for k in (1, 5, 20):
+        logs.append(P.step(k - done).numpy())
+        done = k
+        _close(P.get_cp(), g[f"{objective}/cp_after_{k}"])
+        _close(P.last_grad, g[f"{objective}/grad_at_{k}"], 1e-11)
+    log = np.concatenate(logs)
+    _close(log, g[f"{objective}/loss_log"])
+    assert (log[:, :, 6] > 0).all() and (log[:, :, 7] > 0).all()
+    with pytest.raises(ValueError):
+        P.objective = "acoustic"
+        P.step(1)
+
+
 def test_torch_and_manual_oracles_agree_on_random_shapes():
     """The two independent restatements -- torch autograd (oracle/planner.py) and numpy with explicit BPTT (oracle/manual.py:
     the arithmetic the kernels implement) -- against each other on shapes no fixture holds (property test, hypothesis):
