@@ -218,6 +218,19 @@ int pl_set_pred_optimizer_state(pl_handle *h, int layer, int which, const float 
                                 const float *b_hh);
 int64_t pl_get_pred_optimizer_step(const pl_handle *h);
 int pl_set_pred_optimizer_step(pl_handle *h, int64_t step);
+/* The same step for any ForwardModel of the handle: model_id PL_MODEL_PRED (= pl_train_pred_step), PL_MODEL_CP_TUBE
+ * (input cp [n_rows, n_frames, cp_dim], target tube [n_rows, n_frames, tube_dim]: no half sequence) or PL_MODEL_TUBE_MEL
+ * (input tube [n_rows, n_frames, tube_dim], target mel [n_rows, n_frames/2, mel_dim]) -- continue_learning_tube,
+ * paule/paule.py:1381-1404 with tube_optimizer / tube_mel_optimizer = Adam(lr 0.001) and RMSELoss (:296-306) -- and the
+ * optimizer state of each (reset, exp_avg / exp_avg_sq transfer, step count), as for the predictive model. */
+int pl_train_model_step(pl_handle *h, int model_id, int n_rows, int n_frames, const float *input, const float *target, float lr,
+                        float beta1, float beta2, float eps, float *loss_out);
+int pl_reset_model_optimizer(pl_handle *h, int model_id);
+int pl_get_model_optimizer_state(pl_handle *h, int model_id, int layer, int which, float *w_ih, float *w_hh, float *b_ih, float *b_hh);
+int pl_set_model_optimizer_state(pl_handle *h, int model_id, int layer, int which, const float *w_ih, const float *w_hh,
+                                 const float *b_ih, const float *b_hh);
+int64_t pl_get_model_optimizer_step(pl_handle *h, int model_id);
+int pl_set_model_optimizer_step(pl_handle *h, int model_id, int64_t step);
 /* Current parameters in torch layout (the layouts of pl_set_lstm_weights / pl_set_linear), float32 device pointers:
  * how the host's torch module is brought back in sync after continued learning. */
 int pl_get_lstm_weights(pl_handle *h, int model_id, int layer, float *w_ih, float *w_hh, float *b_ih, float *b_hh);

@@ -28,6 +28,8 @@ EXPORTED_SYMBOLS = (
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
     "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
     "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
+    "pl_train_model_step", "pl_reset_model_optimizer", "pl_get_model_optimizer_state", "pl_set_model_optimizer_state",
+    "pl_get_model_optimizer_step", "pl_set_model_optimizer_step",
     "pl_last_error", "pl_version",
 )
 
@@ -107,6 +109,13 @@ def load_library(path: str | None = None):
     lib.pl_get_pred_optimizer_step.restype = C.c_int64
     lib.pl_get_pred_optimizer_step.argtypes = [vp]
     lib.pl_set_pred_optimizer_step.argtypes = [vp, C.c_int64]
+    lib.pl_train_model_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+    lib.pl_reset_model_optimizer.argtypes = [vp, C.c_int]
+    lib.pl_get_model_optimizer_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
+    lib.pl_set_model_optimizer_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
+    lib.pl_get_model_optimizer_step.restype = C.c_int64
+    lib.pl_get_model_optimizer_step.argtypes = [vp, C.c_int]
+    lib.pl_set_model_optimizer_step.argtypes = [vp, C.c_int, C.c_int64]
     lib.pl_device_bytes.restype = C.c_int64
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double
@@ -115,7 +124,9 @@ def load_library(path: str | None = None):
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
                  "pl_get_pred", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
                  "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
-                 "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_set_pred_optimizer_step"):
+                 "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_set_pred_optimizer_step",
+                 "pl_train_model_step", "pl_reset_model_optimizer", "pl_get_model_optimizer_state", "pl_set_model_optimizer_state",
+                 "pl_set_model_optimizer_step"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib

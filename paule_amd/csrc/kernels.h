@@ -184,7 +184,7 @@ void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols
 // scal[0] = sqrt(mean((pred - target)^2)) over n elements (f64), scal[1] = the sum of squares; loss_out (device f32) optional
 void launch_train_rmse(hipStream_t stream, const float* pred, const float* target, int64_t n, double* scal, float* loss_out);
 void launch_train_dy(hipStream_t stream, int dt, const float* pred, const float* target, const double* scal, int n_rows, int T, int Tp,
-                     int M, int Bp, int Mp, void* dY);
+                     int M, int Bp, int Mp, void* dY, bool pooled = true);
 struct AdamHyper {
     double lr, b1, b2, eps, bc1, bc2;   // bc = 1 - beta^k of the step being taken
 };

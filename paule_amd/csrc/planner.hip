@@ -1446,37 +1446,51 @@ int ensure_train_state(pl_handle* h, Model& md) {
 
 }  // namespace
 
-int pl_train_pred_step(pl_handle* h, int n_rows, int n_frames, const float* cp, const float* mel_target, float lr, float beta1,
-                       float beta2, float eps, float* loss_out) {
-    if (!h || !cp || !mel_target) return fail(PL_ERR_INVALID, "pl_train_pred_step: NULL argument");
-    if (n_rows < 1 || n_rows > h->Bp) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_rows has to be in [1, batch rounded up to 16]");
-    if (n_frames < 2 || n_frames > h->T) return fail(PL_ERR_INVALID, "pl_train_pred_step: n_frames has to be in [2, n_frames of the handle]");
+// One optimizer step of a ForwardModel of the handle on a mini-batch (paule/paule.py:1372-1377 for pred_model, :1386-1404 for
+// the cp -> tube and tube -> mel models of the somatosensory path): forward, batch RMSE, backward with weight gradients, Adam.
+int pl_train_model_step(pl_handle* h, int model_id, int n_rows, int n_frames, const float* input, const float* target, float lr,
+                        float beta1, float beta2, float eps, float* loss_out) {
+    if (!h || !input || !target) return fail(PL_ERR_INVALID, "pl_train_model_step: NULL argument");
+    if (model_id != PL_MODEL_PRED && model_id != PL_MODEL_CP_TUBE && model_id != PL_MODEL_TUBE_MEL)
+        return fail(PL_ERR_INVALID, "pl_train_model_step: model_id has to be PL_MODEL_PRED, PL_MODEL_CP_TUBE or PL_MODEL_TUBE_MEL");
+    if (n_rows < 1 || n_rows > h->Bp) return fail(PL_ERR_INVALID, "pl_train_model_step: n_rows has to be in [1, batch rounded up to 16]");
+    if (n_frames < 2 || n_frames > h->T) return fail(PL_ERR_INVALID, "pl_train_model_step: n_frames has to be in [2, n_frames of the handle]");
     if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f))
-        return fail(PL_ERR_INVALID, "pl_train_pred_step: bad optimizer hyper-parameter");
-    Model& p = h->pred;
-    if (!p.ready()) return fail(PL_ERR_STATE, "pl_train_pred_step: predictive-model weights are not set");
+        return fail(PL_ERR_INVALID, "pl_train_model_step: bad optimizer hyper-parameter");
+    Model& p = *model_by_id(h, model_id);
+    if (p.L == 0) return fail(PL_ERR_INVALID, "pl_train_model_step: the handle has no such model");
+    if (!p.ready()) return fail(PL_ERR_STATE, "pl_train_model_step: the model's weights are not set");
     DeviceGuard guard(h->cfg.device);
     SweepChain chain(h->cfg.device, h->stream);
     int rc = ensure_train_state(h, p);
     if (rc) return rc;
     hipStream_t st = h->stream;
-    const int Bp = h->Bp, T = n_frames, Tp = n_frames / 2, nb = pad16(n_rows);
-    // forward: Y_hat = pred_model(batch_input) (paule/paule.py:1372); rows >= n_rows of every slab are zero input
-    launch_pack_mel(st, h->dt, cp, n_rows, T, h->C, h->X0, Bp, h->Cp);
-    model_forward(h, st, p, h->X0, T);
+    const bool pooled = model_id != PL_MODEL_CP_TUBE;   // ForwardModel(apply_half_sequence=...) (paule/paule.py:236, :252)
+    const int Bp = h->Bp, T = n_frames, To = pooled ? n_frames / 2 : n_frames, nb = pad16(n_rows);
+    // buffers by model: time-major input slab, f32 post_linear output, batch-major prediction, output gradient
+    void* in_tm = model_id == PL_MODEL_TUBE_MEL ? h->tube_tm : h->X0;
+    float* Yf = model_id == PL_MODEL_PRED ? h->Y : h->Y2;
+    float* out_bm = model_id == PL_MODEL_PRED ? h->mel_bm : h->mel2_bm;
+    void* dYb = model_id == PL_MODEL_PRED ? h->dY : model_id == PL_MODEL_TUBE_MEL ? h->dY2 : h->dYt;
+    // forward: Y_hat = model(batch_input) (paule/paule.py:1372, :1387, :1397); rows >= n_rows of every slab are zero input
+    launch_pack_mel(st, h->dt, input, n_rows, T, p.in, in_tm, Bp, p.in_p);
+    model_forward(h, st, p, in_tm, T);
     const LstmLayer& top = p.layers[p.L - 1];
-    launch_gemm_nt(st, h->dt, true, top.h, p.Hp, p.Wlin, p.Hp, p.blin, h->Y, h->Mp, T * Bp, h->Mp, p.Hp);
-    launch_pool_mel(st, h->dt, h->Y, n_rows, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm);
-    // pred_loss = rmse over the whole batch (pred_criterion = RMSELoss(eps=0), paule/paule.py:288, :1375)
-    launch_train_rmse(st, h->mel_bm, mel_target, (int64_t)n_rows * Tp * h->M, h->scal, loss_out);
+    launch_gemm_nt(st, h->dt, true, top.h, p.Hp, p.Wlin, p.Hp, p.blin, Yf, p.out_p, T * Bp, p.out_p, p.Hp);
+    if (pooled)
+        launch_pool_mel(st, h->dt, Yf, n_rows, T, p.out, Bp, p.out_p, out_bm, model_id == PL_MODEL_PRED ? h->mel_tm : h->mel2_tm);
+    else
+        launch_tm_to_bm(st, Yf, n_rows, T, p.out, Bp, p.out_p, out_bm);
+    // loss = rmse over the whole batch (RMSELoss(eps=0), paule/paule.py:288, :301, :306, :1375)
+    launch_train_rmse(st, out_bm, target, (int64_t)n_rows * To * p.out, h->scal, loss_out);
     // backward (paule/paule.py:1376): dY, post_linear gradients, then the recurrences with weight gradients
-    launch_train_dy(st, h->dt, h->mel_bm, mel_target, h->scal, n_rows, T, Tp, h->M, Bp, h->Mp, h->dY);
-    launch_gemm_tn(st, h->dt, h->dY, h->Mp, top.h, p.Hp, p.gWlin, p.Hp, h->Mp, p.Hp, Bp, nb, T, 0, 0, p.train_scratch,
+    launch_train_dy(st, h->dt, out_bm, target, h->scal, n_rows, T, To, p.out, Bp, p.out_p, dYb, pooled);
+    launch_gemm_tn(st, h->dt, dYb, p.out_p, top.h, p.Hp, p.gWlin, p.Hp, p.out_p, p.Hp, Bp, nb, T, 0, 0, p.train_scratch,
                    p.train_scratch_bytes, h->n_cu);
-    launch_colsum(st, h->dt, h->dY, h->Mp, h->Mp, Bp, nb, T, 0, p.gblin, p.colsum_part);
-    launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, T * Bp, p.Hp, h->Mp);
-    model_backward(h, st, p, nullptr, nullptr, nb, h->X0, T);
-    // pred_optimizer.step() (paule/paule.py:1377; torch.optim.Adam defaults, :287) + refresh of the packed compute copies
+    launch_colsum(st, h->dt, dYb, p.out_p, p.out_p, Bp, nb, T, 0, p.gblin, p.colsum_part);
+    launch_gemm_nt(st, h->dt, false, dYb, p.out_p, p.WlinT, p.out_p, nullptr, p.dh_ext, p.Hp, T * Bp, p.Hp, p.out_p);
+    model_backward(h, st, p, nullptr, nullptr, nb, in_tm, T);
+    // optimizer.step() (paule/paule.py:1377; torch.optim.Adam defaults, :287, :300, :305) + refresh of the packed compute copies
     p.train_steps += 1;
     AdamHyper hp{(double)lr, (double)beta1, (double)beta2, (double)eps, 1.0 - std::pow((double)beta1, (double)p.train_steps),
                  1.0 - std::pow((double)beta2, (double)p.train_steps)};
@@ -1490,10 +1504,24 @@ int pl_train_pred_step(pl_handle* h, int n_rows, int n_frames, const float* cp, 
     return check_launch();
 }
 
-int pl_reset_pred_optimizer(pl_handle* h) {
-    if (!h) return fail(PL_ERR_INVALID, "pl_reset_pred_optimizer: NULL handle");
+int pl_train_pred_step(pl_handle* h, int n_rows, int n_frames, const float* cp, const float* mel_target, float lr, float beta1,
+                       float beta2, float eps, float* loss_out) {
+    return pl_train_model_step(h, PL_MODEL_PRED, n_rows, n_frames, cp, mel_target, lr, beta1, beta2, eps, loss_out);
+}
+
+namespace {
+bool trainable_id(pl_handle* h, int model_id) {
+    return (model_id == PL_MODEL_PRED || model_id == PL_MODEL_CP_TUBE || model_id == PL_MODEL_TUBE_MEL) && model_by_id(h, model_id)->L > 0;
+}
+}  // namespace
+
+int pl_reset_pred_optimizer(pl_handle* h) { return pl_reset_model_optimizer(h, PL_MODEL_PRED); }
+
+int pl_reset_model_optimizer(pl_handle* h, int model_id) {
+    if (!h) return fail(PL_ERR_INVALID, "pl_reset_model_optimizer: NULL handle");
+    if (!trainable_id(h, model_id)) return fail(PL_ERR_INVALID, "pl_reset_model_optimizer: no such trainable model in this handle");
     DeviceGuard guard(h->cfg.device);
-    Model& p = h->pred;
+    Model& p = *model_by_id(h, model_id);
     p.train_steps = 0;
     if (!p.train_ready) return PL_OK;
     auto zero = [&](ParamState& ps) -> int {
@@ -1515,10 +1543,12 @@ int pl_reset_pred_optimizer(pl_handle* h) {
 // which: 1 exp_avg, 2 exp_avg_sq.  layer >= 0: the four LSTM tensors of that layer; layer = -1: post_linear (w_ih = weight,
 // b_ih = bias; w_hh, b_hh ignored).  float32 device pointers in torch layout.
 namespace {
-int pred_state_io(pl_handle* h, bool set, int layer, int which, float* w_ih, float* w_hh, float* b_ih, float* b_hh, const char* who) {
+int pred_state_io(pl_handle* h, int model_id, bool set, int layer, int which, float* w_ih, float* w_hh, float* b_ih, float* b_hh,
+                  const char* who) {
     if (!h || !w_ih || !b_ih || (layer >= 0 && (!w_hh || !b_hh))) return fail(PL_ERR_INVALID, std::string(who) + ": NULL argument");
     if (which != 1 && which != 2) return fail(PL_ERR_INVALID, std::string(who) + ": which has to be 1 (exp_avg) or 2 (exp_avg_sq)");
-    Model& p = h->pred;
+    if (!trainable_id(h, model_id)) return fail(PL_ERR_INVALID, std::string(who) + ": no such trainable model in this handle");
+    Model& p = *model_by_id(h, model_id);
     if (layer < -1 || layer >= p.L) return fail(PL_ERR_INVALID, std::string(who) + ": layer out of range");
     DeviceGuard guard(h->cfg.device);
     int rc = ensure_train_state(h, p);
@@ -1542,16 +1572,33 @@ int pred_state_io(pl_handle* h, bool set, int layer, int which, float* w_ih, flo
 }  // namespace
 
 int pl_get_pred_optimizer_state(pl_handle* h, int layer, int which, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
-    return pred_state_io(h, false, layer, which, w_ih, w_hh, b_ih, b_hh, "pl_get_pred_optimizer_state");
+    return pred_state_io(h, PL_MODEL_PRED, false, layer, which, w_ih, w_hh, b_ih, b_hh, "pl_get_pred_optimizer_state");
 }
 int pl_set_pred_optimizer_state(pl_handle* h, int layer, int which, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh) {
-    return pred_state_io(h, true, layer, which, const_cast<float*>(w_ih), const_cast<float*>(w_hh), const_cast<float*>(b_ih),
+    return pred_state_io(h, PL_MODEL_PRED, true, layer, which, const_cast<float*>(w_ih), const_cast<float*>(w_hh), const_cast<float*>(b_ih),
                          const_cast<float*>(b_hh), "pl_set_pred_optimizer_state");
 }
 int64_t pl_get_pred_optimizer_step(const pl_handle* h) { return h ? (int64_t)h->pred.train_steps : -1; }
 int pl_set_pred_optimizer_step(pl_handle* h, int64_t step) {
     if (!h || step < 0) return fail(PL_ERR_INVALID, "pl_set_pred_optimizer_step: bad argument");
     h->pred.train_steps = (long long)step;
+    return PL_OK;
+}
+// the same for any trainable model of the handle (tube_optimizer / tube_mel_optimizer, paule/paule.py:296-306)
+int pl_get_model_optimizer_state(pl_handle* h, int model_id, int layer, int which, float* w_ih, float* w_hh, float* b_ih, float* b_hh) {
+    return pred_state_io(h, model_id, false, layer, which, w_ih, w_hh, b_ih, b_hh, "pl_get_model_optimizer_state");
+}
+int pl_set_model_optimizer_state(pl_handle* h, int model_id, int layer, int which, const float* w_ih, const float* w_hh, const float* b_ih,
+                                 const float* b_hh) {
+    return pred_state_io(h, model_id, true, layer, which, const_cast<float*>(w_ih), const_cast<float*>(w_hh), const_cast<float*>(b_ih),
+                         const_cast<float*>(b_hh), "pl_set_model_optimizer_state");
+}
+int64_t pl_get_model_optimizer_step(pl_handle* h, int model_id) {
+    return (h && trainable_id(h, model_id)) ? (int64_t)model_by_id(h, model_id)->train_steps : -1;
+}
+int pl_set_model_optimizer_step(pl_handle* h, int model_id, int64_t step) {
+    if (!h || step < 0 || !trainable_id(h, model_id)) return fail(PL_ERR_INVALID, "pl_set_model_optimizer_step: bad argument");
+    model_by_id(h, model_id)->train_steps = (long long)step;
     return PL_OK;
 }
 

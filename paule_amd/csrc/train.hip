@@ -183,19 +183,19 @@ __global__ __launch_bounds__(1024) void train_rmse_kernel(const float* __restric
 // dL/dY of rmse(avgpool2(Y), target): each of the two pooled frames gets half of (mel - target) / (N rmse)
 template <typename AT>
 __global__ void train_dy_kernel(const float* __restrict__ pred, const float* __restrict__ target, const double* __restrict__ scal,
-                                int n_rows, int T, int Tp, int M, int Bp, int Mp, AT* __restrict__ dY) {
+                                int n_rows, int T, int Tp, int M, int Bp, int Mp, AT* __restrict__ dY, int pooled) {
     const int64_t n = (int64_t)T * Bp * Mp;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int m = (int)(idx % Mp);
     const int b = (int)((idx / Mp) % Bp);
     const int t = (int)(idx / ((int64_t)Mp * Bp));
-    const int tp = t >> 1;
+    const int tp = pooled ? t >> 1 : t;     // pooled = 0: the model does not halve its sequence (Tp = T; cp -> tube model)
     float v = 0.f;
     const double rmse = scal[0];
     if (b < n_rows && m < M && tp < Tp && rmse > 0.0) {
         const size_t e = ((size_t)b * Tp + tp) * M + m;
-        v = (float)(0.5 * ((double)pred[e] - (double)target[e]) / ((double)n_rows * Tp * M * rmse));
+        v = (float)((pooled ? 0.5 : 1.0) * ((double)pred[e] - (double)target[e]) / ((double)n_rows * Tp * M * rmse));
     }
     dY[idx] = from_f32<AT>(v);
 }
@@ -304,14 +304,14 @@ void launch_train_rmse(hipStream_t stream, const float* pred, const float* targe
 }
 
 void launch_train_dy(hipStream_t stream, int dt, const float* pred, const float* target, const double* scal, int n_rows, int T, int Tp,
-                     int M, int Bp, int Mp, void* dY) {
+                     int M, int Bp, int Mp, void* dY, bool pooled) {
     const int64_t n = (int64_t)T * Bp * Mp;
     if (dt == BF16)
         hipLaunchKernelGGL(train_dy_kernel<bf16_t>, dim3(blocks256(n)), dim3(256), 0, stream, pred, target, scal, n_rows, T, Tp, M, Bp, Mp,
-                           static_cast<bf16_t*>(dY));
+                           static_cast<bf16_t*>(dY), pooled ? 1 : 0);
     else
         hipLaunchKernelGGL(train_dy_kernel<float>, dim3(blocks256(n)), dim3(256), 0, stream, pred, target, scal, n_rows, T, Tp, M, Bp, Mp,
-                           static_cast<float*>(dY));
+                           static_cast<float*>(dY), pooled ? 1 : 0);
 }
 
 void launch_adam_matrix(hipStream_t stream, int dt, const float* grad, int nblk, int R, int C, int Rp, int Cp, double* x, double* am,

@@ -140,6 +140,9 @@ class HipPlanner:
             self._dims.update({"embedder": (lay_e, hid_e, "post_linear" if self._emb_post else "linear_mapping"), "embedder_in": self.M})
         self.set_weights(pred_sd, emb_sd)
         if self.has_tube:
+            self._dims.update({"cp_tube": (lay_u, hid_u, "post_linear"), "cp_tube_in": self.C,
+                               "tube_mel": (lay_m, hid_m, "post_linear"), "tube_mel_in": self.U,
+                               "tube_embedder": (lay_e2, hid_e2, "linear_mapping"), "tube_embedder_in": self.U})
             self.set_tube_weights(*tube_sds)
         if inv_sd is not None:
             self._dims.update({"inverse": (lay_i, hid_i, "post_linear"), "inverse_in": 3 * self.M})
@@ -264,9 +267,11 @@ class HipPlanner:
         pred = model == "pred"
         if model == "embedder" and not self.has_embedder:
             raise ValueError("this engine has no embedder")
-        model_id = _capi.PL_MODEL_PRED if pred else _capi.PL_MODEL_EMBED
-        if model not in ("pred", "embedder"):
-            raise ValueError("model has to be 'pred' or 'embedder'")
+        ids = {"pred": _capi.PL_MODEL_PRED, "embedder": _capi.PL_MODEL_EMBED, "cp_tube": _capi.PL_MODEL_CP_TUBE,
+               "tube_mel": _capi.PL_MODEL_TUBE_MEL, "tube_embedder": _capi.PL_MODEL_TUBE_EMBED}
+        if model not in ids or model not in self._dims:
+            raise ValueError("model has to be 'pred', 'embedder' or (with tube_models=) 'cp_tube', 'tube_mel', 'tube_embedder'")
+        model_id = ids[model]
         n_layers, H, lin = self._dims[model]
         sd = {}
         for l in range(n_layers):
@@ -276,7 +281,8 @@ class HipPlanner:
             self._call(self.lib.pl_get_lstm_weights, model_id, l, *[t.data_ptr() for t in ts])
             for k, t in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), ts):
                 sd[f"lstm.{k}_l{l}"] = t
-        out = self.M if pred else (self._emb_post or self.S)   # the linear that reads the LSTM output
+        out = {"pred": self.M, "cp_tube": getattr(self, "U", 0), "tube_mel": self.M, "tube_embedder": self.S}.get(
+            model, getattr(self, "_emb_post", 0) or self.S)   # the linear that reads the LSTM output
         w = torch.empty((out, H), dtype=torch.float32, device=self.device)
         b = torch.empty((out,), dtype=torch.float32, device=self.device)
         self._call(self.lib.pl_get_linear, model_id, w.data_ptr(), b.data_ptr())
@@ -308,6 +314,36 @@ class HipPlanner:
         self._call(self.lib.pl_train_pred_step, n, t, cp.data_ptr(), mel.data_ptr(), C.c_float(lr), C.c_float(betas[0]),
                    C.c_float(betas[1]), C.c_float(eps), loss.data_ptr())
         self._keep = (cp, mel)   # the launches are asynchronous: keep the operands alive until the next call
+        return loss
+
+    _TRAINABLE = {"pred": _capi.PL_MODEL_PRED, "cp_tube": _capi.PL_MODEL_CP_TUBE, "tube_mel": _capi.PL_MODEL_TUBE_MEL}
+
+    def train_model_step(self, model, inputs, target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        """One Adam step of ``model`` in ("pred", "cp_tube", "tube_mel") on a mini-batch (paule/paule.py:1372-1377, :1386-1404):
+        pred: cp (n, t, cp_dim) -> mel (n, t/2, mel_dim); cp_tube: cp -> tube (n, t, tube_dim); tube_mel: tube -> mel (n, t/2,
+        mel_dim).  RMSE over the whole batch; returns the loss as a 0-d device tensor."""
+        if model not in self._TRAINABLE or (model != "pred" and not self.has_tube):
+            raise ValueError("model has to be 'pred' or (with tube_models=) 'cp_tube' / 'tube_mel'")
+        x = self._dev(inputs)
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        n, t = int(x.shape[0]), int(x.shape[1])
+        if not 1 <= n <= self.train_capacity:
+            raise ValueError(f"mini-batch of {n} samples does not fit an engine built for batch {self.B} "
+                             f"({self.train_capacity} rows with padding)")
+        if not 2 <= t <= self.T:
+            raise ValueError(f"samples of {t} frames do not fit an engine built for {self.T} frames")
+        in_dim = self.U if model == "tube_mel" else self.C
+        out_shape = (n, t, self.U) if model == "cp_tube" else (n, t // 2, self.M)
+        x = self._dev(x, (n, t, in_dim))
+        y = self._dev(target)
+        if y.dim() == 2:
+            y = y.unsqueeze(0)
+        y = self._dev(y, out_shape)
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_train_model_step, self._TRAINABLE[model], n, t, x.data_ptr(), y.data_ptr(), C.c_float(lr),
+                   C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), loss.data_ptr())
+        self._keep = (x, y)   # the launches are asynchronous: keep the operands alive until the next call
         return loss
 
     def reset_pred_optimizer(self):

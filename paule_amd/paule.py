@@ -270,16 +270,24 @@ class Paule():
         return [idxs[i * batch_size:(i + 1) * batch_size] for i in range(len(idxs) // batch_size)]
 
     def _continue_learning_pred(self, planner, cp_steps_ii, prod_mel_steps_ii, *, n_batches, batch_size, n_epochs, lr,
-                                add_training_data_pred=False, target_semvec=None):
+                                add_training_data_pred=False, target_semvec=None, prod_tube_steps_ii=None, tube_losses=None):
         """Continued learning of ``pred_model`` after an outer iteration (paule/paule.py:1244-1320, :1353-1379, :1406,
         :1439-1443): the (cp, mel) pairs produced in this iteration -- with ``add_training_data_pred`` half of every batch comes
         from ``self.continue_data`` instead (:1250-1287) -- are sampled, sorted by length and cut into same-size mini-batches for
         ``n_epochs`` epochs; a batch is padded to its longest sample by repeating the last frame (``pad_batch_online``,
         paule/util.py:674-726) and is one ``pred_optimizer`` step on the device.  Returns the mean loss of every epoch
         (``pred_model_loss``).  With B > 1 every utterance of a logged step is one produced sample.  Afterwards
-        ``self.pred_model`` holds the trained parameters and ``self.continue_data`` has grown by the produced samples."""
+        ``self.pred_model`` holds the trained parameters and ``self.continue_data`` has grown by the produced samples.
+        ``prod_tube_steps_ii`` (continue_learning_tube, paule/paule.py:1381-1404): the produced tubes of the same samples; every
+        mini-batch then also is one step of the cp -> tube model (cp_norm -> tube_norm) and one of the tube -> mel model
+        (tube_norm -> melspec_norm_synthesized); their epoch means are appended to ``tube_losses`` (two lists)."""
         prod_cps = [np.asarray(x, dtype=np.float32) for c in cp_steps_ii for x in np.asarray(c).reshape(-1, *np.shape(c)[-2:])]
         prod_mels = [np.asarray(x, dtype=np.float32) for m in prod_mel_steps_ii for x in np.asarray(m).reshape(-1, *np.shape(m)[-2:])]
+        learn_tube = prod_tube_steps_ii is not None
+        prod_tubes = [np.asarray(x, dtype=np.float32) for u in (prod_tube_steps_ii or []) for x in np.asarray(u).reshape(-1, *np.shape(u)[-2:])]
+        if learn_tube and len(prod_tubes) != len(prod_cps):
+            raise ValueError("continue_learning_tube needs one produced tube per produced sample (tube_extractor)")
+        train_tubes = None
         n = len(prod_cps)
         records = None
         if self.continue_data is not None:
@@ -298,12 +306,18 @@ class Paule():
             train_cps = [np.asarray(records[i]["cp_norm"], dtype=np.float32) for i in pick_data] + [prod_cps[i] for i in pick_prod]
             train_mels = [np.asarray(records[i]["melspec_norm_synthesized"], dtype=np.float32) for i in pick_data] + \
                          [prod_mels[i] for i in pick_prod]
+            if learn_tube:                                                       # 'tube_norm' column, :1273
+                train_tubes = [np.asarray(records[i]["tube_norm"], dtype=np.float32) for i in pick_data] + [prod_tubes[i] for i in pick_prod]
         k = n if n < batch_size * n_batches else batch_size * n_batches           # :1289-1303 (drawn in either case)
         picked = random.sample(range(n), k=k)
         if train_cps is None:                                                     # :1310-1313
             train_cps, train_mels = [prod_cps[i] for i in picked], [prod_mels[i] for i in picked]
+            if learn_tube:
+                train_tubes = [prod_tubes[i] for i in picked]
         order = np.argsort([len(c) for c in train_cps], kind="stable")            # sort_values(by="lens_input"), :1283, :1308
         train_cps, train_mels = [train_cps[i] for i in order], [train_mels[i] for i in order]
+        if learn_tube:
+            train_tubes = [train_tubes[i] for i in order]
         lens = np.array([len(c) for c in train_cps])
         if batch_size > getattr(planner, "train_capacity", planner.B):
             raise ValueError(f"batch_size={batch_size} of continued learning exceeds the planner's rows ({planner.train_capacity})")
@@ -316,21 +330,35 @@ class Paule():
         grp = self.pred_optimizer.param_groups[0] if self.pred_optimizer is not None else {}
         lr = grp.get("lr", lr)
         losses = []
+        tube_grp = getattr(self.tube_optimizer, "param_groups", [{}])[0] if self.tube_optimizer is not None else {}
+        tmel_grp = getattr(self.tube_mel_optimizer, "param_groups", [{}])[0] if self.tube_mel_optimizer is not None else {}
         for _ in range(n_epochs):
             by_len = {int(l): np.where(lens == l)[0] for l in np.unique(lens)}    # :1313-1319 (rebuilt: shuffled in place)
             epoch = self.create_epoch_batches(len(lens), batch_size, shuffle=True, same_size_batching=True, training_length_dict=by_len)
-            step_losses = []
+            step_losses, tube_step, tmel_step = [], [], []
             for j in epoch:
                 cp_b = padded([train_cps[i] for i in j], max(len(train_cps[i]) for i in j))
                 mel_b = padded([train_mels[i] for i in j], max(len(train_mels[i]) for i in j))
                 if mel_b.shape[1] != cp_b.shape[1] // 2:
                     raise ValueError("a training batch's mel length has to be half its cp length (ForwardModel halves the sequence)")
                 step_losses.append(planner.train_pred_step(cp_b, mel_b, lr=lr, betas=grp.get("betas", (0.9, 0.999)), eps=grp.get("eps", 1e-8)))
+                if learn_tube:                                                   # :1381-1404, Adam(lr 0.001) each (:300, :305)
+                    tube_b = padded([train_tubes[i] for i in j], cp_b.shape[1])
+                    tube_step.append(planner.train_model_step("cp_tube", cp_b, tube_b, lr=tube_grp.get("lr", 0.001),
+                                                              betas=tube_grp.get("betas", (0.9, 0.999)), eps=tube_grp.get("eps", 1e-8)))
+                    tmel_step.append(planner.train_model_step("tube_mel", tube_b, mel_b, lr=tmel_grp.get("lr", 0.001),
+                                                              betas=tmel_grp.get("betas", (0.9, 0.999)), eps=tmel_grp.get("eps", 1e-8)))
             losses.append(float(np.mean([float(x) for x in step_losses])))
+            if learn_tube and tube_losses is not None:                           # :1407-1409
+                tube_losses[0].append(float(np.mean([float(x) for x in tube_step])))
+                tube_losses[1].append(float(np.mean([float(x) for x in tmel_step])))
         if self.continue_data is not None:                                        # :1439-1443
             vec = None if target_semvec is None else np.asarray(target_semvec)
             new = [{"vector": None if vec is None else vec[min(i % max(len(vec), 1), len(vec) - 1)].copy(), "cp_norm": c,
                     "melspec_norm_synthesized": m, "segment_data": False} for i, (c, m) in enumerate(zip(prod_cps, prod_mels))]
+            if prod_tubes:                                                       # :1251
+                for rec, u in zip(new, prod_tubes):
+                    rec["tube_norm"] = u
             if hasattr(self.continue_data, "to_dict"):
                 import pandas as pd
                 data = pd.concat([self.continue_data, pd.DataFrame(new)]).reset_index(drop=True)
@@ -356,6 +384,16 @@ class Paule():
                 self.pred_model.load_state_dict(new)
             else:
                 self.pred_model.update(new)
+        if learn_tube:                       # the trained tube models back into the instance, like pred_model
+            for attr, name in (("cp_tube_model", "cp_tube"), ("tube_mel_model", "tube_mel")):
+                cur = getattr(self, attr)
+                sd = planner.get_weights(name)
+                ref = cur.state_dict() if hasattr(cur, "state_dict") else cur
+                new = {k_: torch.as_tensor(v).to(device=ref[k_].device, dtype=ref[k_].dtype) for k_, v in sd.items()}
+                if hasattr(cur, "load_state_dict"):
+                    cur.load_state_dict(new)
+                else:
+                    cur.update(new)
         return losses
 
     def plan_resynth(self, *, learning_rate_planning=0.01, learning_rate_learning=0.001,
@@ -459,8 +497,8 @@ class Paule():
             if objective == "acoustic":
                 raise NotImplementedError("use_somatosensory_feedback with objective='acoustic': the reference's criterion fails there "
                                           "(unassigned pred_tube_semvec, paule/paule.py:692); use 'acoustic_semvec' or 'semvec'")
-            if continue_learning_tube:
-                raise NotImplementedError("continue_learning_tube is not on the MI355X planning path")
+            if continue_learning_tube and self.tube_extractor is None:
+                raise NotImplementedError("continue_learning_tube needs tube_extractor= (the produced tubes are the training targets)")
             tube_kw = dict(tube_models=(self.cp_tube_model, self.tube_mel_model, self.tube_embedder))
         if initial_cp is None:
             if initialize_from == "acoustic":
@@ -747,7 +785,9 @@ class Paule():
                     pred_model_loss.extend(self._continue_learning_pred(
                         planner, cp_steps_ii, prod_mel_steps_ii, n_batches=n_batches, batch_size=batch_size,
                         n_epochs=n_epochs, lr=learning_rate_learning or 0.001, add_training_data_pred=add_training_data_pred,
-                        target_semvec=target_semvec))
+                        target_semvec=target_semvec,
+                        prod_tube_steps_ii=prod_tube_steps_ii if (soma and continue_learning_tube) else None,
+                        tube_losses=(tube_model_loss, tube_mel_model_loss)))
                 elif ii_outer == 0:
                     warnings.warn("continue_learning=True but nothing was synthesised (no synthesizer / mel_extractor): the "
                                   "predictive model is kept fixed", stacklevel=2)

@@ -60,6 +60,21 @@ class OracleEngine:
         self._build()
         return loss
 
+    def train_model_step(self, model, inputs, target, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        if model == "pred":
+            return self.train_pred_step(inputs, target, lr=lr, betas=betas, eps=eps)
+        idx = {"cp_tube": 0, "tube_mel": 1}[model]
+        trainers = self.__dict__.setdefault("tube_trainers", {})
+        if model not in trainers:
+            trainers[model] = op.OracleTrainer(op.forward_model_from_state_dict(self.tube_sds[idx], apply_half_sequence=(idx == 1)),
+                                               lr=lr, betas=betas, eps=eps)
+        for grp in trainers[model].optimizer.param_groups:
+            grp["lr"] = lr
+        loss = trainers[model].train_pred_step(np.asarray(inputs), np.asarray(target))
+        self.tube_sds[idx] = trainers[model].state_dict()
+        self._build()
+        return loss
+
     def _ensure_trainer(self, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
         if getattr(self, "trainer", None) is None:
             self.trainer = op.OracleTrainer(op.forward_model_from_state_dict(self.pred_sd), lr=lr, betas=betas, eps=eps)
@@ -77,6 +92,8 @@ class OracleEngine:
             self.trainer.optimizer.load_state_dict(sd)
 
     def get_weights(self, model="pred"):
+        if model in ("cp_tube", "tube_mel", "tube_embedder"):
+            return dict(self.tube_sds[("cp_tube", "tube_mel", "tube_embedder").index(model)])
         return dict(self.pred_sd if model == "pred" else self.emb_sd)
 
     def set_weights(self, pred_model=None, embedder=None):

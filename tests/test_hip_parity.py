@@ -561,6 +561,41 @@ def test_paule_somatosensory_hip_equals_oracle_engine(golden_soma):
         np.testing.assert_allclose(a, b, atol=2e-4, rtol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_tube_models_training_steps_vs_oracle(HipPlanner, golden_soma, dtype):
+    """continue_learning_tube (paule/paule.py:1381-1404): Adam steps of the cp -> tube model (no half sequence) and of the
+    tube -> mel model on the device (pl_train_model_step) against torch autograd + torch.optim.Adam on the CPU: step losses,
+    the trained parameters, and the tube predictions the planner then makes with them."""
+    from oracle import planner as op
+    g = golden_soma
+    eng = _soma_engine(HipPlanner, g, "acoustic_semvec", dtype=dtype)
+    rng = np.random.default_rng(3)
+    cps = g["cp0"].astype(np.float32)
+    tubes = (g["fwd/pred_tube"] + 0.2 * rng.standard_normal(g["fwd/pred_tube"].shape)).astype(np.float32)
+    mels = g["target_mel"].astype(np.float32)
+    tr_u = op.OracleTrainer(op.forward_model_from_state_dict(state_dict_from(g, "cp_tube"), apply_half_sequence=False))
+    tr_m = op.OracleTrainer(op.forward_model_from_state_dict(state_dict_from(g, "tube_mel")))
+    sched = [[0, 1, 2], [1], [2, 0], [0, 1, 2]]
+    lh, lo = [], []
+    for j in sched:
+        lh.append((float(eng.train_model_step("cp_tube", cps[j], tubes[j])), float(eng.train_model_step("tube_mel", tubes[j], mels[j]))))
+        lo.append((float(tr_u.train_pred_step(cps[j], tubes[j])), float(tr_m.train_pred_step(tubes[j], mels[j]))))
+    f32 = dtype == "f32"
+    np.testing.assert_allclose(np.array(lh), np.array(lo), rtol=1e-5 if f32 else 2e-2)
+    for name, tr in (("cp_tube", tr_u), ("tube_mel", tr_m)):
+        got, want = eng.get_weights(name), tr.state_dict()
+        for k in want:
+            d = np.abs(_n(got[k]) - _n(want[k]))
+            # Adam moves a parameter by at most ~lr per step: f32 has to agree far inside that, bf16 within the budget
+            assert d.max() <= (2e-5 if f32 else 1.0 * 1e-3 * len(sched)), (name, k, d.max())
+    if f32:
+        with torch.no_grad():
+            want_tube = tr_u.pred_model(torch.from_numpy(g["cp0"]))
+        np.testing.assert_allclose(_n(eng.get_tube_pred()[0]), _n(want_tube), atol=5e-5, rtol=0)
+    with pytest.raises(ValueError, match="model_id"):
+        eng._call(eng.lib.pl_train_model_step, 5, 1, 4, 1, 1, 0.001, 0.9, 0.999, 1e-8, None)
+
+
 def test_paule_initialize_from_acoustic_hip(golden_inverse):
     """Paule.plan_resynth(initialize_from='acoustic') with the inverse model on the device: initial_cp equals the reference's
     clipped inverse output, and the plan starts from it."""

@@ -336,6 +336,30 @@ def test_somatosensory_feedback_on_the_planner(golden_soma):
         pp.Paule(pred_model=g, embedder=g, use_somatosensory_feedback=True, use_speech_classifier=True, planner_factory=factory)
 
 
+def test_continue_learning_tube_on_the_planner(golden_soma):
+    """continue_learning_tube=True (paule/paule.py:1381-1409): every mini-batch of the continued learning also trains the
+    cp -> tube and the tube -> mel model on the produced tubes; epoch means land in tube_model_loss / tube_mel_model_loss, the
+    instance's models change, produced samples carry 'tube_norm'."""
+    g = golden_soma
+    factory = lambda pm, em, **kw: OracleEngine(pm, em, **kw)
+    rng = np.random.default_rng(0)
+    model = _soma_paule(g, factory, torch.device("cpu"), tube_extractor=lambda cp: 0.3 * rng.standard_normal(cp.shape[:2] + (10,)),
+                        synthesizer=lambda cp: (np.zeros(100), 44100), mel_extractor=lambda sig, sr: np.full((20, 60), 0.25),
+                        continue_data=[])
+    before = {k: v.clone() for k, v in model.cp_tube_model.items()}
+    res = model.plan_resynth(target_acoustic=g["target_mel"][:2], target_semvec=g["target_semvec"][:2], initial_cp=g["cp0"][:2],
+                             initialize_from=None, objective="acoustic_semvec", n_outer=2, n_inner=4, log_ii=2, continue_learning=True,
+                             continue_learning_tube=True, n_batches=2, batch_size=2, n_epochs=3, seed=3, verbose=False)
+    assert len(res.tube_model_loss) == 2 * 3 and len(res.tube_mel_model_loss) == 2 * 3 and len(res.pred_model_loss) == 2 * 3
+    assert all(np.isfinite(res.tube_model_loss)) and res.tube_model_loss[-1] < res.tube_model_loss[0]
+    assert any(not torch.equal(torch.as_tensor(model.cp_tube_model[k]), before[k]) for k in before)
+    assert all("tube_norm" in rec and rec["tube_norm"].shape == (40, 10) for rec in model.continue_data)
+    with pytest.raises(NotImplementedError, match="tube_extractor"):
+        _soma_paule(g, factory, torch.device("cpu")).plan_resynth(
+            target_acoustic=g["target_mel"][:2], target_semvec=g["target_semvec"][:2], initial_cp=g["cp0"][:2], initialize_from=None,
+            objective="semvec", n_outer=1, n_inner=2, continue_learning=True, continue_learning_tube=True, verbose=False)
+
+
 def test_speech_classifier_config(small):
     """minimal_example.py's configuration (use_speech_classifier=True, acoustic_semvec; docs/examples/minimal_example.py:13-47)."""
     clf = {"linear.weight": torch.full((1, 60), 0.05, dtype=torch.float64), "linear.bias": torch.tensor([0.3], dtype=torch.float64)}
