@@ -65,6 +65,9 @@ struct LstmSweepArgs {
     // state (forward: c, backward: dL/dc) crosses the chunk border through `carry` [Bp][Hp] f32.
     int t0, t1;
     float* carry;
+    // f32 kernels: 1 .. 4 = that many batch rows are in use and the batch is one group: the recurrent products run as
+    // f32 FMAs on those rows only (the 16x16x4 MFMA costs the same for 1 row as for 16 and bounds the step); 0 = MFMA
+    int n_valid;
     int stash_via_lds;     // forward, 32-row kernel: 1 = the five stash arrays leave through LDS as 64-byte row pieces
 };
 bool lstm_sweep_supported(int dt, int Hp);

@@ -37,10 +37,64 @@ __device__ __forceinline__ void st16_handoff(__amdgpu_buffer_rsrc_t r, unsigned 
     else __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, kAuxSc1);
 }
 
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+__device__ __forceinline__ void st4_handoff(__amdgpu_buffer_rsrc_t r, unsigned off, float v, bool plain) {
+    if (plain) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, kAuxSc1);
+}
+
+// Few-row forward product (1 <= NB <= 4 batch rows in use): lane (r = lane & 15, kq = lane >> 4) holds gate row r of its wave at
+// k = 16 s + 4 kq .. + 3 (the MFMA A fragment), so the recurrent product of batch row b is a per-lane FMA chain over s and a
+// sum over the four kq lanes.  vimg [wave][b][r] hands the sums over to the epilogue layout (lane bl = batch row, kq = unit
+// slot, the four gates of that unit): returns them, zero for lanes whose batch row is not in use.
+template <int NB, int KS, int KSX>
+__device__ __forceinline__ f32x4 fwd_rows_valu(const float4 (&wreg)[KS], const float4* wx, const unsigned char* himg, int RS, bool have_h,
+                                               const unsigned char* ximg, int XRS, float* vimg, int lane, int wave) {
+    const int kq = lane >> 4, r = lane & 15;
+    float pv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pv[b] = 0.f;
+    if (have_h) {
+        float part[NB][4];   // four independent chains per row (fixed order: deterministic)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[b][j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) part[b][s & 3] += dot4(wreg[s], *reinterpret_cast<const float4*>(himg + b * RS + s * 64 + kq * 16));
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) pv[b] = (part[b][0] + part[b][1]) + (part[b][2] + part[b][3]);
+    }
+    if constexpr (KSX > 0) {
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) pv[b] += dot4(wx[s], *reinterpret_cast<const float4*>(ximg + b * XRS + s * 64 + kq * 16));
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        pv[b] += __shfl_xor(pv[b], 16, 64);
+        pv[b] += __shfl_xor(pv[b], 32, 64);
+        if (kq == 0) vimg[(wave * 4 + b) * 16 + r] = pv[b];
+    }
+    __syncthreads();
+    f32x4 out = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < NB) {   // r doubles as the batch row of the epilogue layout
+        const float4 v = *reinterpret_cast<const float4*>(vimg + (wave * 4 + r) * 16 + 4 * kq);
+        out = f32x4{v.x, v.y, v.z, v.w};
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward sweep (all-gather of h); KSX > 0: input projection fused (in_p = 16 * KSX = 32 / 64)
 // ---------------------------------------------------------------------------------------------------
-template <int KS, int KSX>   // KS = Hp / 16
+template <int KS, int KSX, int NV>   // KS = Hp / 16; NV > 0: that many batch rows in use, products as FMA chains (one group only)
 __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
     constexpr int ROWB = Hp * 4;                 // bytes of one h row
@@ -64,6 +118,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
     const int n_groups = (Bp + 15) / 16;         // Bp is a multiple of 16: groups are whole
     const float* __restrict__ W = static_cast<const float*>(a.W);
     const int kq = lane >> 4;
+    constexpr int nv = NV;
 
     // weights -> registers: A row r (= lane & 15): unit slot r >> 2, gate r & 3
     float4 wreg[KS];
@@ -125,20 +180,22 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
                 if (t == t_begin + 1 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
                 const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t - 1) * slabH, (unsigned)(slabH * 4));
+                const int n_chunks = (nv ? nv : 16) * CPR;   // the few-row path reads the rows in use only
                 uint4 v[NLD];
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
                     const int e = tid + 256 * i;
-                    v[i] = (e < 16 * CPR) ? ld16_ho(rh, (unsigned)((16 * g + e / CPR) * ROWB + (e % CPR) * 16), plain_handoff)
+                    v[i] = (e < n_chunks) ? ld16_ho(rh, (unsigned)((16 * g + e / CPR) * ROWB + (e % CPR) * 16), plain_handoff)
                                           : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
                     const int e = tid + 256 * i;
-                    if (e < 16 * CPR) *reinterpret_cast<uint4*>(himg + (e / CPR) * RS + (e % CPR) * 16) = v[i];
+                    if (e < n_chunks) *reinterpret_cast<uint4*>(himg + (e / CPR) * RS + (e % CPR) * 16) = v[i];
                 }
                 __syncthreads();
                 PL_ST(2);
+                if constexpr (NV == 0) {
                 const unsigned char* bsrc = himg + bl * RS + kq * 16;
                 float4 bq[PF];
 #pragma unroll
@@ -151,8 +208,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
                     if (s + PF < KS) bq[s % PF] = *reinterpret_cast<const float4*>(bsrc + (s + PF) * 64);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }
             }
-            if constexpr (KSX > 0) {
+            if constexpr (NV > 0) {   // few rows in use: FMA chains instead of the MFMAs (recurrent and, if fused, input product)
+                float* vimg = reinterpret_cast<float*>(hst);   // the staging image is free until the cell update below
+                const f32x4 add = fwd_rows_valu<NV, KS, KSX>(wreg, wx, himg, RS, t > 0, ximg, XRS, vimg, lane, wave);
+                acc[0] += add[0]; acc[1] += add[1]; acc[2] += add[2]; acc[3] += add[3];
+                __syncthreads();   // vimg (= hst) is written again by the cell update
+            } else if constexpr (KSX > 0) {
 #pragma unroll
                 for (int s = 0; s < KSX; ++s)
                     acc = mfma4(wx[s], *reinterpret_cast<const float4*>(ximg + bl * XRS + s * 64 + kq * 16), acc);
@@ -208,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
 // ---------------------------------------------------------------------------------------------------
 // backward sweep, reduce-scatter of f32 partial dh tiles (backward-DATA only)
 // ---------------------------------------------------------------------------------------------------
-template <int KS>
+template <int KS, int NV>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
     constexpr int P = KS;                        // workgroups per group = N tiles of 16 hidden units
@@ -226,6 +289,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
     const int n_groups = (Bp + 15) / 16;
     const float* __restrict__ WT = static_cast<const float*>(a.W);   // Whh^T packed [Hp][4*Hp]
     const int kq = lane >> 4;
+    constexpr int nv = NV;
 
     // weights -> registers: tile nt = wave + 4 i: A row = hidden column n = 16 nt + (lane & 15); chunk c = gate c:
     // k = 4 kq + e  <->  gate row c * Hp + 16 p + 4 kq + e
@@ -336,11 +400,31 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
             }
             __syncthreads();
             PL_ST(3);
+            float* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 4));
+            if constexpr (NV > 0) {
+                // few rows in use: lane (n = lane & 15, kq) holds column 16 nt + n of W^T at k = 16 c + 4 kq .. + 3 (the MFMA A
+                // fragment): partial[n][b] is a per-lane FMA chain over the four gates and a sum over the four kq lanes; the
+                // rows not in use keep the zeros the exchange was allocated with
+#pragma unroll
+                for (int b = 0; b < nv; ++b) {
+                    float4 d4[4];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) d4[c4] = *reinterpret_cast<const float4*>(da_img + b * DRS + c4 * 64 + kq * 16);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const int nt = wave + 4 * i;
+                        if (nt >= P) break;
+                        float q = dot4(wreg[i][0], d4[0]) + dot4(wreg[i][1], d4[1]) + dot4(wreg[i][2], d4[2]) + dot4(wreg[i][3], d4[3]);
+                        q += __shfl_xor(q, 16, 64);
+                        q += __shfl_xor(q, 32, 64);
+                        if (kq == 0) st4_handoff(ro, (unsigned)(((size_t)nt * P * TILE + b * 16 + (lane & 15)) * 4), q, plain_handoff);
+                    }
+                }
+            } else {
             float4 bfr[4];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) bfr[c4] = *reinterpret_cast<const float4*>(da_img + (lane & 15) * DRS + c4 * 64 + kq * 16);
-            float* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 4));
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
@@ -352,6 +436,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
                 st16_handoff(ro, (unsigned)(((size_t)nt * P * TILE + (lane & 15) * 16 + 4 * kq) * 4),
                              make_float4(acc[0], acc[1], acc[2], acc[3]), plain_handoff);
             }
+            }
             PL_ST(4);
             publish<0>(cnt + (size_t)t * a.flag_stride + p, plain_handoff);
             PL_ST(6);
@@ -362,6 +447,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
 }
 
 // ---------------------------------------------------------------------------------------------------
+#ifndef PL_F32_FEW_ROWS
+#define PL_F32_FEW_ROWS 1
+#endif
 #define PL_SWEEP_F32_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
 
 bool lstm_sweep_f32_supported(int Hp) {
@@ -389,15 +477,27 @@ size_t lstm_f32_exchange_bytes(int Hp, int Bp) {
     return 2 * groups * P * P * 16 * 16 * 4;
 }
 
+// rows in use for the few-row FMA kernels (0 = MFMA kernels): one group with ONE row in use (B = 1, the reference's operating
+// point: 6.84 -> 5.52 ms per iteration; two rows already lose against the MFMA kernels, 7.16 vs 6.85 ms)
+static int few_rows(const LstmSweepArgs& a) { return (a.Bp == 16 && a.n_valid >= 1 && a.n_valid <= PL_F32_FEW_ROWS) ? a.n_valid : 0; }
+
+template <int K, int NV>
+static void launch_f32_nv(hipStream_t stream, bool backward, int ksx, int grid, const LstmSweepArgs& a) {
+    if (backward) hipLaunchKernelGGL((lstm_bwd_sweep_f32_kernel<K, NV>), dim3(grid), dim3(256), 0, stream, a);
+    else if (ksx == 2) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 2, NV>), dim3(grid), dim3(256), 0, stream, a);
+    else if (ksx == 4) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 4, NV>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 0, NV>), dim3(grid), dim3(256), 0, stream, a);
+}
+
 void launch_lstm_sweep_f32(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a) {
     const int ksx = (!backward && a.x_in) ? a.in_p / 16 : 0;
-#define PL_CASE(K)                                                                                                      \
-    if (Hp == 16 * K) {                                                                                                 \
-        if (backward) hipLaunchKernelGGL(lstm_bwd_sweep_f32_kernel<K>, dim3(grid), dim3(256), 0, stream, a);            \
-        else if (ksx == 2) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 2>), dim3(grid), dim3(256), 0, stream, a);  \
-        else if (ksx == 4) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a);  \
-        else hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 0>), dim3(grid), dim3(256), 0, stream, a);                \
-        return;                                                                                                         \
+    const int nv = few_rows(a);
+#define PL_CASE(K)                                                                   \
+    if (Hp == 16 * K) {                                                              \
+        if (nv == 1) launch_f32_nv<K, 1>(stream, backward, ksx, grid, a);            \
+        else if (nv == 2) launch_f32_nv<K, 2>(stream, backward, ksx, grid, a);       \
+        else launch_f32_nv<K, 0>(stream, backward, ksx, grid, a);                    \
+        return;                                                                      \
     }
     PL_SWEEP_F32_KS_LIST(PL_CASE)
 #undef PL_CASE

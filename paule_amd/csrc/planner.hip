@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <unordered_map>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -200,15 +201,22 @@ struct pl_handle {
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
     bool wide_ingest = true;    // PAULE_HIP_WIDE_INGEST: f32 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool wide_ingest16 = true;  // PAULE_HIP_WIDE_INGEST16: 16-row bf16 backward sweep sums the partial tiles with 16-byte loads, wave by wave
+    bool f32_valu = true;       // PAULE_HIP_F32_VALU: f32 sweeps of at most 4 rows in use run their recurrent products as FMA chains
+    int rows_in_use = 0;        // batch rows that carry data (B); 0 inside pl_train_model_step (few-row kernels off)
     int wavefront = 4;          // PAULE_HIP_WAVEFRONT = time chunks (0 off): small sweeps run the layers of a model side by side, layer l + 1
                                 // on chunk c while layer l is on chunk c + 1 (model_forward_wavefront)
     int wf_dirs = 3;            // PAULE_HIP_WF_DIRS: bit 0 forward, bit 1 backward (experiments)
-    std::vector<hipStream_t> wf_streams;   // layer streams: every wavefront region of an iteration takes its own (HIP's capture does not
-                                           // survive a stream that is forked, joined and forked again with others in one capture)
-    size_t wf_stream_next = 0;
+    // graph mode: the wavefront is captured on ONE stream (a chain of nodes) and its edges are rewritten before the graph is
+    // instantiated (build_graph): multi-stream capture crashed inside hipStreamEndCapture about once in a hundred captures
+    // (tools/microbench/capture_stress.py), single-stream capture never did
+    struct WfSeg { hipGraphNode_t before, last; int dep1, dep2; };   // chain neighbours of a (layer, chunk) segment; true dependencies
+    struct WfRegion { std::vector<WfSeg> segs; std::vector<int> finals; };
+    std::vector<WfRegion> wf_regions;
+    bool capturing = false;
+    size_t wf_stream_next = 0;  // cursor into the device's pool of layer streams: every wavefront region of an iteration takes its own
+                                // (HIP's capture does not survive a stream that is forked, joined and forked again with others)
     bool wf_on = false;
-    std::vector<hipEvent_t> wf_pool;   // events of the (layer, chunk) dependencies: none is recorded twice inside one iteration
-    size_t wf_next = 0;
+    size_t wf_next = 0;         // cursor into the device's pool of events ((layer, chunk) dependencies: none is recorded twice inside one iteration)
     bool sweep16 = true;        // PAULE_HIP_SWEEP16: 16-row groups for bf16 batches of up to 128 rows (lstm_persist16.hip)
     bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
                                 // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
@@ -381,6 +389,7 @@ void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, 
             s.c = ly.c;
             if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
             s.stash_via_lds = h->stash_lds ? 1 : 0;
+            s.n_valid = (h->dt == F32 && h->f32_valu) ? h->rows_in_use : 0;
             s.counters = take_sweep_slice(h, st);
             s.flag_stride = h->flag_stride;
             s.xcc_tab = s.counters + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
@@ -440,6 +449,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.c = ly.c;
             s.dh_ext = sparse_top ? nullptr : md.dh_ext;
             s.dh_last = sparse_top ? dh_last : nullptr;
+            s.n_valid = (h->dt == F32 && h->f32_valu) ? h->rows_in_use : 0;
             s.counters = take_sweep_slice(h, st);
             s.flag_stride = h->flag_stride;
             s.xcc_tab = s.counters + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
@@ -528,22 +538,41 @@ int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb) {
     return nc >= 2 ? nc : 0;
 }
 
+// Layer streams and events live in one pool per device for the life of the process (callers hold the device's SweepChain
+// mutex): hipStreamEndCapture crashed (segmentation fault inside the runtime, reproducible with
+// tools/microbench/capture_stress.py) once streams that had taken part in an earlier capture had been destroyed with their
+// handle and new ones were created for the next capture.  A handle only keeps cursors into the pool.
+std::vector<hipStream_t>& wf_stream_pool(int dev) { static std::vector<hipStream_t> p[SweepChain::kMaxDev]; return p[dev]; }
+std::vector<hipEvent_t>& wf_event_pool(int dev) { static std::vector<hipEvent_t> p[SweepChain::kMaxDev]; return p[dev]; }
+
 hipStream_t wavefront_stream(pl_handle* h) {
-    if (h->wf_stream_next == h->wf_streams.size()) {
+    auto& pool = wf_stream_pool(h->cfg.device);
+    if (h->wf_stream_next == pool.size()) {
         hipStream_t q = nullptr;
         (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
-        h->wf_streams.push_back(q);
+        pool.push_back(q);
     }
-    return h->wf_streams[h->wf_stream_next++];
+    return pool[h->wf_stream_next++];
 }
 
 hipEvent_t wavefront_event(pl_handle* h) {
-    if (h->wf_next == h->wf_pool.size()) {
+    auto& pool = wf_event_pool(h->cfg.device);
+    if (h->wf_next == pool.size()) {
         hipEvent_t e = nullptr;
         (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        h->wf_pool.push_back(e);
+        pool.push_back(e);
     }
-    return h->wf_pool[h->wf_next++];
+    return pool[h->wf_next++];
+}
+
+// last node the capturing stream has recorded so far (null at the very start of the capture)
+hipGraphNode_t capture_tail(hipStream_t st) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    const hipGraphNode_t* deps = nullptr;
+    size_t n = 0;
+    if (hipStreamGetCaptureInfo_v2(st, &status, nullptr, nullptr, &deps, &n) != hipSuccess || status != hipStreamCaptureStatusActive || n == 0)
+        return nullptr;
+    return deps[n - 1];
 }
 
 void fill_sweep_common(pl_handle* h, LstmSweepArgs& s, int Tl, int* slice) {
@@ -557,6 +586,7 @@ void fill_sweep_common(pl_handle* h, LstmSweepArgs& s, int Tl, int* slice) {
     s.status = h->sweep_status;
     s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
     s.stamps = nullptr;
+    s.n_valid = (h->dt == F32 && h->f32_valu) ? h->rows_in_use : 0;
 }
 
 // layers lb .. le-1 (le - lb <= 8) of the model as one wavefront of nc time chunks
@@ -567,16 +597,20 @@ void model_forward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void
     int* slice[8];
     hipEvent_t ev[8] = {};   // ev[i]: layer lb + i finished its latest chunk
     hipStream_t ls[8];
+    const bool cap = h->capturing;   // graph capture: everything on st, dependencies rewritten afterwards (build_graph)
+    const int nl = le - lb;
+    if (cap) h->wf_regions.emplace_back();
     for (int l = lb; l < le; ++l) {
         slice[l - lb] = take_sweep_slice(h, st);
-        ls[l - lb] = l == lb ? st : wavefront_stream(h);
+        ls[l - lb] = (l == lb || cap) ? st : wavefront_stream(h);
     }
     for (int c = 0; c < nc; ++c) {
         const int t0 = (int)((long long)c * Tl / nc), t1 = (int)((long long)(c + 1) * Tl / nc);
         for (int l = lb; l < le; ++l) {
             LstmLayer& ly = md.layers[l];
             hipStream_t sl = ls[l - lb];
-            if (l > lb) (void)hipStreamWaitEvent(sl, ev[l - 1 - lb], 0);
+            pl_handle::WfSeg seg{cap ? capture_tail(st) : nullptr, nullptr, l > lb ? c * nl + (l - 1 - lb) : -1, c > 0 ? (c - 1) * nl + (l - lb) : -1};
+            if (l > lb && !cap) (void)hipStreamWaitEvent(sl, ev[l - 1 - lb], 0);
             const void* cur_in = l == 0 ? in_act : md.layers[l - 1].h;
             const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
             if (!fuse_in)
@@ -589,13 +623,18 @@ void model_forward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void
             s.stash_via_lds = h->stash_lds ? 1 : 0;
             s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
             launch_sweep(h, sl, false, Hp, grid, s);
-            if (l < le - 1 || c == nc - 1) {
+            if (cap) {
+                seg.last = capture_tail(st);
+                h->wf_regions.back().segs.push_back(seg);
+                if (c == nc - 1) h->wf_regions.back().finals.push_back(c * nl + (l - lb));
+            } else if (l < le - 1 || c == nc - 1) {
                 ev[l - lb] = wavefront_event(h);
                 (void)hipEventRecord(ev[l - lb], sl);
             }
         }
     }
-    for (int l = lb + 1; l < le; ++l) (void)hipStreamWaitEvent(st, ev[l - lb], 0);   // join
+    if (!cap)
+        for (int l = lb + 1; l < le; ++l) (void)hipStreamWaitEvent(st, ev[l - lb], 0);   // join
 }
 
 void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn, int Tl, int nc, int lb, int le) {
@@ -605,16 +644,22 @@ void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const voi
     int* slice[8];
     hipEvent_t ev[8] = {};   // ev[i]: layer lb + i finished its latest chunk, projection included
     hipStream_t ls[8];
+    const bool cap = h->capturing;   // graph capture: everything on st, dependencies rewritten afterwards (build_graph)
+    const int nl = le - lb;
+    if (cap) h->wf_regions.emplace_back();
     for (int l = top; l >= lb; --l) {
         slice[l - lb] = take_sweep_slice(h, st);
-        ls[l - lb] = l == top ? st : wavefront_stream(h);
+        ls[l - lb] = (l == top || cap) ? st : wavefront_stream(h);
     }
     for (int c = nc - 1; c >= 0; --c) {
         const int t0 = (int)((long long)c * Tl / nc), t1 = (int)((long long)(c + 1) * Tl / nc);
         for (int l = top; l >= lb; --l) {
             LstmLayer& ly = md.layers[l];
             hipStream_t sl = ls[l - lb];
-            if (l < top) (void)hipStreamWaitEvent(sl, ev[l + 1 - lb], 0);
+            // launch order: chunk nc-1 first, layer `top` first: segment (l, c) is number (nc-1-c) * nl + (top - l)
+            pl_handle::WfSeg seg{cap ? capture_tail(st) : nullptr, nullptr, l < top ? (nc - 1 - c) * nl + (top - l - 1) : -1,
+                                 c < nc - 1 ? (nc - 2 - c) * nl + (top - l) : -1};
+            if (l < top && !cap) (void)hipStreamWaitEvent(sl, ev[l + 1 - lb], 0);
             const bool sparse_top = l == md.L - 1 && dh_last;
             LstmSweepArgs s{};
             fill_sweep_common(h, s, Tl, slice[l - lb]);
@@ -633,13 +678,18 @@ void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const voi
             else
                 launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
                                dIn + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * Hp);
-            if (l > lb || c == 0) {
+            if (cap) {
+                seg.last = capture_tail(st);
+                h->wf_regions.back().segs.push_back(seg);
+                if (c == 0) h->wf_regions.back().finals.push_back((nc - 1 - c) * nl + (top - l));
+            } else if (l > lb || c == 0) {
                 ev[l - lb] = wavefront_event(h);
                 (void)hipEventRecord(ev[l - lb], sl);
             }
         }
     }
-    for (int l = lb; l < top; ++l) (void)hipStreamWaitEvent(st, ev[l - lb], 0);   // join
+    if (!cap)
+        for (int l = lb; l < top; ++l) (void)hipStreamWaitEvent(st, ev[l - lb], 0);   // join
 }
 
 void pred_forward(pl_handle* h, hipStream_t st) {
@@ -835,20 +885,80 @@ int check_launch() {
     return PL_OK;
 }
 
+static const bool g_dbg_graph = std::getenv("PAULE_HIP_DEBUG_GRAPH") != nullptr;
+#define DBG_G(msg) do { if (g_dbg_graph) { fprintf(stderr, "[pl] %s\n", msg); fflush(stderr); } } while (0)
 void drop_graph(pl_handle* h) {
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    DBG_G("drop: exec destroy");
+    // A graph exec with parallel branches (layer wavefront) is NOT destroyed: after hipGraphExecDestroy of such execs, the first
+    // hipGraphLaunch of a later branched exec crashed inside the runtime about once in a hundred handles (ROCm 7.2;
+    // tools/microbench/capture_stress.py reproduces it with PAULE_HIP_DESTROY_BRANCHED=1, 720 handles pass without).  The exec
+    // of a retired handle stays allocated for the life of the process (kernel arguments only; device buffers are freed).
+    if (h->graph_exec && (h->wf_regions.empty() || std::getenv("PAULE_HIP_DESTROY_BRANCHED"))) (void)hipGraphExecDestroy(h->graph_exec);
+    DBG_G("drop: graph destroy");
     if (h->graph) (void)hipGraphDestroy(h->graph);
+    DBG_G("drop: done");
     h->graph_exec = nullptr;
     h->graph = nullptr;
 }
 
 int build_graph(pl_handle* h) {
-    if (!h->cap_stream) PL_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    if (!h->cap_stream) {   // one capture stream per device for the life of the process, like the layer streams (wf_stream_pool)
+        static hipStream_t cap[SweepChain::kMaxDev] = {};
+        const int dev = h->cfg.device;
+        if (dev < 0 || dev >= SweepChain::kMaxDev) return fail(PL_ERR_INVALID, "device ordinal out of range for graph capture");
+        if (!cap[dev]) PL_HIP(hipStreamCreateWithFlags(&cap[dev], hipStreamNonBlocking));
+        h->cap_stream = cap[dev];
+    }
+    DBG_G("capture begin");
     PL_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed));
+    h->wf_regions.clear();
+    h->capturing = true;
     enqueue_iteration(h, h->cap_stream);
+    h->capturing = false;
+    DBG_G("end capture");
     hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
+    DBG_G("end capture done");
     if (e != hipSuccess) return fail(PL_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    if (!h->wf_regions.empty()) {
+        // the capture is one chain; give the wavefront regions their real dependencies: segment (layer, chunk) waits for
+        // (layer below / above, same chunk) and (same layer, previous chunk) only, the node after a region for all its final segments
+        size_t n_edges = 0;
+        PL_HIP(hipGraphGetEdges(h->graph, nullptr, nullptr, &n_edges));
+        std::vector<hipGraphNode_t> from(n_edges), to(n_edges);
+        if (n_edges) PL_HIP(hipGraphGetEdges(h->graph, from.data(), to.data(), &n_edges));
+        std::unordered_map<hipGraphNode_t, hipGraphNode_t> succ;
+        for (size_t i = 0; i < n_edges; ++i) succ[from[i]] = to[i];
+        for (const pl_handle::WfRegion& rg : h->wf_regions) {
+            const size_t ns = rg.segs.size();
+            std::vector<hipGraphNode_t> first(ns, nullptr);
+            for (size_t k = 0; k < ns; ++k) {
+                auto it = succ.find(rg.segs[k].before);
+                if (rg.segs[k].before == nullptr || it == succ.end() || rg.segs[k].last == nullptr)
+                    return fail(PL_ERR_HIP, "graph capture of the layer wavefront: unexpected node chain");
+                first[k] = it->second;
+            }
+            auto after = succ.find(rg.segs[ns - 1].last);
+            for (size_t k = 1; k < ns; ++k) {
+                const pl_handle::WfSeg& sg = rg.segs[k];
+                hipGraphNode_t deps[2];
+                size_t nd = 0;
+                bool keep_chain = false;
+                for (int d : {sg.dep1, sg.dep2})
+                    if (d >= 0) {
+                        if (rg.segs[d].last == sg.before) keep_chain = true;
+                        else deps[nd++] = rg.segs[d].last;
+                    }
+                if (!keep_chain) PL_HIP(hipGraphRemoveDependencies(h->graph, &sg.before, &first[k], 1));
+                for (size_t i = 0; i < nd; ++i) PL_HIP(hipGraphAddDependencies(h->graph, &deps[i], &first[k], 1));
+            }
+            if (after != succ.end())
+                for (int f : rg.finals)
+                    if ((size_t)f != ns - 1) PL_HIP(hipGraphAddDependencies(h->graph, &rg.segs[f].last, &after->second, 1));
+        }
+    }
+    DBG_G("instantiate");
     PL_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    DBG_G("instantiate done");
     return PL_OK;
 }
 
@@ -954,6 +1064,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     h->dt = cfg->dtype == PL_BF16 ? BF16 : F32;
     h->act = dtype_size(h->dt);
     h->loss_cap = 256;
+    h->rows_in_use = h->B;
 
     int rc = PL_OK;
     auto bail = [&](int code) { pl_destroy(h); return code; };
@@ -1090,6 +1201,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
                 }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
         }
+        if (const char* z = std::getenv("PAULE_HIP_F32_VALU")) h->f32_valu = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WAVEFRONT")) h->wavefront = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
         if (h->wavefront > 0 && h->use_sweep) {
@@ -1112,8 +1224,13 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
                     n_streams += 2 * (size_t)(md->L - 1);
                     n_events += 2 * (size_t)md->L * (size_t)(h->wavefront < 32 ? h->wavefront : 32);
                 }
-            for (size_t i = 0; i < n_streams; ++i) (void)wavefront_stream(h);
-            for (size_t i = 0; i < n_events; ++i) (void)wavefront_event(h);
+            if (cfg->device >= 0 && cfg->device < SweepChain::kMaxDev) {
+                std::lock_guard<std::mutex> lock(SweepChain::mu(cfg->device));
+                for (size_t i = 0; i < n_streams; ++i) (void)wavefront_stream(h);
+                for (size_t i = 0; i < n_events; ++i) (void)wavefront_event(h);
+            } else {
+                h->wf_on = false;
+            }
             h->wf_stream_next = 0;
             h->wf_next = 0;
         }
@@ -1147,9 +1264,6 @@ int pl_destroy(pl_handle* h) {
     DeviceGuard guard(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     drop_graph(h);
-    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    for (auto& ws : h->wf_streams) if (ws) (void)hipStreamDestroy(ws);
-    for (auto& ev : h->wf_pool) if (ev) (void)hipEventDestroy(ev);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return PL_OK;
@@ -1299,8 +1413,11 @@ int pl_step(pl_handle* h, int n_iters, float* loss_log, float* grad_out) {
         const int chunk = (n_iters - done) < h->loss_cap ? (n_iters - done) : h->loss_cap;
         PL_HIP(hipMemsetAsync(h->counters + 1, 0, sizeof(int), h->stream));
         for (int i = 0; i < chunk; ++i) {
-            if (h->graph_exec)
+            if (h->graph_exec) {
+                DBG_G("launch");
                 PL_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+                DBG_G("launch done");
+            }
             else
                 enqueue_iteration(h, h->stream);
         }
@@ -1465,6 +1582,11 @@ int pl_train_model_step(pl_handle* h, int model_id, int n_rows, int n_frames, co
     int rc = ensure_train_state(h, p);
     if (rc) return rc;
     hipStream_t st = h->stream;
+    struct RowsGuard {   // training sums weight gradients over the 16-row block of the mini-batch and relies on EXACT zeros in the
+        pl_handle* h; int prev;   // padded rows: the few-row kernels leave those rows of the exchange untouched, so they stay off here
+        explicit RowsGuard(pl_handle* hh) : h(hh), prev(hh->rows_in_use) { h->rows_in_use = 0; }
+        ~RowsGuard() { h->rows_in_use = prev; }
+    } rows_guard(h);
     const bool pooled = model_id != PL_MODEL_CP_TUBE;   // ForwardModel(apply_half_sequence=...) (paule/paule.py:236, :252)
     const int Bp = h->Bp, T = n_frames, To = pooled ? n_frames / 2 : n_frames, nb = pad16(n_rows);
     // buffers by model: time-major input slab, f32 post_linear output, batch-major prediction, output gradient
