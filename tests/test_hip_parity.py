@@ -902,6 +902,42 @@ def test_somatosensory_feedback_bf16_and_errors(HipPlanner, golden_soma):
         _soma_engine(HipPlanner, g, "acoustic")
 
 
+@pytest.mark.parametrize("shape", [dict(T=46, set="A"), dict(T=61, set="B"), dict(T=40, set=None)])
+def test_f32_one_row_kernels_vs_oracle(HipPlanner, golden_small, shape, monkeypatch):
+    """B = 1 in f32 (the reference's own operating point) runs the recurrent products as FMA chains on the one row in use
+    (lstm_persist_f32.hip, NV = 1) instead of 16x16x4 MFMAs: against the CPU oracle at the f32 bars, and against the MFMA kernels
+    (PAULE_HIP_F32_VALU=0) to summation-order noise; with the layer wavefront on top (set B: 4 layers)."""
+    from oracle import planner as op
+    if shape["set"] is None:
+        g = golden_small
+        pred_sd, emb_sd = state_dict_from(g, "pred"), state_dict_from(g, "emb")
+        tm, ts, cp0 = g["target_mel"][:1], g["target_semvec"][:1], g["cp0"][:1]
+    else:
+        wl = synthetic.make_workload(1, shape["T"], shape["set"])
+        pred_sd, emb_sd, tm, ts, cp0 = wl.pred_sd, wl.emb_sd, wl.target_mel, wl.target_semvec, wl.cp0
+    T = int(np.asarray(cp0).shape[1])
+    outs = []
+    for valu in ("1", "0"):
+        monkeypatch.setenv("PAULE_HIP_F32_VALU", valu)
+        eng = HipPlanner(pred_sd, emb_sd, batch=1, n_frames=T, objective="acoustic_semvec")
+        eng.set_targets(tm, ts)
+        eng.set_cp(cp0)
+        loss, grad = eng.step(1, return_grad=True)
+        more = eng.step(9)
+        outs.append((np.concatenate([_n(loss), _n(more)]), _n(grad), _n(eng.get_cp())))
+    P = op.OraclePlanner(op.forward_model_from_state_dict(pred_sd, dtype=torch.float32), op.embedding_model_from_state_dict(emb_sd, dtype=torch.float32),
+                         objective="acoustic_semvec", dtype=torch.float32)
+    P.set_targets(np.asarray(tm), np.asarray(ts))
+    P.set_cp(np.asarray(cp0))
+    want = P.step(10).numpy()
+    for loss, grad, cp in outs:
+        np.testing.assert_allclose(loss[:, :, :6], want[:, :, :6], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(cp, _n(P.get_cp()), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-5 * max(1.0, np.abs(outs[1][1]).max()), rtol=0)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], atol=1e-5, rtol=0)
+
+
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
     """Nonzero return code -> ValueError with the library's message (the reference's convention for its one C library,
     paule/util.py:33-34): call-sequence errors (PL_ERR_STATE) and bad arguments (PL_ERR_INVALID); nothing aborts, and the
