@@ -61,10 +61,24 @@ __device__ __forceinline__ f32x4 fwd_rows_valu(const float4 (&wreg)[KS], const f
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[b][j] = 0.f;
+        // the h fragments come from LDS through a ring of RA reads in flight: one read per FMA group would serialise the
+        // ~100-cycle LDS latency 46 times (the wave is alone on its SIMD)
+        constexpr int RA = 8;
+        float4 ring[NB][RA];
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (i < KS) ring[b][i] = *reinterpret_cast<const float4*>(himg + b * RS + i * 64 + kq * 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) part[b][s & 3] += dot4(wreg[s], *reinterpret_cast<const float4*>(himg + b * RS + s * 64 + kq * 16));
+            for (int b = 0; b < NB; ++b) {
+                part[b][s & 3] += dot4(wreg[s], ring[b][s % RA]);
+                if (s + RA < KS) ring[b][s % RA] = *reinterpret_cast<const float4*>(himg + b * RS + (s + RA) * 64 + kq * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) pv[b] = (part[b][0] + part[b][1]) + (part[b][2] + part[b][3]);
@@ -411,14 +425,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
                     float4 d4[4];
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4) d4[c4] = *reinterpret_cast<const float4*>(da_img + b * DRS + c4 * 64 + kq * 16);
+                    float q[NT];   // all tiles first, then the two cross-lane steps back to back (their latencies overlap)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        q[i] = (dot4(wreg[i][0], d4[0]) + dot4(wreg[i][1], d4[1])) + (dot4(wreg[i][2], d4[2]) + dot4(wreg[i][3], d4[3]));
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) q[i] += __shfl_xor(q[i], 16, 64);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) q[i] += __shfl_xor(q[i], 32, 64);
 #pragma unroll
                     for (int i = 0; i < NT; ++i) {
                         const int nt = wave + 4 * i;
-                        if (nt >= P) break;
-                        float q = dot4(wreg[i][0], d4[0]) + dot4(wreg[i][1], d4[1]) + dot4(wreg[i][2], d4[2]) + dot4(wreg[i][3], d4[3]);
-                        q += __shfl_xor(q, 16, 64);
-                        q += __shfl_xor(q, 32, 64);
-                        if (kq == 0) st4_handoff(ro, (unsigned)(((size_t)nt * P * TILE + b * 16 + (lane & 15)) * 4), q, plain_handoff);
+                        if (nt < P && kq == 0)
+                            st4_handoff(ro, (unsigned)(((size_t)nt * P * TILE + b * 16 + (lane & 15)) * 4), q[i], plain_handoff);
                     }
                 }
             } else {
