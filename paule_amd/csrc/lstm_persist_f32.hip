@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
 
 // ---------------------------------------------------------------------------------------------------
 #ifndef PL_F32_FEW_ROWS
-#define PL_F32_FEW_ROWS 1
+#define PL_F32_FEW_ROWS 2
 #endif
 #define PL_SWEEP_F32_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
 
@@ -496,8 +496,8 @@ size_t lstm_f32_exchange_bytes(int Hp, int Bp) {
     return 2 * groups * P * P * 16 * 16 * 4;
 }
 
-// rows in use for the few-row FMA kernels (0 = MFMA kernels): one group with ONE row in use (B = 1, the reference's operating
-// point: 6.84 -> 5.52 ms per iteration; two rows already lose against the MFMA kernels, 7.16 vs 6.85 ms)
+// rows in use for the few-row FMA kernels (0 = MFMA kernels): one group with one or two rows in use (B = 1, the reference's
+// operating point: 6.85 -> 4.78 ms per iteration; B = 2: 6.83 -> 6.00; a third row would cost more than the MFMAs)
 static int few_rows(const LstmSweepArgs& a) { return (a.Bp == 16 && a.n_valid >= 1 && a.n_valid <= PL_F32_FEW_ROWS) ? a.n_valid : 0; }
 
 template <int K, int NV>

@@ -902,24 +902,26 @@ def test_somatosensory_feedback_bf16_and_errors(HipPlanner, golden_soma):
         _soma_engine(HipPlanner, g, "acoustic")
 
 
-@pytest.mark.parametrize("shape", [dict(T=46, set="A"), dict(T=61, set="B"), dict(T=40, set=None)])
+@pytest.mark.parametrize("shape", [dict(T=46, set="A"), dict(T=61, set="B"), dict(T=40, set=None), dict(T=52, set="A", B=2),
+                                   dict(T=40, set=None, B=2)])
 def test_f32_one_row_kernels_vs_oracle(HipPlanner, golden_small, shape, monkeypatch):
-    """B = 1 in f32 (the reference's own operating point) runs the recurrent products as FMA chains on the one row in use
-    (lstm_persist_f32.hip, NV = 1) instead of 16x16x4 MFMAs: against the CPU oracle at the f32 bars, and against the MFMA kernels
+    """B = 1 (the reference's own operating point) and B = 2 in f32 run the recurrent products as FMA chains on the rows in use
+    (lstm_persist_f32.hip, NV = 1 / 2) instead of 16x16x4 MFMAs: against the CPU oracle at the f32 bars, and against the MFMA kernels
     (PAULE_HIP_F32_VALU=0) to summation-order noise; with the layer wavefront on top (set B: 4 layers)."""
     from oracle import planner as op
+    B = shape.get("B", 1)
     if shape["set"] is None:
         g = golden_small
         pred_sd, emb_sd = state_dict_from(g, "pred"), state_dict_from(g, "emb")
-        tm, ts, cp0 = g["target_mel"][:1], g["target_semvec"][:1], g["cp0"][:1]
+        tm, ts, cp0 = g["target_mel"][:B], g["target_semvec"][:B], g["cp0"][:B]
     else:
-        wl = synthetic.make_workload(1, shape["T"], shape["set"])
+        wl = synthetic.make_workload(B, shape["T"], shape["set"])
         pred_sd, emb_sd, tm, ts, cp0 = wl.pred_sd, wl.emb_sd, wl.target_mel, wl.target_semvec, wl.cp0
     T = int(np.asarray(cp0).shape[1])
     outs = []
     for valu in ("1", "0"):
         monkeypatch.setenv("PAULE_HIP_F32_VALU", valu)
-        eng = HipPlanner(pred_sd, emb_sd, batch=1, n_frames=T, objective="acoustic_semvec")
+        eng = HipPlanner(pred_sd, emb_sd, batch=B, n_frames=T, objective="acoustic_semvec")
         eng.set_targets(tm, ts)
         eng.set_cp(cp0)
         loss, grad = eng.step(1, return_grad=True)
