@@ -349,50 +349,66 @@ class HipPlanner:
     def reset_pred_optimizer(self):
         self._call(self.lib.pl_reset_pred_optimizer)
 
-    def _pred_param_shapes(self):
+    def _pred_param_shapes(self, model="pred"):
         """(name, shape) in the order of ``ForwardModel.parameters()`` (= the parameter indices of torch.optim.Adam's state)."""
-        n_layers, H, _ = self._dims["pred"]
+        n_layers, H, _ = self._dims[model]
         out = []
         for l in range(n_layers):
-            in_l = self._dims["pred_in"] if l == 0 else H
+            in_l = self._dims[model + "_in"] if l == 0 else H
             out += [(f"lstm.weight_ih_l{l}", (4 * H, in_l)), (f"lstm.weight_hh_l{l}", (4 * H, H)),
                     (f"lstm.bias_ih_l{l}", (4 * H,)), (f"lstm.bias_hh_l{l}", (4 * H,))]
-        return out + [("post_linear.weight", (self.M, H)), ("post_linear.bias", (self.M,))]
+        n_out = self.U if model == "cp_tube" else self.M
+        return out + [("post_linear.weight", (n_out, H)), ("post_linear.bias", (n_out,))]
 
     def get_pred_optimizer_state(self, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
         """The parameter optimiser's state in the layout of ``torch.optim.Adam.state_dict()`` (what the reference's users save,
         docs/examples/minimal_example.py:51): step / exp_avg / exp_avg_sq per parameter, in ``parameters()`` order."""
-        step = int(self.lib.pl_get_pred_optimizer_step(self._h))
-        shapes = self._pred_param_shapes()
+        return self.get_optimizer_state("pred", lr=lr, betas=betas, eps=eps)
+
+    def set_pred_optimizer_state(self, state_dict):
+        """Loads a ``torch.optim.Adam.state_dict()`` of the predictive model's optimiser (an empty state = a fresh optimiser)."""
+        self.set_optimizer_state("pred", state_dict)
+
+    def _trainable_id(self, model):
+        if model not in self._TRAINABLE or (model != "pred" and not self.has_tube):
+            raise ValueError("model has to be 'pred' or (with tube_models=) 'cp_tube' / 'tube_mel'")
+        return self._TRAINABLE[model]
+
+    def get_optimizer_state(self, model="pred", lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        """Adam state of ``model`` in ("pred", "cp_tube", "tube_mel") as a ``torch.optim.Adam.state_dict()`` (pred_optimizer,
+        tube_optimizer, tube_mel_optimizer of the reference, paule/paule.py:284-306)."""
+        mid = self._trainable_id(model)
+        step = int(self.lib.pl_get_model_optimizer_step(self._h, mid))
+        shapes = self._pred_param_shapes(model)
         bufs = {w: [torch.empty(shape, dtype=torch.float32, device=self.device) for _, shape in shapes] for w in (1, 2)}
-        n_layers = self._dims["pred"][0]
+        n_layers = self._dims[model][0]
         for which in (1, 2):
             for l in range(n_layers):
-                self._call(self.lib.pl_get_pred_optimizer_state, l, which, *[t.data_ptr() for t in bufs[which][4 * l:4 * l + 4]])
+                self._call(self.lib.pl_get_model_optimizer_state, mid, l, which, *[t.data_ptr() for t in bufs[which][4 * l:4 * l + 4]])
             w, b = bufs[which][-2:]
-            self._call(self.lib.pl_get_pred_optimizer_state, -1, which, w.data_ptr(), None, b.data_ptr(), None)
+            self._call(self.lib.pl_get_model_optimizer_state, mid, -1, which, w.data_ptr(), None, b.data_ptr(), None)
         state = {} if step == 0 else {i: {"step": torch.tensor(float(step)), "exp_avg": bufs[1][i], "exp_avg_sq": bufs[2][i]}
                                       for i in range(len(shapes))}
         group = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
                      differentiable=False, fused=None, params=list(range(len(shapes))))
         return {"state": state, "param_groups": [group]}
 
-    def set_pred_optimizer_state(self, state_dict):
-        """Loads a ``torch.optim.Adam.state_dict()`` of the predictive model's optimiser (an empty state = a fresh optimiser)."""
+    def set_optimizer_state(self, model, state_dict):
+        mid = self._trainable_id(model)
         state = state_dict.get("state", {})
-        shapes = self._pred_param_shapes()
+        shapes = self._pred_param_shapes(model)
         if not state:
-            self.reset_pred_optimizer()
+            self._call(self.lib.pl_reset_model_optimizer, mid)
             return
         if sorted(state) != list(range(len(shapes))):
-            raise ValueError("optimizer state does not match the predictive model's parameters")
-        n_layers = self._dims["pred"][0]
+            raise ValueError(f"optimizer state does not match the parameters of '{model}'")
+        n_layers = self._dims[model][0]
         for which, key in ((1, "exp_avg"), (2, "exp_avg_sq")):
             ts = [self._dev(state[i][key], shape) for i, (_, shape) in enumerate(shapes)]
             for l in range(n_layers):
-                self._call(self.lib.pl_set_pred_optimizer_state, l, which, *[t.data_ptr() for t in ts[4 * l:4 * l + 4]])
-            self._call(self.lib.pl_set_pred_optimizer_state, -1, which, ts[-2].data_ptr(), None, ts[-1].data_ptr(), None)
-        self._call(self.lib.pl_set_pred_optimizer_step, int(round(float(state[0]["step"]))))
+                self._call(self.lib.pl_set_model_optimizer_state, mid, l, which, *[t.data_ptr() for t in ts[4 * l:4 * l + 4]])
+            self._call(self.lib.pl_set_model_optimizer_state, mid, -1, which, ts[-2].data_ptr(), None, ts[-1].data_ptr(), None)
+        self._call(self.lib.pl_set_model_optimizer_step, mid, int(round(float(state[0]["step"]))))
 
     def set_speech_classifier(self, classifier=None, weight=0.1):
         """LinearClassifier(mel_dim -> 1) term (paule/models.py:887-910; ``use_speech_classifier=True``): module or state

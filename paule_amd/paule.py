@@ -141,7 +141,9 @@ class Paule():
         # embedder without dropout (EmbeddingModel(input_size=10, ..., dropout=0) with the same weights is deterministic).
         self.use_somatosensory_feedback = bool(use_somatosensory_feedback)
         self.cp_tube_model, self.tube_mel_model, self.tube_embedder = cp_tube_model, tube_mel_model, tube_embedder
-        self.tube_optimizer, self.tube_mel_optimizer = tube_optimizer, tube_mel_optimizer
+        # torch.optim.Adam(lr=0.001) each in the reference (paule/paule.py:296-306): stand-ins that carry the moments between plans
+        self.tube_optimizer = tube_optimizer if tube_optimizer is not None else (PlannerAdam() if use_somatosensory_feedback else None)
+        self.tube_mel_optimizer = tube_mel_optimizer if tube_mel_optimizer is not None else (PlannerAdam() if use_somatosensory_feedback else None)
         # tube_extractor(cp (B, T, 30) normalised) -> normalised tube (B, T, 10): the reference's
         # speak_and_extract_tube_information + get_area_info_within_oral_cavity + normalize_tube (paule/paule.py:1070-1078, VTL)
         self.tube_extractor = tube_extractor
@@ -384,6 +386,15 @@ class Paule():
                 self.pred_model.load_state_dict(new)
             else:
                 self.pred_model.update(new)
+        if learn_tube and hasattr(planner, "get_optimizer_state"):   # tube_optimizer / tube_mel_optimizer outlive the plan
+            for attr, name, g_ in (("tube_optimizer", "cp_tube", tube_grp), ("tube_mel_optimizer", "tube_mel", tmel_grp)):
+                sd = planner.get_optimizer_state(name, lr=g_.get("lr", 0.001), betas=g_.get("betas", (0.9, 0.999)), eps=g_.get("eps", 1e-8))
+                try:
+                    getattr(self, attr).load_state_dict(sd)
+                except (ValueError, KeyError, AttributeError):
+                    opt = PlannerAdam(lr=g_.get("lr", 0.001))
+                    opt.load_state_dict(sd)
+                    setattr(self, attr, opt)
         if learn_tube:                       # the trained tube models back into the instance, like pred_model
             for attr, name in (("cp_tube_model", "cp_tube"), ("tube_mel_model", "tube_mel")):
                 cur = getattr(self, attr)
@@ -567,6 +578,12 @@ class Paule():
         self.planner = planner
         if continue_learning and hasattr(planner, "set_pred_optimizer_state"):   # the optimiser outlives a plan (paule/paule.py:284-287)
             planner.set_pred_optimizer_state(self.pred_optimizer.state_dict())
+        if self.use_somatosensory_feedback and continue_learning and continue_learning_tube and hasattr(planner, "set_optimizer_state"):
+            for name, opt in (("cp_tube", self.tube_optimizer), ("tube_mel", self.tube_mel_optimizer)):
+                try:
+                    planner.set_optimizer_state(name, opt.state_dict())
+                except (ValueError, KeyError):   # a torch optimizer over other parameter objects: start fresh on the device
+                    planner.set_optimizer_state(name, {"state": {}})
         planner.set_cp(initial_cp)
         planner.reset_optimizer()                       # a fresh Adam per call (paule/paule.py:797)
         cls_w = cls_b = None

@@ -596,6 +596,30 @@ def test_tube_models_training_steps_vs_oracle(HipPlanner, golden_soma, dtype):
         eng._call(eng.lib.pl_train_model_step, 5, 1, 4, 1, 1, 0.001, 0.9, 0.999, 1e-8, None)
 
 
+def test_paule_continue_learning_tube_hip(golden_soma):
+    """Paule(..., use_somatosensory_feedback=True).plan_resynth(continue_learning_tube=True) on the device: epoch losses of all three
+    trained models, the tube optimisers' state outliving the plan (their step counts add up over two calls), models written back."""
+    from paule_amd import paule as pp
+    g = golden_soma
+    sdf = state_dict_from
+    rng = np.random.default_rng(1)
+    model = pp.Paule(pred_model=sdf(g, "pred"), embedder=sdf(g, "emb"), use_somatosensory_feedback=True, cp_tube_model=sdf(g, "cp_tube"),
+                     tube_mel_model=sdf(g, "tube_mel"), tube_embedder=sdf(g, "tube_emb"),
+                     tube_extractor=lambda cp: 0.3 * rng.standard_normal(cp.shape[:2] + (10,)),
+                     synthesizer=lambda cp: (np.zeros(100), 44100), mel_extractor=lambda sig, sr: np.full((20, 60), 0.25),
+                     device=torch.device("cuda"))
+    before = {k: v.clone() for k, v in model.tube_mel_model.items()}
+    steps = []
+    for _ in range(2):
+        res = model.plan_resynth(target_acoustic=g["target_mel"][:2], target_semvec=g["target_semvec"][:2], initial_cp=g["cp0"][:2],
+                                 initialize_from=None, objective="acoustic_semvec", n_outer=1, n_inner=4, log_ii=2, continue_learning=True,
+                                 continue_learning_tube=True, n_batches=2, batch_size=2, n_epochs=2, seed=3, verbose=False)
+        assert len(res.tube_model_loss) == 2 and len(res.tube_mel_model_loss) == 2 and np.isfinite(res.tube_model_loss).all()
+        steps.append(float(model.tube_optimizer.state_dict()["state"][0]["step"]))
+    assert steps[0] > 0 and steps[1] == 2 * steps[0]
+    assert any(not torch.equal(torch.as_tensor(model.tube_mel_model[k]).cpu(), before[k].cpu()) for k in before)
+
+
 def test_paule_initialize_from_acoustic_hip(golden_inverse):
     """Paule.plan_resynth(initialize_from='acoustic') with the inverse model on the device: initial_cp equals the reference's
     clipped inverse output, and the plan starts from it."""
@@ -1066,6 +1090,35 @@ def test_pred_optimizer_state_round_trip(HipPlanner, golden_train):
         np.testing.assert_allclose(_n(wc[name]), _n(wa[name]), atol=1e-6, rtol=0, err_msg=name)
     c.set_pred_optimizer_state({"state": {}})
     assert c.get_pred_optimizer_state()["state"] == {}
+
+
+def test_tube_optimizer_state_round_trip(HipPlanner, golden_soma):
+    """pl_{get,set}_model_optimizer_state / _step for the somatosensory models: two training steps of the cp -> tube model, export of
+    parameters + Adam state, a NEW handle loaded with them, two more steps == four steps on one handle."""
+    g = golden_soma
+    rng = np.random.default_rng(5)
+    cps = g["cp0"].astype(np.float32)
+    tubes = (g["fwd/pred_tube"] + 0.2 * rng.standard_normal(g["fwd/pred_tube"].shape)).astype(np.float32)
+    a = _soma_engine(HipPlanner, g, "acoustic_semvec")
+    for _ in range(4):
+        a.train_model_step("cp_tube", cps, tubes)
+    b = _soma_engine(HipPlanner, g, "acoustic_semvec")
+    for _ in range(2):
+        b.train_model_step("cp_tube", cps, tubes)
+    state = b.get_optimizer_state("cp_tube")
+    assert float(state["state"][0]["step"]) == 2 and b.get_optimizer_state("tube_mel")["state"] == {}
+    c = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, "emb"), batch=int(g["B"]), n_frames=int(g["T"]), objective="acoustic_semvec",
+                   tube_models=(b.get_weights("cp_tube"), state_dict_from(g, "tube_mel"), state_dict_from(g, "tube_emb")))
+    c.set_optimizer_state("cp_tube", state)
+    for _ in range(2):
+        c.train_model_step("cp_tube", cps, tubes)
+    wa, wc = a.get_weights("cp_tube"), c.get_weights("cp_tube")
+    for name in wa:
+        np.testing.assert_allclose(_n(wc[name]), _n(wa[name]), atol=1e-6, rtol=0, err_msg=name)
+    c.set_optimizer_state("cp_tube", {"state": {}})
+    assert c.get_optimizer_state("cp_tube")["state"] == {}
+    with pytest.raises(ValueError):
+        c.get_optimizer_state("tube_embedder")
 
 
 def test_random_shapes_f32_vs_oracle(HipPlanner):
