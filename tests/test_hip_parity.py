@@ -964,6 +964,39 @@ def test_f32_one_row_kernels_vs_oracle(HipPlanner, golden_small, shape, monkeypa
     np.testing.assert_allclose(outs[0][2], outs[1][2], atol=1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("combo", ["soma+smiling+past", "melsmooth+classifier+past", "upsampling+smiling", "soma+melsmooth"])
+def test_feature_combinations_f32_vs_oracle(HipPlanner, golden_soma, golden_embvar, golden_small, combo):
+    """The widened rows combined (somatosensory feedback, embedder variants, speech classifier, smiling, past_cp): eight
+    iterations on the device against the CPU oracle given the same models, f32 bars."""
+    from oracle import planner as op
+    gs, ge, g0 = golden_soma, golden_embvar, golden_small
+    pred_sd = state_dict_from(gs, "pred")
+    emb_sd = state_dict_from(ge, "melsmooth/emb") if "melsmooth" in combo else \
+        state_dict_from(ge, "upsampling/emb") if "upsampling" in combo else state_dict_from(gs, "emb")
+    tube = ("soma" in combo)
+    tube_sds = (state_dict_from(gs, "cp_tube"), state_dict_from(gs, "tube_mel"), state_dict_from(gs, "tube_emb")) if tube else None
+    smiling, past, cls = "smiling" in combo, "past" in combo, "classifier" in combo
+    B, T = 3, 40
+    eng = HipPlanner(pred_sd, emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", smiling=smiling, tube_models=tube_sds)
+    ora_tube = None
+    if tube:
+        ora_tube = (op.forward_model_from_state_dict(tube_sds[0], apply_half_sequence=False), op.forward_model_from_state_dict(tube_sds[1]),
+                    op.embedding_model_from_state_dict(tube_sds[2]))
+    P = op.OraclePlanner(op.forward_model_from_state_dict(pred_sd), op.embedding_model_from_state_dict(emb_sd), objective="acoustic_semvec",
+                         smiling=smiling, tube_models=ora_tube)
+    for pl in (eng, P):
+        pl.set_targets(gs["target_mel"], gs["target_semvec"])
+        pl.set_cp(gs["cp0"])
+        if past:
+            pl.set_past_cp(g0["past_cp"])
+        if cls:
+            pl.set_speech_classifier(state_dict_from(g0, "clf"))
+    got = _n(eng.step(8))
+    want = P.step(8).numpy()
+    np.testing.assert_allclose(got, want, rtol=LOSS_RTOL_F32, atol=1e-6)
+    np.testing.assert_allclose(_n(eng.get_cp()), _n(P.get_cp()), atol=CP_ATOL_F32, rtol=0)
+
+
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
     """Nonzero return code -> ValueError with the library's message (the reference's convention for its one C library,
     paule/util.py:33-34): call-sequence errors (PL_ERR_STATE) and bad arguments (PL_ERR_INVALID); nothing aborts, and the
