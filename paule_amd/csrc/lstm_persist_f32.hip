@@ -91,16 +91,19 @@ __device__ __forceinline__ f32x4 fwd_rows_valu(const float4 (&wreg)[KS], const f
         }
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        pv[b] += __shfl_xor(pv[b], 16, 64);
-        pv[b] += __shfl_xor(pv[b], 32, 64);
-        if (kq == 0) vimg[(wave * 4 + b) * 16 + r] = pv[b];
-    }
-    __syncthreads();
+    for (int b = 0; b < NB; ++b) pv[b] += __shfl_xor(pv[b], 16, 64);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pv[b] += __shfl_xor(pv[b], 32, 64);
+    // every lane of gate row r now holds the row's sums; the epilogue lane (batch row r', unit slot kq) wants gate rows 4 kq .. + 3
+    // of batch row r': four lane reads per row in use (no LDS image, no barriers)
+    (void)vimg; (void)wave;
     f32x4 out = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (r < NB) {   // r doubles as the batch row of the epilogue layout
-        const float4 v = *reinterpret_cast<const float4*>(vimg + (wave * 4 + r) * 16 + 4 * kq);
-        out = f32x4{v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float g4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g4[i] = __shfl(pv[b], 4 * kq + i, 64);
+        if (r == b) out = f32x4{g4[0], g4[1], g4[2], g4[3]};   // r doubles as the batch row of the epilogue layout
     }
     return out;
 }
@@ -228,7 +231,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_f32_kernel(LstmSweepArg
                 float* vimg = reinterpret_cast<float*>(hst);   // the staging image is free until the cell update below
                 const f32x4 add = fwd_rows_valu<NV, KS, KSX>(wreg, wx, himg, RS, t > 0, ximg, XRS, vimg, lane, wave);
                 acc[0] += add[0]; acc[1] += add[1]; acc[2] += add[2]; acc[3] += add[3];
-                __syncthreads();   // vimg (= hst) is written again by the cell update
             } else if constexpr (KSX > 0) {
 #pragma unroll
                 for (int s = 0; s < KSX; ++s)
