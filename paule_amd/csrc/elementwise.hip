@@ -106,10 +106,11 @@ void launch_pack_mel(hipStream_t stream, int dt, const float* mel, int B, int Tp
 // AvgPool1d(2, stride 2) over time (paule/models.py:351-354); an odd last frame is dropped.
 template <typename AT>
 __global__ void pool_mel_kernel(const float* __restrict__ Y, int B, int Tp, int C, int Bp, int Cp,
-                                float* __restrict__ mel_bm, AT* __restrict__ mel_tm) {
-    const int64_t n = (int64_t)Tp * Bp * Cp;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                float* __restrict__ mel_bm, AT* __restrict__ mel_tm, int tp0, int n_tp) {
+    const int64_t n = (int64_t)n_tp * Bp * Cp;   // pooled frames tp0 .. tp0 + n_tp - 1
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
+    idx += (int64_t)tp0 * Bp * Cp;
     const int c = (int)(idx % Cp);
     const int b = (int)((idx / Cp) % Bp);
     const int tp = (int)(idx / ((int64_t)Cp * Bp));
@@ -123,15 +124,17 @@ __global__ void pool_mel_kernel(const float* __restrict__ Y, int B, int Tp, int 
 }
 
 void launch_pool_mel(hipStream_t stream, int dt, const float* Y, int B, int T, int C, int Bp, int Cp, float* mel_bm,
-                     void* mel_tm) {
+                     void* mel_tm, int tp0, int n_tp) {
     const int Tp = T / 2;
-    const int64_t n = (int64_t)Tp * Bp * Cp;
+    if (n_tp < 0) { tp0 = 0; n_tp = Tp; }
+    const int64_t n = (int64_t)n_tp * Bp * Cp;
+    if (n <= 0) return;
     if (dt == BF16)
         hipLaunchKernelGGL(pool_mel_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, Y, B, Tp, C, Bp, Cp, mel_bm,
-                           static_cast<bf16_t*>(mel_tm));
+                           static_cast<bf16_t*>(mel_tm), tp0, n_tp);
     else
         hipLaunchKernelGGL(pool_mel_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, Y, B, Tp, C, Bp, Cp, mel_bm,
-                           static_cast<float*>(mel_tm));
+                           static_cast<float*>(mel_tm), tp0, n_tp);
 }
 
 // output[i, lens[i]-1, :] gather of EmbeddingModel.forward (paule/models.py:442)
@@ -330,10 +333,11 @@ void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem, bool
 
 // dL/dY (pre-pool linear output): each pooled frame's gradient goes half to each of its two frames.
 template <typename AT>
-__global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __restrict__ dY, int tube) {
-    const int64_t n = (int64_t)a.T * a.Bp * a.Mp;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __restrict__ dY, int tube, int t0, int n_t) {
+    const int64_t n = (int64_t)n_t * a.Bp * a.Mp;   // frames t0 .. t0 + n_t - 1
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
+    idx += (int64_t)t0 * a.Bp * a.Mp;
     const int m = (int)(idx % a.Mp);
     const int b = (int)((idx / a.Mp) % a.Bp);
     const int t = (int)(idx / ((int64_t)a.Mp * a.Bp));
@@ -360,12 +364,14 @@ __global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __re
     dY[idx] = from_f32<AT>(v);
 }
 
-void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube) {
-    const int64_t n = (int64_t)a.T * a.Bp * a.Mp;
+void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube, int t0, int n_t) {
+    if (n_t < 0) { t0 = 0; n_t = a.T; }
+    const int64_t n = (int64_t)n_t * a.Bp * a.Mp;
+    if (n <= 0) return;
     if (dt == BF16)
-        hipLaunchKernelGGL(dy_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<bf16_t*>(dY), tube ? 1 : 0);
+        hipLaunchKernelGGL(dy_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<bf16_t*>(dY), tube ? 1 : 0, t0, n_t);
     else
-        hipLaunchKernelGGL(dy_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<float*>(dY), tube ? 1 : 0);
+        hipLaunchKernelGGL(dy_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<float*>(dY), tube ? 1 : 0, t0, n_t);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -104,7 +104,7 @@ void launch_pack_cp(hipStream_t stream, int dt, const double* x, int B, int T, i
 void launch_pack_mel(hipStream_t stream, int dt, const float* mel, int B, int Tp, int C, void* dst, int Bp, int Cp);
 // Y f32 [T][Bp][Cp] -> pooled mel: f32 batch-major [B][Tp][C] and activation time-major [Tp][Bp][Cp]
 void launch_pool_mel(hipStream_t stream, int dt, const float* Y, int B, int T, int C, int Bp, int Cp, float* mel_bm,
-                     void* mel_tm);
+                     void* mel_tm, int tp0 = 0, int n_tp = -1);   // n_tp >= 0: pooled frames tp0 .. tp0 + n_tp - 1 only
 // gather rows h[lens[b]-1][b][:] (lens null -> Tl) of a time-major activation buffer into [Bp][Hp]
 void launch_gather_last(hipStream_t stream, int dt, const void* h_tm, const int32_t* lens, int B, int Tl, int Bp, int Hp,
                         void* dst);
@@ -140,7 +140,7 @@ void launch_loss_finalize(hipStream_t stream, const LossArgs& a);
 void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem, bool tube = false);
 // dY activation [T][Bp][Mp]: 0.5 * (use_mel * w_mel (mel - tgt)/(N rmse) + dmel_e[t/2][b][m]) ; dmel_e f32 [Tp][Bp][Mp] or null
 // tube = true: the tube-mel model's output gradient: w_mel (mel2 - tgt)/(N rmse2) only (always part of the objective)
-void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube = false);
+void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube = false, int t0 = 0, int n_t = -1);   // n_t >= 0: frames t0 .. only
 // out (activation type) = a + b (f32), n elements: the two gradient streams that meet at the predicted tube
 void launch_add2_act(hipStream_t stream, int dt, const float* a, const float* b, int64_t n, void* out);
 // time-major padded f32 [T][Bp][Cp] -> batch-major [B][T][C]

@@ -201,6 +201,7 @@ struct pl_handle {
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
     bool wide_ingest = true;    // PAULE_HIP_WIDE_INGEST: f32 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool wide_ingest16 = true;  // PAULE_HIP_WIDE_INGEST16: 16-row bf16 backward sweep sums the partial tiles with 16-byte loads, wave by wave
+    bool wf_pipeline = true;    // PAULE_HIP_WF_PIPELINE: predictor -> mel head -> embedder as one pipeline over time chunks (small batches)
     bool f32_valu = true;       // PAULE_HIP_F32_VALU: f32 sweeps of at most 4 rows in use run their recurrent products as FMA chains
     int rows_in_use = 0;        // batch rows that carry data (B); 0 inside pl_train_model_step (few-row kernels off)
     int wavefront = 4;          // PAULE_HIP_WAVEFRONT = time chunks (0 off): small sweeps run the layers of a model side by side, layer l + 1
@@ -352,6 +353,7 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
         launch_lstm_sweep(st, bwd, Hp, grid, s);
 }
 
+int sweep_per_xcd(pl_handle* h, const Model& md);
 int wavefront_depth(pl_handle* h, const Model& md);
 int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb);
 void model_forward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl, int nc, int lb, int le);
@@ -507,26 +509,45 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
 // neither would ever complete.  A band of at most depth = (CUs of an XCD) / (workgroups one sweep keeps on an XCD) layers
 // forms one wavefront; a deeper model runs band after band.  H = 720 in bf16 pins a group's 23 workgroups to one XCD
 // (the 8-slot grid): no second sweep fits beside it, and spreading the group instead costs more than the overlap gains.
-int wavefront_depth(pl_handle* h, const Model& md) {
+// workgroups one sweep of the model keeps on an XCD (worst case); 0 = the model's sweeps cannot be cut into time chunks
+int sweep_per_xcd(pl_handle* h, const Model& md) {
     const int Hp = md.Hp;
-    if (md.L < 2 || sweep_grid_for(h, Hp, false) <= 0 || sweep_grid_for(h, Hp, true) <= 0) return 0;
+    if (md.L < 1 || sweep_grid_for(h, Hp, false) <= 0 || sweep_grid_for(h, Hp, true) <= 0) return 0;
     const int groups = (h->Bp + 15) / 16;
-    int per_xcd;
     if (h->dt == F32) {
         const int P = Hp / 16, grid = lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu);
         if (grid < groups * P) return 0;   // the groups take turns already
-        per_xcd = (grid + 7) / 8;
-    } else if (use_sweep16(h, Hp, false) && use_sweep16(h, Hp, true)) {
+        return (grid + 7) / 8;
+    }
+    if (use_sweep16(h, Hp, false) && use_sweep16(h, Hp, true)) {
         const int P = Hp / 32, slots = lstm_sweep16_grid(Hp, h->Bp, h->n_cu, h->small_grid) / P;
         if (slots < groups) return 0;
-        per_xcd = slots % 8 == 0 ? (groups + 7) / 8 * P : (slots * P + 7) / 8;   // slot s sits on XCD s % 8 / spread
-    } else {
-        return 0;
+        return slots % 8 == 0 ? (groups + 7) / 8 * P : (slots * P + 7) / 8;   // slot s sits on XCD s % 8 / spread
     }
+    return 0;
+}
+
+int wavefront_depth(pl_handle* h, const Model& md) {
+    const int per_xcd = sweep_per_xcd(h, md);
+    if (md.L < 2 || per_xcd == 0) return 0;
     int depth = (h->n_cu / 8) / per_xcd;
     if (depth > md.L) depth = md.L;
     if (depth > 8) depth = 8;
     return depth >= 2 ? depth : 0;
+}
+
+// Cross-model pipeline of the acoustic path (small batches): predictor (one layer) -> mel head + pooling -> embedder layers,
+// chunk by chunk, when one sweep of each fits side by side on every XCD.  Returns the number of chunks (of mel frames) or 0.
+int acoustic_pipeline_chunks(pl_handle* h) {
+    if (h->wavefront <= 0 || !h->wf_pipeline || h->sweep_slot < 0 || !h->need_emb_in_step()) return 0;
+    const Model &p = h->pred, &e = h->emb;
+    if (p.L != 1 || e.L < 1 || e.L > 7 || h->emb_blocks > 0 || !p.layers[0].carry_f || !e.layers[0].carry_f) return 0;
+    const int pp = sweep_per_xcd(h, p), pe = sweep_per_xcd(h, e);
+    if (pp == 0 || pe == 0 || pp + e.L * pe > h->n_cu / 8) return 0;
+    if (h->sweep_slot != 0 || 2 * (p.L + e.L) > h->n_sweep_slots) return 0;
+    int nc = h->wavefront < 32 ? h->wavefront : 32;
+    if (nc > h->Tp / 4) nc = h->Tp / 4;
+    return nc >= 2 ? nc : 0;
 }
 
 int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb) {
@@ -724,6 +745,7 @@ bool tube_ready(pl_handle* h) { return h->tube.ready() && h->tmel.ready() && h->
 
 constexpr float kLeakySlope = 0.01f;   // torch.nn.LeakyReLU() default (paule/models.py:374, :425)
 
+void emb_head_forward(pl_handle* h, hipStream_t st, const int32_t* lens);
 // mel_bm: the embedder's input batch-major [B][Tp][M] f32 (read by the mel blocks only); h->mel_tm holds the same time-major
 void emb_forward(pl_handle* h, hipStream_t st, const int32_t* lens, const float* mel_bm) {
     Model& e = h->emb;
@@ -740,6 +762,12 @@ void emb_forward(pl_handle* h, hipStream_t st, const int32_t* lens, const float*
         in_tm = h->emb_in;
     }
     model_forward(h, st, e, in_tm);
+    emb_head_forward(h, st, lens);
+}
+
+// output at lens - 1, then linear_mapping or post_linear -> LeakyReLU -> output mapping
+void emb_head_forward(pl_handle* h, hipStream_t st, const int32_t* lens) {
+    Model& e = h->emb;
     launch_gather_last(st, h->dt, e.layers[e.L - 1].h, lens, h->B, e.Tl, h->Bp, e.Hp, h->h_last);
     if (h->emb_post == 0) {
         launch_gemm_nt(st, h->dt, true, h->h_last, e.Hp, e.Wlin, e.Hp, e.blin, h->sem, h->Sp, h->Bp, h->Sp, e.Hp);
@@ -753,7 +781,7 @@ void emb_forward(pl_handle* h, hipStream_t st, const int32_t* lens, const float*
 }
 
 // dL/dsem (h->dsem) back through the embedder to dL/dmel (h->dmel_e, time-major f32 [Tp][Bp][Mp])
-void emb_backward(pl_handle* h, hipStream_t st) {
+void emb_head_backward(pl_handle* h, hipStream_t st) {
     Model& e = h->emb;
     if (h->emb_post == 0) {
         // dL/dh_last = dsem * W_m
@@ -764,6 +792,11 @@ void emb_backward(pl_handle* h, hipStream_t st) {
         launch_leaky_bwd(st, h->dt, h->head_d, h->head_pre, (int64_t)h->Bp * Pp, kLeakySlope, h->head_act);
         launch_gemm_nt(st, h->dt, false, h->head_act, Pp, e.WlinT, Pp, nullptr, h->dv, e.Hp, h->Bp, e.Hp, Pp);
     }
+}
+
+void emb_backward(pl_handle* h, hipStream_t st) {
+    Model& e = h->emb;
+    emb_head_backward(h, st);
     if (h->emb_blocks == 0) {
         model_backward(h, st, e, h->dv, h->dmel_e);
         return;
@@ -818,6 +851,155 @@ void tube_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
     model_backward(h, st, u, nullptr, h->dX2);
 }
 
+// ---- cross-model pipeline of the acoustic path (acoustic_pipeline_chunks) ---------------------------------------------------
+// Stage 0 = predictor (sweep chunk, then post_linear and pooling of its frames), stage k >= 1 = embedder layer k - 1 on the
+// pooled frames of the same chunk.  Segment (stage, chunk) waits for (stage - 1, chunk) and (stage, chunk - 1): the structure of
+// the layer wavefront with a model boundary inside, same eager / capture mechanics.
+struct PipeCtx {
+    pl_handle* h; hipStream_t st; bool cap; int nst;
+    hipStream_t ls[8]; hipEvent_t ev[8];
+    PipeCtx(pl_handle* hh, hipStream_t s, int n_stages) : h(hh), st(s), cap(hh->capturing), nst(n_stages) {
+        if (cap) h->wf_regions.emplace_back();
+        for (int i = 0; i < nst; ++i) { ls[i] = (i == 0 || cap) ? st : wavefront_stream(h); ev[i] = nullptr; }
+    }
+    pl_handle::WfSeg seg;
+    hipStream_t begin(int stage, int k_chunk) {   // k_chunk: chunks in launch order
+        seg = pl_handle::WfSeg{cap ? capture_tail(st) : nullptr, nullptr, stage > 0 ? k_chunk * nst + stage - 1 : -1,
+                               k_chunk > 0 ? (k_chunk - 1) * nst + stage : -1};
+        if (!cap && stage > 0) (void)hipStreamWaitEvent(ls[stage], ev[stage - 1], 0);
+        return ls[stage];
+    }
+    void end(int stage, int k_chunk, bool last_chunk) {
+        if (cap) {
+            seg.last = capture_tail(st);
+            h->wf_regions.back().segs.push_back(seg);
+            if (last_chunk) h->wf_regions.back().finals.push_back(k_chunk * nst + stage);
+        } else {
+            ev[stage] = wavefront_event(h);
+            (void)hipEventRecord(ev[stage], ls[stage]);
+        }
+    }
+    void join() {
+        if (!cap)
+            for (int i = 1; i < nst; ++i) (void)hipStreamWaitEvent(st, ev[i], 0);
+    }
+};
+
+void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
+    Model &p = h->pred, &e = h->emb;
+    const int Bp = h->Bp, T = h->T, Tp = h->Tp;
+    const size_t a = h->act;
+    launch_pack_cp(st, h->dt, h->x, h->B, T, h->C, h->X0, Bp, h->Cp);
+    int* slice[8];
+    slice[0] = take_sweep_slice(h, st);
+    for (int l = 0; l < e.L; ++l) slice[1 + l] = take_sweep_slice(h, st);
+    PipeCtx px(h, st, 1 + e.L);
+    const int grid_p = sweep_grid_for(h, p.Hp), grid_e = sweep_grid_for(h, e.Hp);
+    for (int c = 0; c < nc; ++c) {
+        const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
+        const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;   // an odd last frame runs with the last chunk
+        {   // predictor
+            hipStream_t sl = px.begin(0, c);
+            LstmLayer& ly = p.layers[0];
+            const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
+            if (!fuse_in)
+                launch_gemm_nt(sl, h->dt, false, off(h->X0, (size_t)t0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p, ly.bias,
+                               off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, (t1 - t0) * Bp, 4 * p.Hp, ly.in_p);
+            LstmSweepArgs s{};
+            fill_sweep_common(h, s, T, slice[0]);
+            s.G = ly.G; s.W = ly.Whh; s.h = ly.h; s.c = ly.c;
+            if (fuse_in) { s.x_in = h->X0; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
+            s.stash_via_lds = h->stash_lds ? 1 : 0;
+            s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
+            launch_sweep(h, sl, false, p.Hp, grid_p, s);
+            launch_gemm_nt(sl, h->dt, true, off(ly.h, (size_t)t0 * Bp * p.Hp, a), p.Hp, p.Wlin, p.Hp, p.blin,
+                           h->Y + (size_t)t0 * Bp * h->Mp, h->Mp, (t1 - t0) * Bp, h->Mp, p.Hp);
+            launch_pool_mel(sl, h->dt, h->Y, h->B, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm, e0, e1 - e0);
+            px.end(0, c, c == nc - 1);
+        }
+        for (int l = 0; l < e.L; ++l) {   // embedder layers on the pooled frames e0 .. e1-1
+            hipStream_t sl = px.begin(1 + l, c);
+            LstmLayer& ly = e.layers[l];
+            const void* cur_in = l == 0 ? h->mel_tm : e.layers[l - 1].h;
+            const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
+            if (!fuse_in)
+                launch_gemm_nt(sl, h->dt, false, off(const_cast<void*>(cur_in), (size_t)e0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p,
+                               ly.bias, off(ly.G, (size_t)e0 * Bp * 4 * e.Hp, a), 4 * e.Hp, (e1 - e0) * Bp, 4 * e.Hp, ly.in_p);
+            LstmSweepArgs s{};
+            fill_sweep_common(h, s, Tp, slice[1 + l]);
+            s.G = ly.G; s.W = ly.Whh; s.h = ly.h; s.c = ly.c;
+            if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
+            s.stash_via_lds = h->stash_lds ? 1 : 0;
+            s.t0 = e0; s.t1 = e1; s.carry = ly.carry_f;
+            launch_sweep(h, sl, false, e.Hp, grid_e, s);
+            px.end(1 + l, c, c == nc - 1);
+        }
+    }
+    px.join();
+    emb_head_forward(h, st, nullptr);
+}
+
+// backward: embedder layers top .. 0, then dY rows, dY W_p rows and the predictor, chunk by chunk from the last one
+void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs& la) {
+    Model &p = h->pred, &e = h->emb;
+    const int Bp = h->Bp, T = h->T, Tp = h->Tp;
+    const size_t a = h->act;
+    launch_dsem(st, h->dt, la, h->dsem);
+    emb_head_backward(h, st);
+    int* slice[8];
+    for (int l = e.L - 1; l >= 0; --l) slice[l] = take_sweep_slice(h, st);
+    int* slice_p = take_sweep_slice(h, st);
+    PipeCtx px(h, st, 1 + e.L);   // stage i = embedder layer L-1-i, last stage = predictor
+    const int grid_p = sweep_grid_for(h, p.Hp, true), grid_e = sweep_grid_for(h, e.Hp, true);
+    const int bwd_flags = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
+    for (int k = 0; k < nc; ++k) {
+        const int c = nc - 1 - k;
+        const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
+        const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;
+        for (int i = 0; i < e.L; ++i) {
+            const int l = e.L - 1 - i;
+            hipStream_t sl = px.begin(i, k);
+            LstmLayer& ly = e.layers[l];
+            const bool top = l == e.L - 1;
+            LstmSweepArgs s{};
+            fill_sweep_common(h, s, Tp, slice[l]);
+            s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
+            s.dh_ext = top ? nullptr : e.dh_ext;
+            s.dh_last = top ? h->dv : nullptr;
+            s.xchg = ly.xchg;
+            s.stash_via_lds = bwd_flags;
+            s.t0 = e0; s.t1 = e1; s.carry = ly.carry_b;
+            launch_sweep(h, sl, true, e.Hp, grid_e, s);
+            if (l > 0)
+                launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)e0 * Bp * 4 * e.Hp, a), 4 * e.Hp, ly.WihT, 4 * e.Hp, nullptr,
+                               off(e.dh_ext, (size_t)e0 * Bp * e.Hp, a), e.Hp, (e1 - e0) * Bp, e.Hp, 4 * e.Hp);
+            else
+                launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)e0 * Bp * 4 * e.Hp, a), 4 * e.Hp, ly.WihT, 4 * e.Hp, nullptr,
+                               h->dmel_e + (size_t)e0 * Bp * ly.in_p, ly.in_p, (e1 - e0) * Bp, ly.in_p, 4 * e.Hp);
+            px.end(i, k, c == 0);
+        }
+        {   // predictor: dL/dY of its frames, dL/dh_top = dY W_p, the sweep, dL/dCP rows
+            hipStream_t sl = px.begin(e.L, k);
+            LstmLayer& ly = p.layers[0];
+            launch_dy(sl, h->dt, la, h->dmel_e, h->dY, false, t0, t1 - t0);
+            launch_gemm_nt(sl, h->dt, false, off(h->dY, (size_t)t0 * Bp * h->Mp, a), h->Mp, p.WlinT, h->Mp, nullptr,
+                           off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, h->Mp);
+            LstmSweepArgs s{};
+            fill_sweep_common(h, s, T, slice_p);
+            s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
+            s.dh_ext = p.dh_ext;
+            s.xchg = ly.xchg;
+            s.stash_via_lds = bwd_flags;
+            s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
+            launch_sweep(h, sl, true, p.Hp, grid_p, s);
+            launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr,
+                           h->dX + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * p.Hp);
+            px.end(e.L, k, c == 0);
+        }
+    }
+    px.join();
+}
+
 LossArgs loss_args(pl_handle* h, bool with_sem) {
     LossArgs a{};
     a.B = h->B; a.T = h->T; a.Tp = h->Tp; a.C = h->C; a.M = h->M; a.S = h->S;
@@ -855,23 +1037,32 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     h->wf_next = 0;
     h->wf_stream_next = 0;
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
-    pred_forward(h, st);
-    if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
+    const int pipe_nc = acoustic_pipeline_chunks(h);
+    if (pipe_nc) {
+        acoustic_forward_pipeline(h, st, pipe_nc);
+    } else {
+        pred_forward(h, st);
+        if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
+    }
     if (h->tube_on()) tube_forward(h, st);
     LossArgs la = loss_args(h, with_sem);
     launch_loss_reduce(st, la);
     launch_loss_finalize(st, la);
-    const float* dmel_e = nullptr;
-    if (with_sem) {
-        launch_dsem(st, h->dt, la, h->dsem);
-        emb_backward(h, st);
-        dmel_e = h->dmel_e;
+    if (pipe_nc) {
+        acoustic_backward_pipeline(h, st, pipe_nc, la);
+    } else {
+        const float* dmel_e = nullptr;
+        if (with_sem) {
+            launch_dsem(st, h->dt, la, h->dsem);
+            emb_backward(h, st);
+            dmel_e = h->dmel_e;
+        }
+        launch_dy(st, h->dt, la, dmel_e, h->dY);
+        Model& p = h->pred;
+        // dL/dh_top(t) = dY_t * W_p
+        launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, h->T * h->Bp, p.Hp, h->Mp);
+        model_backward(h, st, p, nullptr, h->dX);
     }
-    launch_dy(st, h->dt, la, dmel_e, h->dY);
-    Model& p = h->pred;
-    // dL/dh_top(t) = dY_t * W_p
-    launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, h->T * h->Bp, p.Hp, h->Mp);
-    model_backward(h, st, p, nullptr, h->dX);
     if (h->tube_on()) tube_backward(h, st, la);
     AdamArgs aa = adam_args(h);
     launch_total_grad(st, aa);
@@ -1202,11 +1393,14 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
         }
         if (const char* z = std::getenv("PAULE_HIP_F32_VALU")) h->f32_valu = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_WF_PIPELINE")) h->wf_pipeline = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WAVEFRONT")) h->wavefront = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
         if (h->wavefront > 0 && h->use_sweep) {
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
-                if (md->L < 2 || wavefront_depth(h, *md) < 2) continue;
+                const int pxcd = sweep_per_xcd(h, *md);
+                const bool pipe = (md == &h->pred || md == &h->emb) && cfg->emb_layers > 0 && h->pred.L == 1 && pxcd > 0 && 2 * pxcd <= h->n_cu / 8;
+                if ((md->L < 2 || wavefront_depth(h, *md) < 2) && !pipe) continue;
                 const size_t xb = h->dt == F32 ? (lstm_sweep_f32_supported(md->Hp) ? lstm_f32_exchange_bytes(md->Hp, h->Bp) : 0)
                                                : (lstm_sweep_supported(h->dt, md->Hp) ? lstm_rs_exchange_bytes(md->Hp, h->Bp) : 0);
                 if (!xb) continue;
@@ -1220,8 +1414,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             // streams and events of an iteration up front (none is created while a capture is running)
             size_t n_streams = 0, n_events = 0;
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb})
-                if (md->L >= 2 && md->layers[0].carry_f) {
-                    n_streams += 2 * (size_t)(md->L - 1);
+                if (md->L >= 1 && md->layers[0].carry_f) {
+                    n_streams += 2 * (size_t)md->L;
                     n_events += 2 * (size_t)md->L * (size_t)(h->wavefront < 32 ? h->wavefront : 32);
                 }
             if (cfg->device >= 0 && cfg->device < SweepChain::kMaxDev) {

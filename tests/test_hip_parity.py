@@ -997,6 +997,32 @@ def test_feature_combinations_f32_vs_oracle(HipPlanner, golden_soma, golden_embv
     np.testing.assert_allclose(_n(eng.get_cp()), _n(P.get_cp()), atol=CP_ATOL_F32, rtol=0)
 
 
+@pytest.mark.parametrize("shape", [dict(B=1, T=64, objective="acoustic_semvec", graph=True), dict(B=5, T=61, objective="semvec", graph=True),
+                                   dict(B=16, T=46, objective="acoustic_semvec", graph=False), dict(B=3, T=40, objective="acoustic_semvec", graph=True, variant=True),
+                                   dict(B=2, T=51, objective="acoustic_semvec", graph=True, classifier=True)])
+def test_acoustic_pipeline_is_bit_identical(HipPlanner, golden_small, golden_embvar, shape, monkeypatch):
+    """Small f32 batches run predictor -> mel head + pooling -> embedder layers as ONE pipeline over time chunks, forward and
+    backward (planner.hip, acoustic_forward_pipeline / acoustic_backward_pipeline): same kernels on frame ranges, so losses,
+    gradients, CP and predictions are bit-identical to the model-after-model schedule (odd T, semvec objective, speech
+    classifier, an embedder with a post_linear head, eager and graph)."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "A")
+    emb_sd = state_dict_from(golden_embvar, "upsampling/emb") if shape.get("variant") else wl.emb_sd
+    outs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("PAULE_HIP_WF_PIPELINE", pipe)
+        eng = HipPlanner(wl.pred_sd, emb_sd, batch=B, n_frames=T, objective=shape["objective"], use_graph=shape["graph"])
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        if shape.get("classifier"):
+            eng.set_speech_classifier(state_dict_from(golden_small, "clf"))
+        loss, grad = eng.step(1, return_grad=True)
+        more = eng.step(4)
+        outs.append((_n(loss), _n(grad), _n(more), _n(eng.get_cp())) + tuple(_n(x) for x in eng.get_pred()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
     """Nonzero return code -> ValueError with the library's message (the reference's convention for its one C library,
     paule/util.py:33-34): call-sequence errors (PL_ERR_STATE) and bad arguments (PL_ERR_INVALID); nothing aborts, and the
