@@ -536,14 +536,14 @@ int wavefront_depth(pl_handle* h, const Model& md) {
     return depth >= 2 ? depth : 0;
 }
 
-// Cross-model pipeline of the acoustic path (small batches): predictor (one layer) -> mel head + pooling -> embedder layers,
+// Cross-model pipeline of the acoustic path (small batches): predictor layers -> mel head + pooling -> embedder layers,
 // chunk by chunk, when one sweep of each fits side by side on every XCD.  Returns the number of chunks (of mel frames) or 0.
 int acoustic_pipeline_chunks(pl_handle* h) {
     if (h->wavefront <= 0 || !h->wf_pipeline || h->sweep_slot < 0 || !h->need_emb_in_step()) return 0;
     const Model &p = h->pred, &e = h->emb;
-    if (p.L != 1 || e.L < 1 || e.L > 7 || h->emb_blocks > 0 || !p.layers[0].carry_f || !e.layers[0].carry_f) return 0;
+    if (e.L < 1 || p.L + e.L > 8 || h->emb_blocks > 0 || !p.layers[0].carry_f || !e.layers[0].carry_f) return 0;
     const int pp = sweep_per_xcd(h, p), pe = sweep_per_xcd(h, e);
-    if (pp == 0 || pe == 0 || pp + e.L * pe > h->n_cu / 8) return 0;
+    if (pp == 0 || pe == 0 || p.L * pp + e.L * pe > h->n_cu / 8) return 0;
     if (h->sweep_slot != 0 || 2 * (p.L + e.L) > h->n_sweep_slots) return 0;
     int nc = h->wavefront < 32 ? h->wavefront : 32;
     if (nc > h->Tp / 4) nc = h->Tp / 4;
@@ -852,8 +852,8 @@ void tube_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
 }
 
 // ---- cross-model pipeline of the acoustic path (acoustic_pipeline_chunks) ---------------------------------------------------
-// Stage 0 = predictor (sweep chunk, then post_linear and pooling of its frames), stage k >= 1 = embedder layer k - 1 on the
-// pooled frames of the same chunk.  Segment (stage, chunk) waits for (stage - 1, chunk) and (stage, chunk - 1): the structure of
+// Stages = the predictor's layers (the top one also runs post_linear and the pooling of its frames), then the embedder's layers
+// on the pooled frames of the same chunk.  Segment (stage, chunk) waits for (stage - 1, chunk) and (stage, chunk - 1): the structure of
 // the layer wavefront with a model boundary inside, same eager / capture mechanics.
 struct PipeCtx {
     pl_handle* h; hipStream_t st; bool cap; int nst;
@@ -891,34 +891,36 @@ void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
     const size_t a = h->act;
     launch_pack_cp(st, h->dt, h->x, h->B, T, h->C, h->X0, Bp, h->Cp);
     int* slice[8];
-    slice[0] = take_sweep_slice(h, st);
-    for (int l = 0; l < e.L; ++l) slice[1 + l] = take_sweep_slice(h, st);
-    PipeCtx px(h, st, 1 + e.L);
+    for (int l = 0; l < p.L + e.L; ++l) slice[l] = take_sweep_slice(h, st);
+    PipeCtx px(h, st, p.L + e.L);   // stages: predictor layers 0 .. Lp-1, then embedder layers 0 .. Le-1
     const int grid_p = sweep_grid_for(h, p.Hp), grid_e = sweep_grid_for(h, e.Hp);
     for (int c = 0; c < nc; ++c) {
         const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
         const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;   // an odd last frame runs with the last chunk
-        {   // predictor
-            hipStream_t sl = px.begin(0, c);
-            LstmLayer& ly = p.layers[0];
+        for (int l = 0; l < p.L; ++l) {   // predictor layers on frames t0 .. t1-1; the top one also runs the mel head and the pooling
+            hipStream_t sl = px.begin(l, c);
+            LstmLayer& ly = p.layers[l];
+            const void* cur_in = l == 0 ? h->X0 : p.layers[l - 1].h;
             const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
             if (!fuse_in)
-                launch_gemm_nt(sl, h->dt, false, off(h->X0, (size_t)t0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p, ly.bias,
-                               off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, (t1 - t0) * Bp, 4 * p.Hp, ly.in_p);
+                launch_gemm_nt(sl, h->dt, false, off(const_cast<void*>(cur_in), (size_t)t0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p,
+                               ly.bias, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, (t1 - t0) * Bp, 4 * p.Hp, ly.in_p);
             LstmSweepArgs s{};
-            fill_sweep_common(h, s, T, slice[0]);
+            fill_sweep_common(h, s, T, slice[l]);
             s.G = ly.G; s.W = ly.Whh; s.h = ly.h; s.c = ly.c;
-            if (fuse_in) { s.x_in = h->X0; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
+            if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
             s.stash_via_lds = h->stash_lds ? 1 : 0;
             s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
             launch_sweep(h, sl, false, p.Hp, grid_p, s);
-            launch_gemm_nt(sl, h->dt, true, off(ly.h, (size_t)t0 * Bp * p.Hp, a), p.Hp, p.Wlin, p.Hp, p.blin,
-                           h->Y + (size_t)t0 * Bp * h->Mp, h->Mp, (t1 - t0) * Bp, h->Mp, p.Hp);
-            launch_pool_mel(sl, h->dt, h->Y, h->B, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm, e0, e1 - e0);
-            px.end(0, c, c == nc - 1);
+            if (l == p.L - 1) {
+                launch_gemm_nt(sl, h->dt, true, off(ly.h, (size_t)t0 * Bp * p.Hp, a), p.Hp, p.Wlin, p.Hp, p.blin,
+                               h->Y + (size_t)t0 * Bp * h->Mp, h->Mp, (t1 - t0) * Bp, h->Mp, p.Hp);
+                launch_pool_mel(sl, h->dt, h->Y, h->B, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm, e0, e1 - e0);
+            }
+            px.end(l, c, c == nc - 1);
         }
         for (int l = 0; l < e.L; ++l) {   // embedder layers on the pooled frames e0 .. e1-1
-            hipStream_t sl = px.begin(1 + l, c);
+            hipStream_t sl = px.begin(p.L + l, c);
             LstmLayer& ly = e.layers[l];
             const void* cur_in = l == 0 ? h->mel_tm : e.layers[l - 1].h;
             const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
@@ -926,30 +928,32 @@ void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
                 launch_gemm_nt(sl, h->dt, false, off(const_cast<void*>(cur_in), (size_t)e0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p,
                                ly.bias, off(ly.G, (size_t)e0 * Bp * 4 * e.Hp, a), 4 * e.Hp, (e1 - e0) * Bp, 4 * e.Hp, ly.in_p);
             LstmSweepArgs s{};
-            fill_sweep_common(h, s, Tp, slice[1 + l]);
+            fill_sweep_common(h, s, Tp, slice[p.L + l]);
             s.G = ly.G; s.W = ly.Whh; s.h = ly.h; s.c = ly.c;
             if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
             s.stash_via_lds = h->stash_lds ? 1 : 0;
             s.t0 = e0; s.t1 = e1; s.carry = ly.carry_f;
             launch_sweep(h, sl, false, e.Hp, grid_e, s);
-            px.end(1 + l, c, c == nc - 1);
+            px.end(p.L + l, c, c == nc - 1);
         }
     }
     px.join();
     emb_head_forward(h, st, nullptr);
 }
 
-// backward: embedder layers top .. 0, then dY rows, dY W_p rows and the predictor, chunk by chunk from the last one
+// backward: embedder layers top .. 0, then the predictor layers top .. 0 (the top one starts with the dY rows of its frames and
+// dY W_p), chunk by chunk from the last one
 void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs& la) {
     Model &p = h->pred, &e = h->emb;
     const int Bp = h->Bp, T = h->T, Tp = h->Tp;
     const size_t a = h->act;
     launch_dsem(st, h->dt, la, h->dsem);
     emb_head_backward(h, st);
-    int* slice[8];
-    for (int l = e.L - 1; l >= 0; --l) slice[l] = take_sweep_slice(h, st);
-    int* slice_p = take_sweep_slice(h, st);
-    PipeCtx px(h, st, 1 + e.L);   // stage i = embedder layer L-1-i, last stage = predictor
+    int* slice_e[8];
+    int* slice_p[8];
+    for (int l = e.L - 1; l >= 0; --l) slice_e[l] = take_sweep_slice(h, st);
+    for (int l = p.L - 1; l >= 0; --l) slice_p[l] = take_sweep_slice(h, st);
+    PipeCtx px(h, st, p.L + e.L);   // stage i < Le: embedder layer Le-1-i; stage Le + i: predictor layer Lp-1-i
     const int grid_p = sweep_grid_for(h, p.Hp, true), grid_e = sweep_grid_for(h, e.Hp, true);
     const int bwd_flags = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
     for (int k = 0; k < nc; ++k) {
@@ -962,7 +966,7 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
             LstmLayer& ly = e.layers[l];
             const bool top = l == e.L - 1;
             LstmSweepArgs s{};
-            fill_sweep_common(h, s, Tp, slice[l]);
+            fill_sweep_common(h, s, Tp, slice_e[l]);
             s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
             s.dh_ext = top ? nullptr : e.dh_ext;
             s.dh_last = top ? h->dv : nullptr;
@@ -978,23 +982,30 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
                                h->dmel_e + (size_t)e0 * Bp * ly.in_p, ly.in_p, (e1 - e0) * Bp, ly.in_p, 4 * e.Hp);
             px.end(i, k, c == 0);
         }
-        {   // predictor: dL/dY of its frames, dL/dh_top = dY W_p, the sweep, dL/dCP rows
-            hipStream_t sl = px.begin(e.L, k);
-            LstmLayer& ly = p.layers[0];
-            launch_dy(sl, h->dt, la, h->dmel_e, h->dY, false, t0, t1 - t0);
-            launch_gemm_nt(sl, h->dt, false, off(h->dY, (size_t)t0 * Bp * h->Mp, a), h->Mp, p.WlinT, h->Mp, nullptr,
-                           off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, h->Mp);
+        for (int i = 0; i < p.L; ++i) {
+            const int l = p.L - 1 - i;
+            hipStream_t sl = px.begin(e.L + i, k);
+            LstmLayer& ly = p.layers[l];
+            if (l == p.L - 1) {   // dL/dY of the chunk's frames (it reads the embedder's input-gradient rows of this chunk), dL/dh_top = dY W_p
+                launch_dy(sl, h->dt, la, h->dmel_e, h->dY, false, t0, t1 - t0);
+                launch_gemm_nt(sl, h->dt, false, off(h->dY, (size_t)t0 * Bp * h->Mp, a), h->Mp, p.WlinT, h->Mp, nullptr,
+                               off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, h->Mp);
+            }
             LstmSweepArgs s{};
-            fill_sweep_common(h, s, T, slice_p);
+            fill_sweep_common(h, s, T, slice_p[l]);
             s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
             s.dh_ext = p.dh_ext;
             s.xchg = ly.xchg;
             s.stash_via_lds = bwd_flags;
             s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
             launch_sweep(h, sl, true, p.Hp, grid_p, s);
-            launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr,
-                           h->dX + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * p.Hp);
-            px.end(e.L, k, c == 0);
+            if (l > 0)   // in place in p.dh_ext, as in the layer wavefront
+                launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr,
+                               off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, 4 * p.Hp);
+            else
+                launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr,
+                               h->dX + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * p.Hp);
+            px.end(e.L + i, k, c == 0);
         }
     }
     px.join();
@@ -1399,7 +1410,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (h->wavefront > 0 && h->use_sweep) {
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
                 const int pxcd = sweep_per_xcd(h, *md);
-                const bool pipe = (md == &h->pred || md == &h->emb) && cfg->emb_layers > 0 && h->pred.L == 1 && pxcd > 0 && 2 * pxcd <= h->n_cu / 8;
+                const bool pipe = (md == &h->pred || md == &h->emb) && cfg->emb_layers > 0 && pxcd > 0 && 2 * pxcd <= h->n_cu / 8;
                 if ((md->L < 2 || wavefront_depth(h, *md) < 2) && !pipe) continue;
                 const size_t xb = h->dt == F32 ? (lstm_sweep_f32_supported(md->Hp) ? lstm_f32_exchange_bytes(md->Hp, h->Bp) : 0)
                                                : (lstm_sweep_supported(h->dt, md->Hp) ? lstm_rs_exchange_bytes(md->Hp, h->Bp) : 0);

@@ -999,14 +999,15 @@ def test_feature_combinations_f32_vs_oracle(HipPlanner, golden_soma, golden_embv
 
 @pytest.mark.parametrize("shape", [dict(B=1, T=64, objective="acoustic_semvec", graph=True), dict(B=5, T=61, objective="semvec", graph=True),
                                    dict(B=16, T=46, objective="acoustic_semvec", graph=False), dict(B=3, T=40, objective="acoustic_semvec", graph=True, variant=True),
-                                   dict(B=2, T=51, objective="acoustic_semvec", graph=True, classifier=True)])
+                                   dict(B=2, T=51, objective="acoustic_semvec", graph=True, classifier=True),
+                                   dict(B=4, T=57, objective="acoustic_semvec", graph=True, set="B"), dict(B=18, T=44, objective="semvec", graph=False, set="B")])
 def test_acoustic_pipeline_is_bit_identical(HipPlanner, golden_small, golden_embvar, shape, monkeypatch):
     """Small f32 batches run predictor -> mel head + pooling -> embedder layers as ONE pipeline over time chunks, forward and
     backward (planner.hip, acoustic_forward_pipeline / acoustic_backward_pipeline): same kernels on frame ranges, so losses,
     gradients, CP and predictions are bit-identical to the model-after-model schedule (odd T, semvec objective, speech
     classifier, an embedder with a post_linear head, eager and graph)."""
     B, T = shape["B"], shape["T"]
-    wl = synthetic.make_workload(B, T, "A")
+    wl = synthetic.make_workload(B, T, shape.get("set", "A"))   # set B: a stacked predictor (4 x 180) in front of the embedder
     emb_sd = state_dict_from(golden_embvar, "upsampling/emb") if shape.get("variant") else wl.emb_sd
     outs = []
     for pipe in ("1", "0"):
