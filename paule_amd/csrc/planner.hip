@@ -1011,6 +1011,154 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
     px.join();
 }
 
+// one layer of a model on steps t0 .. t1-1 of its Tl-step recurrence (projection of the rows first unless it is fused)
+void fwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void* in_act, int Tl, int t0, int t1, int* slice) {
+    const int Bp = h->Bp, Hp = md.Hp;
+    const size_t a = h->act;
+    LstmLayer& ly = md.layers[l];
+    const void* cur_in = l == 0 ? in_act : md.layers[l - 1].h;
+    const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
+    if (!fuse_in)
+        launch_gemm_nt(sl, h->dt, false, off(const_cast<void*>(cur_in), (size_t)t0 * Bp * ly.in_p, a), ly.in_p, ly.Wih, ly.in_p, ly.bias,
+                       off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, (t1 - t0) * Bp, 4 * Hp, ly.in_p);
+    LstmSweepArgs s{};
+    fill_sweep_common(h, s, Tl, slice);
+    s.G = ly.G; s.W = ly.Whh; s.h = ly.h; s.c = ly.c;
+    if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
+    s.stash_via_lds = h->stash_lds ? 1 : 0;
+    s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
+    launch_sweep(h, sl, false, Hp, sweep_grid_for(h, Hp), s);
+}
+
+// backward of one layer on steps t0 .. t1-1: the sweep, then dL/dh rows for the layer below (in place in md.dh_ext) or, for
+// layer 0, the input gradient rows into dIn (f32 time-major [Tl][Bp][in_p])
+void bwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void* dh_last, float* dIn, int Tl, int t0, int t1, int* slice) {
+    const int Bp = h->Bp, Hp = md.Hp;
+    const size_t a = h->act;
+    LstmLayer& ly = md.layers[l];
+    const bool sparse_top = l == md.L - 1 && dh_last;
+    LstmSweepArgs s{};
+    fill_sweep_common(h, s, Tl, slice);
+    s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
+    s.dh_ext = sparse_top ? nullptr : md.dh_ext;
+    s.dh_last = sparse_top ? dh_last : nullptr;
+    s.xchg = ly.xchg;
+    s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
+    s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
+    launch_sweep(h, sl, true, Hp, sweep_grid_for(h, Hp, true), s);
+    if (l > 0)
+        launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
+                       off(md.dh_ext, (size_t)t0 * Bp * Hp, a), Hp, (t1 - t0) * Bp, Hp, 4 * Hp);
+    else
+        launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
+                       dIn + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * Hp);
+}
+
+// ---- the somatosensory path as a pipeline over time chunks (small batches) ------------------------------------------------------
+// Stages: CP -> tube layers (the top one followed by its post_linear rows), the tube embedder's layers, the tube -> mel layers (the
+// top one followed by post_linear rows and the pooling).  The chain order makes the tube -> mel stages wait for the embedder's
+// stages of the same chunk too -- more than they need, but the pipeline keeps flowing and the bookkeeping stays a chain.
+int tube_pipeline_chunks(pl_handle* h) {
+    if (h->wavefront <= 0 || !h->wf_pipeline || h->sweep_slot < 0 || !h->tube_on()) return 0;
+    const Model &u = h->tube, &m = h->tmel, &e = h->temb;
+    if (u.L + m.L + e.L > 8) return 0;
+    int per = 0;
+    for (const Model* md : {&u, &m, &e}) {
+        const int px = sweep_per_xcd(h, *md);
+        if (px == 0 || !md->layers[0].carry_f) return 0;
+        per += md->L * px;
+    }
+    if (per > h->n_cu / 8) return 0;
+    if (h->sweep_slot + u.L + m.L + e.L > h->n_sweep_slots) return 0;
+    int nc = h->wavefront < 32 ? h->wavefront : 32;
+    if (nc > h->Tp / 4) nc = h->Tp / 4;
+    return nc >= 2 ? nc : 0;
+}
+
+void tube_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
+    Model &u = h->tube, &m = h->tmel, &e = h->temb;
+    const int Bp = h->Bp, T = h->T, Tp = h->Tp, nst = u.L + e.L + m.L;
+    const size_t a = h->act;
+    int* slice[8];
+    for (int i = 0; i < nst; ++i) slice[i] = take_sweep_slice(h, st);
+    PipeCtx px(h, st, nst);
+    for (int c = 0; c < nc; ++c) {
+        const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
+        const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;
+        int stage = 0;
+        for (int l = 0; l < u.L; ++l, ++stage) {
+            hipStream_t sl = px.begin(stage, c);
+            fwd_layer_chunk(h, sl, u, l, h->X0, T, t0, t1, slice[stage]);
+            if (l == u.L - 1)
+                launch_gemm_nt(sl, h->dt, false, off(u.layers[l].h, (size_t)t0 * Bp * u.Hp, a), u.Hp, u.Wlin, u.Hp, u.blin,
+                               off(h->tube_tm, (size_t)t0 * Bp * h->Up, a), h->Up, (t1 - t0) * Bp, h->Up, u.Hp);
+            px.end(stage, c, c == nc - 1);
+        }
+        for (int l = 0; l < e.L; ++l, ++stage) {
+            hipStream_t sl = px.begin(stage, c);
+            fwd_layer_chunk(h, sl, e, l, h->tube_tm, T, t0, t1, slice[stage]);
+            px.end(stage, c, c == nc - 1);
+        }
+        for (int l = 0; l < m.L; ++l, ++stage) {
+            hipStream_t sl = px.begin(stage, c);
+            fwd_layer_chunk(h, sl, m, l, h->tube_tm, T, t0, t1, slice[stage]);
+            if (l == m.L - 1) {
+                launch_gemm_nt(sl, h->dt, true, off(m.layers[l].h, (size_t)t0 * Bp * m.Hp, a), m.Hp, m.Wlin, m.Hp, m.blin,
+                               h->Y2 + (size_t)t0 * Bp * h->Mp, h->Mp, (t1 - t0) * Bp, h->Mp, m.Hp);
+                launch_pool_mel(sl, h->dt, h->Y2, h->B, T, h->M, Bp, h->Mp, h->mel2_bm, h->mel2_tm, e0, e1 - e0);
+            }
+            px.end(stage, c, c == nc - 1);
+        }
+    }
+    px.join();
+    launch_gather_last(st, h->dt, e.layers[e.L - 1].h, nullptr, h->B, e.Tl, Bp, e.Hp, h->h_last2);
+    launch_gemm_nt(st, h->dt, true, h->h_last2, e.Hp, e.Wlin, e.Hp, e.blin, h->sem2, h->Sp, Bp, h->Sp, e.Hp);
+}
+
+void tube_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs& la) {
+    Model &u = h->tube, &m = h->tmel, &e = h->temb;
+    const int Bp = h->Bp, T = h->T, Tp = h->Tp, nst = u.L + e.L + m.L;
+    const size_t a = h->act;
+    launch_dsem(st, h->dt, la, h->dsem2, true);
+    launch_gemm_nt(st, h->dt, false, h->dsem2, h->Sp, e.WlinT, h->Sp, nullptr, h->dv2, e.Hp, Bp, e.Hp, h->Sp);
+    int* slice[8];
+    for (int i = 0; i < nst; ++i) slice[i] = take_sweep_slice(h, st);
+    PipeCtx px(h, st, nst);   // stages: embedder layers top .. 0, tube -> mel layers top .. 0, CP -> tube layers top .. 0
+    for (int k = 0; k < nc; ++k) {
+        const int c = nc - 1 - k;
+        const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
+        const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;
+        int stage = 0;
+        for (int l = e.L - 1; l >= 0; --l, ++stage) {
+            hipStream_t sl = px.begin(stage, k);
+            bwd_layer_chunk(h, sl, e, l, h->dv2, h->dtube_a, T, t0, t1, slice[stage]);
+            px.end(stage, k, c == 0);
+        }
+        for (int l = m.L - 1; l >= 0; --l, ++stage) {
+            hipStream_t sl = px.begin(stage, k);
+            if (l == m.L - 1) {
+                launch_dy(sl, h->dt, la, nullptr, h->dY2, true, t0, t1 - t0);
+                launch_gemm_nt(sl, h->dt, false, off(h->dY2, (size_t)t0 * Bp * h->Mp, a), h->Mp, m.WlinT, h->Mp, nullptr,
+                               off(m.dh_ext, (size_t)t0 * Bp * m.Hp, a), m.Hp, (t1 - t0) * Bp, m.Hp, h->Mp);
+            }
+            bwd_layer_chunk(h, sl, m, l, nullptr, h->dtube_b, T, t0, t1, slice[stage]);
+            px.end(stage, k, c == 0);
+        }
+        for (int l = u.L - 1; l >= 0; --l, ++stage) {
+            hipStream_t sl = px.begin(stage, k);
+            if (l == u.L - 1) {   // the two gradient streams meet at the predicted tube
+                launch_add2_act(sl, h->dt, h->dtube_a + (size_t)t0 * Bp * h->Up, h->dtube_b + (size_t)t0 * Bp * h->Up,
+                                (int64_t)(t1 - t0) * Bp * h->Up, off(h->dYt, (size_t)t0 * Bp * h->Up, a));
+                launch_gemm_nt(sl, h->dt, false, off(h->dYt, (size_t)t0 * Bp * h->Up, a), h->Up, u.WlinT, h->Up, nullptr,
+                               off(u.dh_ext, (size_t)t0 * Bp * u.Hp, a), u.Hp, (t1 - t0) * Bp, u.Hp, h->Up);
+            }
+            bwd_layer_chunk(h, sl, u, l, nullptr, h->dX2, T, t0, t1, slice[stage]);
+            px.end(stage, k, c == 0);
+        }
+    }
+    px.join();
+}
+
 LossArgs loss_args(pl_handle* h, bool with_sem) {
     LossArgs a{};
     a.B = h->B; a.T = h->T; a.Tp = h->Tp; a.C = h->C; a.M = h->M; a.S = h->S;
@@ -1055,7 +1203,9 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
         pred_forward(h, st);
         if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
     }
-    if (h->tube_on()) tube_forward(h, st);
+    const int tube_nc = tube_pipeline_chunks(h);
+    if (tube_nc) tube_forward_pipeline(h, st, tube_nc);
+    else if (h->tube_on()) tube_forward(h, st);
     LossArgs la = loss_args(h, with_sem);
     launch_loss_reduce(st, la);
     launch_loss_finalize(st, la);
@@ -1074,7 +1224,8 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
         launch_gemm_nt(st, h->dt, false, h->dY, h->Mp, p.WlinT, h->Mp, nullptr, p.dh_ext, p.Hp, h->T * h->Bp, p.Hp, h->Mp);
         model_backward(h, st, p, nullptr, h->dX);
     }
-    if (h->tube_on()) tube_backward(h, st, la);
+    if (tube_nc) tube_backward_pipeline(h, st, tube_nc, la);
+    else if (h->tube_on()) tube_backward(h, st, la);
     AdamArgs aa = adam_args(h);
     launch_total_grad(st, aa);
     launch_adam_update(st, aa);
@@ -1410,7 +1561,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (h->wavefront > 0 && h->use_sweep) {
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
                 const int pxcd = sweep_per_xcd(h, *md);
-                const bool pipe = (md == &h->pred || md == &h->emb) && cfg->emb_layers > 0 && pxcd > 0 && 2 * pxcd <= h->n_cu / 8;
+                const bool pipe = cfg->emb_layers > 0 && pxcd > 0 && 2 * pxcd <= h->n_cu / 8;
                 if ((md->L < 2 || wavefront_depth(h, *md) < 2) && !pipe) continue;
                 const size_t xb = h->dt == F32 ? (lstm_sweep_f32_supported(md->Hp) ? lstm_f32_exchange_bytes(md->Hp, h->Bp) : 0)
                                                : (lstm_sweep_supported(h->dt, md->Hp) ? lstm_rs_exchange_bytes(md->Hp, h->Bp) : 0);
