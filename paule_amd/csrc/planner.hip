@@ -201,6 +201,7 @@ struct pl_handle {
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
     bool wide_ingest = true;    // PAULE_HIP_WIDE_INGEST: f32 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool wide_ingest16 = true;  // PAULE_HIP_WIDE_INGEST16: 16-row bf16 backward sweep sums the partial tiles with 16-byte loads, wave by wave
+    bool pipe_spread = true;    // PAULE_HIP_PIPE_SPREAD: pipelines launch small bf16 16-row sweeps spread over the XCDs (pipe_spread16)
     bool wf_pipeline = true;    // PAULE_HIP_WF_PIPELINE: predictor -> mel head -> embedder as one pipeline over time chunks (small batches)
     bool f32_valu = true;       // PAULE_HIP_F32_VALU: f32 sweeps of at most 4 rows in use run their recurrent products as FMA chains
     int rows_in_use = 0;        // batch rows that carry data (B); 0 inside pl_train_model_step (few-row kernels off)
@@ -527,6 +528,25 @@ int sweep_per_xcd(pl_handle* h, const Model& md) {
     return 0;
 }
 
+// Pipelines (not the layer wavefront) may launch the 16-row bf16 sweeps of fewer than 8 groups WITHOUT the 8 group slots: the
+// group's workgroups then spread over all XCDs (ceil(groups * P / 8) per XCD whatever the rotation of the launch) instead of
+// sitting together on one, which is what lets predictor and embedder sweeps of H = 720 run side by side.  The price is the
+// same-XCD exchange, which chunked launches do not use anyway.
+bool pipe_spread16(pl_handle* h, const Model& md) {
+    if (h->dt != BF16 || !h->pipe_spread || !h->small_grid || md.L < 1) return false;
+    if (!use_sweep16(h, md.Hp, false) || !use_sweep16(h, md.Hp, true)) return false;
+    const int P = md.Hp / 32, groups = (h->Bp + 15) / 16;
+    return groups < 8 && lstm_sweep16_grid(md.Hp, h->Bp, h->n_cu, false) == groups * P;
+}
+int pipe_per_xcd(pl_handle* h, const Model& md) {
+    if (pipe_spread16(h, md)) return ((h->Bp + 15) / 16 * (md.Hp / 32) + 7) / 8;
+    return sweep_per_xcd(h, md);
+}
+int pipe_grid(pl_handle* h, const Model& md, bool bwd) {
+    if (pipe_spread16(h, md)) return lstm_sweep16_grid(md.Hp, h->Bp, h->n_cu, false);
+    return sweep_grid_for(h, md.Hp, bwd);
+}
+
 int wavefront_depth(pl_handle* h, const Model& md) {
     const int per_xcd = sweep_per_xcd(h, md);
     if (md.L < 2 || per_xcd == 0) return 0;
@@ -542,7 +562,7 @@ int acoustic_pipeline_chunks(pl_handle* h) {
     if (h->wavefront <= 0 || !h->wf_pipeline || h->sweep_slot < 0 || !h->need_emb_in_step()) return 0;
     const Model &p = h->pred, &e = h->emb;
     if (e.L < 1 || p.L + e.L > 8 || h->emb_blocks > 0 || !p.layers[0].carry_f || !e.layers[0].carry_f) return 0;
-    const int pp = sweep_per_xcd(h, p), pe = sweep_per_xcd(h, e);
+    const int pp = pipe_per_xcd(h, p), pe = pipe_per_xcd(h, e);
     if (pp == 0 || pe == 0 || p.L * pp + e.L * pe > h->n_cu / 8) return 0;
     if (h->sweep_slot != 0 || 2 * (p.L + e.L) > h->n_sweep_slots) return 0;
     int nc = h->wavefront < 32 ? h->wavefront : 32;
@@ -893,7 +913,7 @@ void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
     int* slice[8];
     for (int l = 0; l < p.L + e.L; ++l) slice[l] = take_sweep_slice(h, st);
     PipeCtx px(h, st, p.L + e.L);   // stages: predictor layers 0 .. Lp-1, then embedder layers 0 .. Le-1
-    const int grid_p = sweep_grid_for(h, p.Hp), grid_e = sweep_grid_for(h, e.Hp);
+    const int grid_p = pipe_grid(h, p, false), grid_e = pipe_grid(h, e, false);
     for (int c = 0; c < nc; ++c) {
         const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
         const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;   // an odd last frame runs with the last chunk
@@ -954,7 +974,7 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
     for (int l = e.L - 1; l >= 0; --l) slice_e[l] = take_sweep_slice(h, st);
     for (int l = p.L - 1; l >= 0; --l) slice_p[l] = take_sweep_slice(h, st);
     PipeCtx px(h, st, p.L + e.L);   // stage i < Le: embedder layer Le-1-i; stage Le + i: predictor layer Lp-1-i
-    const int grid_p = sweep_grid_for(h, p.Hp, true), grid_e = sweep_grid_for(h, e.Hp, true);
+    const int grid_p = pipe_grid(h, p, true), grid_e = pipe_grid(h, e, true);
     const int bwd_flags = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
     for (int k = 0; k < nc; ++k) {
         const int c = nc - 1 - k;
@@ -1027,7 +1047,7 @@ void fwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void*
     if (fuse_in) { s.x_in = cur_in; s.Wih = ly.Wih; s.bias = ly.bias; s.in_p = ly.in_p; }
     s.stash_via_lds = h->stash_lds ? 1 : 0;
     s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
-    launch_sweep(h, sl, false, Hp, sweep_grid_for(h, Hp), s);
+    launch_sweep(h, sl, false, Hp, pipe_grid(h, md, false), s);
 }
 
 // backward of one layer on steps t0 .. t1-1: the sweep, then dL/dh rows for the layer below (in place in md.dh_ext) or, for
@@ -1045,7 +1065,7 @@ void bwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void*
     s.xchg = ly.xchg;
     s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
     s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
-    launch_sweep(h, sl, true, Hp, sweep_grid_for(h, Hp, true), s);
+    launch_sweep(h, sl, true, Hp, pipe_grid(h, md, true), s);
     if (l > 0)
         launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
                        off(md.dh_ext, (size_t)t0 * Bp * Hp, a), Hp, (t1 - t0) * Bp, Hp, 4 * Hp);
@@ -1064,7 +1084,7 @@ int tube_pipeline_chunks(pl_handle* h) {
     if (u.L + m.L + e.L > 8) return 0;
     int per = 0;
     for (const Model* md : {&u, &m, &e}) {
-        const int px = sweep_per_xcd(h, *md);
+        const int px = pipe_per_xcd(h, *md);
         if (px == 0 || !md->layers[0].carry_f) return 0;
         per += md->L * px;
     }
@@ -1556,12 +1576,14 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         }
         if (const char* z = std::getenv("PAULE_HIP_F32_VALU")) h->f32_valu = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WF_PIPELINE")) h->wf_pipeline = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_PIPE_SPREAD")) h->pipe_spread = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WAVEFRONT")) h->wavefront = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
         if (h->wavefront > 0 && h->use_sweep) {
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
                 const int pxcd = sweep_per_xcd(h, *md);
-                const bool pipe = cfg->emb_layers > 0 && pxcd > 0 && 2 * pxcd <= h->n_cu / 8;
+                const int ppx = pipe_per_xcd(h, *md);
+                const bool pipe = cfg->emb_layers > 0 && ppx > 0 && 2 * ppx <= h->n_cu / 8;
                 if ((md->L < 2 || wavefront_depth(h, *md) < 2) && !pipe) continue;
                 const size_t xb = h->dt == F32 ? (lstm_sweep_f32_supported(md->Hp) ? lstm_f32_exchange_bytes(md->Hp, h->Bp) : 0)
                                                : (lstm_sweep_supported(h->dt, md->Hp) ? lstm_rs_exchange_bytes(md->Hp, h->Bp) : 0);

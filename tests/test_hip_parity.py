@@ -1000,10 +1000,12 @@ def test_feature_combinations_f32_vs_oracle(HipPlanner, golden_soma, golden_embv
 @pytest.mark.parametrize("shape", [dict(B=1, T=64, objective="acoustic_semvec", graph=True), dict(B=5, T=61, objective="semvec", graph=True),
                                    dict(B=16, T=46, objective="acoustic_semvec", graph=False), dict(B=3, T=40, objective="acoustic_semvec", graph=True, variant=True),
                                    dict(B=2, T=51, objective="acoustic_semvec", graph=True, classifier=True),
-                                   dict(B=4, T=57, objective="acoustic_semvec", graph=True, set="B"), dict(B=18, T=44, objective="semvec", graph=False, set="B")])
+                                   dict(B=4, T=57, objective="acoustic_semvec", graph=True, set="B"), dict(B=18, T=44, objective="semvec", graph=False, set="B"),
+                                   dict(B=3, T=53, objective="acoustic_semvec", graph=True, dtype="bf16"), dict(B=30, T=40, objective="acoustic_semvec", graph=True, dtype="bf16"),
+                                   dict(B=9, T=47, objective="semvec", graph=False, dtype="bf16", set="B")])
 def test_acoustic_pipeline_is_bit_identical(HipPlanner, golden_small, golden_embvar, shape, monkeypatch):
-    """Small f32 batches run predictor -> mel head + pooling -> embedder layers as ONE pipeline over time chunks, forward and
-    backward (planner.hip, acoustic_forward_pipeline / acoustic_backward_pipeline): same kernels on frame ranges, so losses,
+    """Small batches (f32; bf16 with the sweeps spread over the XCDs) run predictor -> mel head + pooling -> embedder layers as
+    ONE pipeline over time chunks, forward and backward (planner.hip, acoustic_forward_pipeline / acoustic_backward_pipeline): same kernels on frame ranges, so losses,
     gradients, CP and predictions are bit-identical to the model-after-model schedule (odd T, semvec objective, speech
     classifier, an embedder with a post_linear head, eager and graph)."""
     B, T = shape["B"], shape["T"]
@@ -1012,7 +1014,8 @@ def test_acoustic_pipeline_is_bit_identical(HipPlanner, golden_small, golden_emb
     outs = []
     for pipe in ("1", "0"):
         monkeypatch.setenv("PAULE_HIP_WF_PIPELINE", pipe)
-        eng = HipPlanner(wl.pred_sd, emb_sd, batch=B, n_frames=T, objective=shape["objective"], use_graph=shape["graph"])
+        eng = HipPlanner(wl.pred_sd, emb_sd, batch=B, n_frames=T, objective=shape["objective"], use_graph=shape["graph"],
+                         dtype=shape.get("dtype", "f32"))
         eng.set_targets(wl.target_mel, wl.target_semvec)
         eng.set_cp(wl.cp0)
         if shape.get("classifier"):
