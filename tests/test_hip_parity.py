@@ -1027,6 +1027,22 @@ def test_acoustic_pipeline_is_bit_identical(HipPlanner, golden_small, golden_emb
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_somatosensory_pipeline_is_bit_identical(HipPlanner, golden_soma, dtype, monkeypatch):
+    """The somatosensory path as a pipeline over time chunks (tube_forward_pipeline / tube_backward_pipeline; with it the acoustic
+    pipeline) against model after model: losses (all eight columns), gradients, CP and the tube predictions are bit-identical."""
+    g = golden_soma
+    outs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("PAULE_HIP_WF_PIPELINE", pipe)
+        eng = _soma_engine(HipPlanner, g, "acoustic_semvec", dtype=dtype)
+        loss, grad = eng.step(1, return_grad=True)
+        more = eng.step(5)
+        outs.append((_n(loss), _n(grad), _n(more), _n(eng.get_cp())) + tuple(_n(x) for x in eng.get_tube_pred()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_error_paths_through_the_c_abi(HipPlanner, golden_small, golden_train):
     """Nonzero return code -> ValueError with the library's message (the reference's convention for its one C library,
     paule/util.py:33-34): call-sequence errors (PL_ERR_STATE) and bad arguments (PL_ERR_INVALID); nothing aborts, and the
