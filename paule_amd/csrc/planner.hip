@@ -917,7 +917,7 @@ void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
     for (int c = 0; c < nc; ++c) {
         const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
         const int t0 = 2 * e0, t1 = c == nc - 1 ? T : 2 * e1;   // an odd last frame runs with the last chunk
-        for (int l = 0; l < p.L; ++l) {   // predictor layers on frames t0 .. t1-1; the top one also runs the mel head and the pooling
+        for (int l = 0; l < p.L; ++l) {   // predictor layers on frames t0 .. t1-1
             hipStream_t sl = px.begin(l, c);
             LstmLayer& ly = p.layers[l];
             const void* cur_in = l == 0 ? h->X0 : p.layers[l - 1].h;
@@ -932,15 +932,16 @@ void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
             s.stash_via_lds = h->stash_lds ? 1 : 0;
             s.t0 = t0; s.t1 = t1; s.carry = ly.carry_f;
             launch_sweep(h, sl, false, p.Hp, grid_p, s);
-            if (l == p.L - 1) {
-                launch_gemm_nt(sl, h->dt, true, off(ly.h, (size_t)t0 * Bp * p.Hp, a), p.Hp, p.Wlin, p.Hp, p.blin,
-                               h->Y + (size_t)t0 * Bp * h->Mp, h->Mp, (t1 - t0) * Bp, h->Mp, p.Hp);
-                launch_pool_mel(sl, h->dt, h->Y, h->B, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm, e0, e1 - e0);
-            }
             px.end(l, c, c == nc - 1);
         }
         for (int l = 0; l < e.L; ++l) {   // embedder layers on the pooled frames e0 .. e1-1
             hipStream_t sl = px.begin(p.L + l, c);
+            if (l == 0) {   // the mel head and the pooling of the chunk's frames run at the consumer: the predictor's next chunk
+                            // (the long pole of the pipeline) does not queue behind them
+                launch_gemm_nt(sl, h->dt, true, off(p.layers[p.L - 1].h, (size_t)t0 * Bp * p.Hp, a), p.Hp, p.Wlin, p.Hp, p.blin,
+                               h->Y + (size_t)t0 * Bp * h->Mp, h->Mp, (t1 - t0) * Bp, h->Mp, p.Hp);
+                launch_pool_mel(sl, h->dt, h->Y, h->B, T, h->M, Bp, h->Mp, h->mel_bm, h->mel_tm, e0, e1 - e0);
+            }
             LstmLayer& ly = e.layers[l];
             const void* cur_in = l == 0 ? h->mel_tm : e.layers[l - 1].h;
             const bool fuse_in = h->fuse_input && (ly.in_p == 32 || ly.in_p == 64);
@@ -997,20 +998,21 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
             if (l > 0)
                 launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)e0 * Bp * 4 * e.Hp, a), 4 * e.Hp, ly.WihT, 4 * e.Hp, nullptr,
                                off(e.dh_ext, (size_t)e0 * Bp * e.Hp, a), e.Hp, (e1 - e0) * Bp, e.Hp, 4 * e.Hp);
-            else
+            else {
                 launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)e0 * Bp * 4 * e.Hp, a), 4 * e.Hp, ly.WihT, 4 * e.Hp, nullptr,
                                h->dmel_e + (size_t)e0 * Bp * ly.in_p, ly.in_p, (e1 - e0) * Bp, ly.in_p, 4 * e.Hp);
+                // dL/dY of the chunk's frames (it reads the input-gradient rows just written) and dL/dh_top = dY W_p of the predictor,
+                // here at the producer: the predictor's stage (the long pole) is then the sweep alone
+                launch_dy(sl, h->dt, la, h->dmel_e, h->dY, false, t0, t1 - t0);
+                launch_gemm_nt(sl, h->dt, false, off(h->dY, (size_t)t0 * Bp * h->Mp, a), h->Mp, p.WlinT, h->Mp, nullptr,
+                               off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, h->Mp);
+            }
             px.end(i, k, c == 0);
         }
         for (int i = 0; i < p.L; ++i) {
             const int l = p.L - 1 - i;
             hipStream_t sl = px.begin(e.L + i, k);
             LstmLayer& ly = p.layers[l];
-            if (l == p.L - 1) {   // dL/dY of the chunk's frames (it reads the embedder's input-gradient rows of this chunk), dL/dh_top = dY W_p
-                launch_dy(sl, h->dt, la, h->dmel_e, h->dY, false, t0, t1 - t0);
-                launch_gemm_nt(sl, h->dt, false, off(h->dY, (size_t)t0 * Bp * h->Mp, a), h->Mp, p.WlinT, h->Mp, nullptr,
-                               off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, h->Mp);
-            }
             LstmSweepArgs s{};
             fill_sweep_common(h, s, T, slice_p[l]);
             s.G = ly.G; s.W = ly.WhhT; s.c = ly.c;
@@ -1022,13 +1024,15 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
             if (l > 0)   // in place in p.dh_ext, as in the layer wavefront
                 launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr,
                                off(p.dh_ext, (size_t)t0 * Bp * p.Hp, a), p.Hp, (t1 - t0) * Bp, p.Hp, 4 * p.Hp);
-            else
-                launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * p.Hp, a), 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr,
-                               h->dX + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * p.Hp);
             px.end(e.L + i, k, c == 0);
         }
     }
     px.join();
+    {   // dL/dCP = dA W_ih of the predictor's first layer: ONE product over all frames after the pipeline (nothing inside needs it,
+        // and per chunk it would sit in the long pole: N = 32 with K = 4H is latency-bound whatever the number of rows)
+        LstmLayer& ly = p.layers[0];
+        launch_gemm_nt(st, h->dt, true, ly.G, 4 * p.Hp, ly.WihT, 4 * p.Hp, nullptr, h->dX, ly.in_p, T * Bp, ly.in_p, 4 * p.Hp);
+    }
 }
 
 // one layer of a model on steps t0 .. t1-1 of its Tl-step recurrence (projection of the rows first unless it is fused)
@@ -1051,7 +1055,7 @@ void fwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void*
 }
 
 // backward of one layer on steps t0 .. t1-1: the sweep, then dL/dh rows for the layer below (in place in md.dh_ext) or, for
-// layer 0, the input gradient rows into dIn (f32 time-major [Tl][Bp][in_p])
+// layer 0, the input gradient rows into dIn (f32 time-major [Tl][Bp][in_p]; null: the caller takes it whole afterwards)
 void bwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void* dh_last, float* dIn, int Tl, int t0, int t1, int* slice) {
     const int Bp = h->Bp, Hp = md.Hp;
     const size_t a = h->act;
@@ -1069,7 +1073,7 @@ void bwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void*
     if (l > 0)
         launch_gemm_nt(sl, h->dt, false, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
                        off(md.dh_ext, (size_t)t0 * Bp * Hp, a), Hp, (t1 - t0) * Bp, Hp, 4 * Hp);
-    else
+    else if (dIn)
         launch_gemm_nt(sl, h->dt, true, off(ly.G, (size_t)t0 * Bp * 4 * Hp, a), 4 * Hp, ly.WihT, 4 * Hp, nullptr,
                        dIn + (size_t)t0 * Bp * ly.in_p, ly.in_p, (t1 - t0) * Bp, ly.in_p, 4 * Hp);
 }
@@ -1109,13 +1113,13 @@ void tube_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
         for (int l = 0; l < u.L; ++l, ++stage) {
             hipStream_t sl = px.begin(stage, c);
             fwd_layer_chunk(h, sl, u, l, h->X0, T, t0, t1, slice[stage]);
-            if (l == u.L - 1)
-                launch_gemm_nt(sl, h->dt, false, off(u.layers[l].h, (size_t)t0 * Bp * u.Hp, a), u.Hp, u.Wlin, u.Hp, u.blin,
-                               off(h->tube_tm, (size_t)t0 * Bp * h->Up, a), h->Up, (t1 - t0) * Bp, h->Up, u.Hp);
             px.end(stage, c, c == nc - 1);
         }
         for (int l = 0; l < e.L; ++l, ++stage) {
             hipStream_t sl = px.begin(stage, c);
+            if (l == 0)   // the tube's post_linear rows at the first consumer
+                launch_gemm_nt(sl, h->dt, false, off(u.layers[u.L - 1].h, (size_t)t0 * Bp * u.Hp, a), u.Hp, u.Wlin, u.Hp, u.blin,
+                               off(h->tube_tm, (size_t)t0 * Bp * h->Up, a), h->Up, (t1 - t0) * Bp, h->Up, u.Hp);
             fwd_layer_chunk(h, sl, e, l, h->tube_tm, T, t0, t1, slice[stage]);
             px.end(stage, c, c == nc - 1);
         }
@@ -1172,11 +1176,13 @@ void tube_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs
                 launch_gemm_nt(sl, h->dt, false, off(h->dYt, (size_t)t0 * Bp * h->Up, a), h->Up, u.WlinT, h->Up, nullptr,
                                off(u.dh_ext, (size_t)t0 * Bp * u.Hp, a), u.Hp, (t1 - t0) * Bp, u.Hp, h->Up);
             }
-            bwd_layer_chunk(h, sl, u, l, nullptr, h->dX2, T, t0, t1, slice[stage]);
+            bwd_layer_chunk(h, sl, u, l, nullptr, nullptr, T, t0, t1, slice[stage]);
             px.end(stage, k, c == 0);
         }
     }
     px.join();
+    LstmLayer& l0 = u.layers[0];   // dL/dCP through the tube path, one product over all frames (as in the acoustic pipeline)
+    launch_gemm_nt(st, h->dt, true, l0.G, 4 * u.Hp, l0.WihT, 4 * u.Hp, nullptr, h->dX2, l0.in_p, T * Bp, l0.in_p, 4 * u.Hp);
 }
 
 LossArgs loss_args(pl_handle* h, bool with_sem) {
@@ -1581,7 +1587,6 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
         if (h->wavefront > 0 && h->use_sweep) {
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
-                const int pxcd = sweep_per_xcd(h, *md);
                 const int ppx = pipe_per_xcd(h, *md);
                 const bool pipe = cfg->emb_layers > 0 && ppx > 0 && 2 * ppx <= h->n_cu / 8;
                 if ((md->L < 2 || wavefront_depth(h, *md) < 2) && !pipe) continue;
