@@ -2276,6 +2276,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         PL_HIP(hipEventCreate(&e1));
         PL_HIP(hipEventRecord(e0, h->stream));
         s.xchg = h->sweep_xchg;
+        s.n_valid = (h->dt == F32 && h->f32_valu) ? h->rows_in_use : 0;   // the kernel the planning path runs at this batch
         s.stash_via_lds = bwd ? (h->dt == F32 ? (h->wide_ingest ? 2 : 0) : (h->own_store ? 2 : 0)) : (h->stash_lds ? 1 : 0);
         for (int i = 0; i < reps; ++i) {
             s.counters = take_sweep_slice(h, h->stream);
