@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  usage: tools/gpu_check.sh [step ...]
-# steps: pytest  pytest_k (PYTEST_K=expr)  smoke  bench  bench_cfg2  bench_f32  bench_train  bench_nograph  rocprof  pmc
+# steps: pytest  pytest_k (PYTEST_K=expr)  smoke  bench  bench_cfg2  bench_f32  bench_train  bench_nograph  bench_all  stress  rocprof  pmc
 # (default: pytest smoke bench bench_cfg2 rocprof)
 # Stops after a timed-out / killed step (never start another GPU step after that).
 set -o pipefail
@@ -30,6 +30,9 @@ for s in $STEPS; do
     bench_train) step bench_train 300 python bench.py --config train8 --steps 30 --warmup 3
                  step bench_train_f32 300 python bench.py --config train8_f32 --steps 30 --warmup 3 --no-cpu-baseline ;;
     bench_nograph) step bench_nograph 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph ;;
+    bench_all) for c in cfg1 cfg3_setB cfg3_setC cfg3_soma cfg5 cfg4_1gpu cfg3_f32; do
+                 step bench_$c 300 python bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline; done ;;
+    stress) step capture_stress 600 python tools/microbench/capture_stress.py 20 ;;
     rocprof) rm -rf gpurun_out/prof
              step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline
              find gpurun_out/prof -name "*stats*" | head ;;
