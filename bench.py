@@ -45,7 +45,7 @@ CONFIGS = {
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md chip-level parameters
 
 
-def cpu_baseline(wl_args, objective, seconds_budget=25.0):
+def cpu_baseline(wl_args, objective, seconds_budget=25.0, full=False):
     """The CPU oracle (torch nn.LSTM + autograd + Adam: the operators the reference executes) on a bounded sample
     of the same workload, float32, all host cores.  Baseline, not target."""
     import torch
@@ -61,7 +61,7 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
     torch.set_num_threads(nthreads)
     f64 = bool(wl_args.get("cpu_f64"))
     cdt = torch.float64 if f64 else torch.float32
-    sample_b = min(16, wl_args["batch"])
+    sample_b = wl_args["batch"] if full else min(16, wl_args["batch"])
     wl = synthetic.make_workload(sample_b, wl_args["frames"], wl_args["model_set"])
     orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, cdt),
                            op.embedding_model_from_state_dict(wl.emb_sd, cdt), objective=objective,
@@ -71,12 +71,13 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0):
     progress(f"cpu baseline: {nthreads} threads, sample of {sample_b} utterances")
     orc.step(1)   # warm-up
     iters, t0 = 0, time.perf_counter()
-    while iters < 2 or (time.perf_counter() - t0 < seconds_budget and iters < 50):
+    while iters < (3 if full else 2) or (not full and time.perf_counter() - t0 < seconds_budget and iters < 50):
         orc.step(1)
         iters += 1
     dt = time.perf_counter() - t0
     utt_it_s = sample_b * iters / dt
-    return dict(value=utt_it_s / wl_args["batch"], unit=f"planning iters/sec at batch={wl_args['batch']} (extrapolated from the sample)",
+    return dict(value=utt_it_s / wl_args["batch"],
+                unit=f"planning iters/sec at batch={wl_args['batch']}" + ("" if full else " (extrapolated from the sample)"),
                 utt_iters_per_s=utt_it_s, cores=torch.get_num_threads(), kind="port",
                 sample=f"{sample_b} utterances x {iters} iterations, T={wl_args['frames']}, {objective}, model set "
                        f"{wl_args['model_set']}, {'float64' if f64 else 'float32'}, torch CPU oracle ({dt:.1f} s)")
@@ -148,6 +149,53 @@ def progress(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def plumbing_only(args, cfg):
+    """The N-rank skeleton of main() with the engine cut out: what can be checked where there is no GPU."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (got {world})")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T = cfg["batch"], cfg["frames"]
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))          # the "steps": ranks finish at different times, the job's time is the slowest rank's
+    elapsed = time.perf_counter() - t0
+    cp = torch.full((B, T, 30), float(rank))
+    outs = [cp]
+    if world > 1:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        outs = [torch.empty_like(cp) for _ in range(world)]
+        dist.all_gather(outs, cp)
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / max(1, args.steps) * 1e3, "scaling": "weak",
+                          "gathered_rows": int(sum(o.shape[0] for o in outs)),
+                          "gathered_ranks_ok": all(float(o[0, 0, 0]) == r for r, o in enumerate(outs))}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def source_digest():
+    """Digest of the kernel sources: what profiles/traffic.json was measured on (the GPU box has no .git to ask for HEAD)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "paule_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,8 +210,29 @@ def main():
     ap.add_argument("--strong-total", type=int, default=0,
                     help="strong scaling: this many utterances in total, split evenly over the ranks (e.g. 2048 = cfg4); "
                          "default 0 = weak scaling with the config's per-GPU batch")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="CPU baseline at the real configuration (all B utterances, 1 warm-up + 3 timed iterations: about a minute at "
+                         "cfg3) instead of the bounded 16-utterance sample")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="multi-rank plumbing without an engine (rendezvous, barrier, max-over-ranks timing, all_gather of a CP-shaped "
+                         "tensor, rank-0 JSON): what tests/test_host.py runs on a machine without a GPU; prints \"plumbing_only\": true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one rank per GPU ourselves -- as CHILD processes, before anything here touches the GPU
+        # (nothing has: torch is not even imported yet), and leave with their exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        progress(f"no launcher environment: starting {args.gpus} ranks: {' '.join(cmd[1:8])} ...")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    if args.plumbing_only:
+        return plumbing_only(args, cfg)
     if cfg.get("train"):
         if args.gpus != 1:
             raise SystemExit("the training configs are single-GPU")
@@ -272,11 +341,18 @@ def main():
             kname = "lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel"
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC pass (rocprofv3 --pmc), see profiles/README.md
+        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc, profiles/README.md): a measurement of ANOTHER run of
+        # the same command, so it is only reported while the kernel sources are the ones it was taken on
+        traffic, traffic_note = None, "no PMC pass recorded for this configuration"
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get(kname + "_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("source_digest") != source_digest():
+                    traffic_note = f"profiles/traffic.json was measured on other kernel sources (digest {tj.get('source_digest')}): not reported"
+                else:
+                    traffic = tj.get(args.config, {}).get(kname + "_bytes_per_launch")
+                    traffic_note = "profiles/traffic.json (separate --pmc passes of this command, same kernel sources)" if traffic else traffic_note
             except Exception:
                 traffic = None
         # algorithmic HBM bytes per utterance-iteration = CP / Adam streams + stash written once and read once
@@ -308,7 +384,7 @@ def main():
             "finite": finite, "final_loss_mean": float(loss[-1, :, 0].mean().item()),
             "device_bytes": eng.device_bytes,
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": ms * 1e3, "flops_per_launch": fl,
                          "us_per_time_step": ms * 1e3 / (T - 1) if swept else ms * 1e3,
                          "fwd_kernel_avg_launch_us": ms_f * 1e3,
@@ -318,7 +394,7 @@ def main():
             out["final_cp_all_gather_ms"] = gather_ms
         progress("kernel timing done; cpu baseline")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, cfg["objective"])
+            out["cpu_baseline"] = cpu_baseline(cfg, cfg["objective"], full=args.cpu_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()   # rank 0 is still timing single kernels: nobody tears the communicator down under it

@@ -158,6 +158,10 @@ int pl_get_cp(pl_handle *h, float *cp_out);
 /* Forward only at the current CP (paule/paule.py:822-824, :1460-1464): pred_mel [B, T/2, mel_dim],
  * pred_semvec [B, sem_dim] (may be NULL; requires an embedder). */
 int pl_get_pred(pl_handle *h, float *pred_mel_out, float *pred_semvec_out);
+/* The predictive model without the half sequence: post_linear(lstm(cp)) of every frame, frames_out [batch, n_frames, mel_dim]
+ * (device).  Replaces ForwardModel(apply_half_sequence=False).forward, paule/models.py:348-356 -- the form the reference
+ * builds its cp -> tube model in (paule/paule.py:232-237). */
+int pl_get_pred_frames(pl_handle *h, float *frames_out);
 /* The same for the somatosensory path (paule/paule.py:916-929): pred_tube [B, T, tube_dim], pred_tube_mel [B, T/2, mel_dim],
  * pred_tube_semvec [B, sem_dim]; any of them may be NULL. */
 int pl_get_tube_pred(pl_handle *h, float *pred_tube_out, float *pred_tube_mel_out, float *pred_tube_semvec_out);

@@ -24,7 +24,7 @@ PL_LOSS_COLS = 8
 EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
     "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
-    "pl_get_pred", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
+    "pl_get_pred", "pl_get_pred_frames", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
     "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
     "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
@@ -91,6 +91,7 @@ def load_library(path: str | None = None):
     lib.pl_synchronize.argtypes = [vp]
     lib.pl_get_cp.argtypes = [vp, fp]
     lib.pl_get_pred.argtypes = [vp, fp, fp]
+    lib.pl_get_pred_frames.argtypes = [vp, fp]
     lib.pl_get_tube_pred.argtypes = [vp, fp, fp, fp]
     lib.pl_embed_tube.argtypes = [vp, fp, fp, fp]
     lib.pl_embed_mel.argtypes = [vp, fp, ip, fp]
@@ -122,7 +123,7 @@ def load_library(path: str | None = None):
     lib.pl_flops_per_iteration.argtypes = [vp]
     for name in ("pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear", "pl_set_speech_classifier",
                  "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_get_cp",
-                 "pl_get_pred", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
+                 "pl_get_pred", "pl_get_pred_frames", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_synchronize", "pl_train_pred_step",
                  "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear", "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
                  "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_set_pred_optimizer_step",
                  "pl_train_model_step", "pl_reset_model_optimizer", "pl_get_model_optimizer_state", "pl_set_model_optimizer_state",

@@ -87,6 +87,74 @@ bool lstm_sweep_f32_supported(int Hp);
 int lstm_sweep_f32_grid(int Hp, int Bp, int n_cu);
 size_t lstm_f32_exchange_bytes(int Hp, int Bp);
 void launch_lstm_sweep_f32(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
+// ---- lstm_fused.hip ------------------------------------------------------------------------
+// The acoustic path's LSTM sweeps of one direction as ONE persistent launch (bf16, all models of one hidden size): the
+// workgroups of the grid take ROLES (a layer's recurrence, a layer's input projection, the mel head with its pooling, ...)
+// from a host-built table, every role runs all its time steps, and the roles hand over per time step through arrival flags
+// -- predictor step t, mel head of frame t / 2, embedder layer 1, projection for layer 2, layer 2 overlap instead of running
+// one sweep after the other.  A workgroup serves C batch groups ("chains") with ONE copy of its weights in registers: while
+// one chain waits for its exchange the others compute.
+constexpr int kFusedMaxRoles = 12;
+constexpr int kFusedMaxChains = 8;
+constexpr int kFusedRing = 4;   // slots of the cross-role partial-tile exchanges (a producer runs at most this far ahead)
+enum { FR_NONE = -1, FR_LSTM_FWD = 0, FR_PROJ_FWD = 1, FR_HEAD_FWD = 2, FR_LSTM_BWD = 3, FR_DX_BWD = 4, FR_HEAD_BWD = 5 };
+// One set of arrival flags a chain-step (group g, step t) of a role waits for: flags[(g * T + tt) * flag_stride + i] with
+// tt = (t >> t_shr) + t_add, for i < n -- or the single flag i = the workgroup's own slice p when per_p is set.  The entry
+// is skipped when tt is outside [0, T) (no step before the first, ring not yet wrapped, ...) or flags is null.
+struct FusedWait {
+    const int* flags;
+    int T, n, per_p, t_shr, t_add;
+};
+struct FusedRole {
+    int type;              // FR_*
+    int ksx;               // FR_LSTM_FWD: k-steps (of 16) of the fused narrow input projection (2 / 4), 0 = G holds the projection
+    int C;                 // chains (batch groups of 32 rows) per workgroup; set s serves groups s * C .. s * C + C - 1
+    int T;                 // time steps of the role
+    int* flags;            // the role's own arrival flags [groups][T][flag_stride] (zeroed before the launch)
+    FusedWait wait[3];     // [0]: <= 32 flags, [1]: <= 31 flags, [2]: one flag
+    int src_sc1;           // LSTM roles: x / G / dh_ext rows are produced by a role of this launch: load them write-through (sc1)
+    // LSTM roles
+    void* G;               // [T][Bp][4 Hp]
+    const void* W;         // forward Whh [4 Hp][Hp], backward Whh^T [Hp][4 Hp]
+    void* h;               // [T][Bp][Hp]
+    void* c;               // [T][Bp][Hp]
+    const void* x_in;      // forward, ksx > 0: [T][Bp][16 ksx]
+    const void* Wih;       // forward, ksx > 0: [4 Hp][16 ksx]
+    const float* bias;     // [4 Hp] (LSTM with fused input, projection role) / [out_p] (head)
+    // projection / head roles: out = src_h[t] * Wg^T + bias
+    const void* src_h;     // [T][Bp][Hp] of the producing layer
+    const void* Wg;        // projection: Wih [4 Hp][Hp] of the consuming layer; head: Wlin [out_p][Hp]; backward head: Wlin^T [Hp][out_p];
+                           // FR_DX_BWD: Wih^T [Hp][4 Hp] of the layer above; FR_LSTM_BWD with dmel_out: Wih^T [out_p][4 Hp] of this layer
+    void* out;             // projection: G of the consuming layer; head: pooled mel, time-major activation [T / 2][Bp][out_p];
+                           // backward head: dL/dh of the predictor's top layer per POOLED frame [T][Bp][Hp]
+    float* out_bm;         // head: pooled mel f32 batch-major [B][T / 2][out_dim]
+    int out_dim, out_p;
+    // backward roles
+    const void* dh_ext;    // LSTM: dL/dh from above [T or T / 2][Bp][Hp]; backward head: loss part of dL/dY, f32 [2 T][Bp][out_p] (row 2 t read)
+    int dh_ext_half;       // 1: step t of the recurrence reads dh_ext row t / 2
+    int dh_ext_rows;       // rows of dh_ext (steps beyond read zeros)
+    const void* dh_last;   // [Bp][Hp], applied at t = T - 1
+    int dA_sc1;            // LSTM: the dA stash is read by a role of this launch: store it write-through and drain it before the flag
+    void* xchg;            // LSTM: reduce-scatter exchange of the recurrence [2][groups][P][P][32][32]
+    void* xchg_ext;        // LSTM: partial tiles of dL/dh from the layer above's FR_DX_BWD role [ring][groups][P][P][32][32] (null: none);
+                           // FR_DX_BWD: where it writes them
+    void* xchg_mel;        // LSTM: partial tiles of this layer's input gradient, out_p / 32 tiles per source [ring][groups][out_p / 32][P][32][32]
+                           // (null: none); backward head: where it reads them
+};
+struct FusedArgs {
+    int Bp, B, n_groups, flag_stride, n_roles, grid;
+    int* status;
+    unsigned long long spin_ticks;
+    unsigned poll_mask;
+    const short* block_tab;   // [grid][4]: role, set, slice p, unused  (role < 0: the block leaves at once)
+    unsigned long long* stamps;
+    const FusedRole* roles;   // [n_roles] in device memory (a table in the kernel arguments would have to be indexed dynamically,
+                              // which makes the compiler copy it to scratch)
+};
+// hidden sizes (padded) the fused kernels are instantiated for
+bool fused_supported(int Hp);
+void launch_fused_fwd(hipStream_t stream, int Hp, const FusedArgs& a);
+void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a);
 // zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
 void launch_zero_counters(hipStream_t stream, int* p, int n);
 

@@ -1,0 +1,1321 @@
+// The acoustic path's LSTM sweeps of one direction as ONE persistent launch (bf16).
+//
+// Why.  A layer's recurrence is a chain of T dependent steps, and a step is mostly latency: of the 4.1 (forward) / 5.3 us
+// (backward) a step of the per-layer sweeps (lstm_persist.hip) takes at B = 256, about 1.7 / 2.2 us are MFMA and cell work
+// of the workgroup, the rest is the group's exchange (store drain, flag, poll, tile read-back).  Run one layer after the
+// other, cfg3 is 1 200 such steps forward and 1 200 backward with the CUs idle more than half of the time.  Two changes:
+//
+//  * chains: a workgroup serves C batch groups of 32 rows with ONE copy of its W_hh slice in registers and works on them in
+//    turn -- while one group's hand-off is in flight the next group's operands (prefetched into registers one chain-step
+//    ahead) multiply.  A sweep of 8 groups then needs 4 x 23 instead of 8 x 23 CUs at the same time per step;
+//  * roles: the CUs that frees carry the OTHER layers at the same time.  The workgroups of one launch take roles from a
+//    host-built table (blockIdx -> role, set of groups, slice): the predictor's recurrence, the mel head (post_linear +
+//    pooling), the embedder's first layer, the input projection of its second layer, the second layer.  A role runs all
+//    its time steps; what it needs from another role it waits for per (group, step) on that role's arrival flags.  The
+//    dependent chain of an iteration shrinks from the sum of the layers' steps to the longest layer's.
+//
+// Hand-off protocol: as in lstm_persist.hip (MI355X guide, hand-off table row 1): handed-off bytes are stored write-through
+// (sc1), every storing wave drains them (s_waitcnt vmcnt), the workgroup barriers, ONE lane raises the flag (sc1); a
+// consumer polls with sc1 loads from ONE wave, barriers, and every load of handed-off bytes is an sc1 load.  Flags only go
+// 0 -> 1 inside a launch and are zeroed by a kernel of ours before it.  All waits are bounded (status word, then every
+// workgroup leaves).  Nothing depends on placement or dispatch order: the role graph is acyclic and every role walks its
+// steps in increasing time, so a resident grid (<= one workgroup per CU, checked by the host) always drains.
+//
+// Arithmetic is that of the per-layer path, instruction for instruction (same MFMA shapes and k order per output element):
+// the forward results are bit-identical to it (tests/test_hip_parity.py::test_fused_forward_is_bit_identical).
+#include "sweep_common.h"
+
+#ifndef FUSED_BWD_ANSWER_AT
+#define FUSED_BWD_ANSWER_AT 1   // backward recurrence: next chain-step's flag answer + prefetch issue 0 before / 1 half way through / 2 after the tiles
+#endif
+#ifndef FUSED_POLL_NUM
+#define FUSED_POLL_NUM 4   // first look at the next chain-step's flags after FUSED_POLL_NUM / 8 of the MFMA chain
+#endif
+
+namespace pl {
+
+namespace {
+
+// Wave-granular conditions are written as SCALAR branches on the readfirstlane'd wave index, never as `tid < 128`: the kernels
+// spill SGPRs (to VGPR lanes), and the compiler placed reloads inside `tid < N` blocks that whole waves skip (s_cbranch_execz)
+// -- those waves then ran on with stale SGPRs (wrong LDS addresses: gates saturated in the columns of waves 2 and 3).  Row
+// guards of ragged groups go through the buffer range check instead of a branch (offset out of range: loads return 0, stores
+// are dropped).
+constexpr unsigned kOob = 0x80000000u;
+
+// Every pointer of a role comes out of the descriptor table, so the compiler cannot tell its address space and would use FLAT
+// instructions -- and while a FLAT access is pending, every LDS wait (each __syncthreads) becomes s_waitcnt vmcnt(0): the
+// prefetched tiles and the hand-off stores in flight would be drained at every barrier.  All global accesses of the roles
+// therefore go through these global-address-space casts (or raw buffer operations).
+#define PL_GLOBAL __attribute__((address_space(1)))
+// keeps a loaded value in its register: under pressure the compiler otherwise REMATERIALIZES loop-invariant loads -- it would
+// fetch the weights again in every chain-step instead of holding them
+__device__ __forceinline__ void pin(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+template <typename V> struct GAcc;   // HIP's vector classes have no address-space-qualified copies: go through the native vectors
+template <> struct GAcc<uint4> {
+    template <typename T> static __device__ __forceinline__ uint4 ld(const T* q) { const u32x4 v = *(const PL_GLOBAL u32x4*)(q); return make_uint4(v[0], v[1], v[2], v[3]); }
+    template <typename T> static __device__ __forceinline__ void st(T* q, uint4 v) { u32x4 d; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; *(PL_GLOBAL u32x4*)(q) = d; }
+};
+template <> struct GAcc<uint2> {
+    template <typename T> static __device__ __forceinline__ uint2 ld(const T* q) { const u32x2 v = *(const PL_GLOBAL u32x2*)(q); return make_uint2(v[0], v[1]); }
+    template <typename T> static __device__ __forceinline__ void st(T* q, uint2 v) { u32x2 d; d[0] = v.x; d[1] = v.y; *(PL_GLOBAL u32x2*)(q) = d; }
+};
+template <> struct GAcc<float4> {
+    template <typename T> static __device__ __forceinline__ float4 ld(const T* q) { const f32x4v v = *(const PL_GLOBAL f32x4v*)(q); return make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct GAcc<float> {
+    template <typename T> static __device__ __forceinline__ float ld(const T* q) { return *(const PL_GLOBAL float*)(q); }
+    template <typename T> static __device__ __forceinline__ void st(T* q, float v) { *(PL_GLOBAL float*)(q) = v; }
+};
+template <typename V, typename T>
+__device__ __forceinline__ V gld(const T* ptr) { return GAcc<V>::ld(ptr); }
+template <typename V, typename T>
+__device__ __forceinline__ void gst(T* ptr, V v) { GAcc<V>::st(ptr, v); }
+__device__ __forceinline__ int flag_load(const int* ptr) {
+    return __hip_atomic_load((const PL_GLOBAL int*)ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(int* ptr, int v) {
+    __hip_atomic_store((PL_GLOBAL int*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what one chain-step waits for, resolved to addresses: lanes 0 .. na-1 read fa[lane], lanes 32 .. 32+nb-1 read fb[lane - 32],
+// lane 63 reads fc
+struct FlagPoll {
+    const int* fa;
+    int na;
+    const int* fb;
+    int nb;
+    const int* fc;
+};
+
+__device__ __forceinline__ int poll_load(const FlagPoll& s, int lane) {
+    int v = 1;
+    if (lane < s.na) v = flag_load(s.fa + lane);
+    else if (lane >= 32 && lane - 32 < s.nb) v = flag_load(s.fb + (lane - 32));
+    else if (lane == 63 && s.fc) v = flag_load(s.fc);
+    return v;
+}
+
+// blocking, bounded; wave 0 polls, everybody meets at the barrier.  false: timed out / aborted (uniform over the workgroup)
+__device__ __forceinline__ bool flags_wait(const FlagPoll& s, int* status, int* lds_word, unsigned long long spin_ticks, unsigned poll_mask) {
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {   // wave 0, as a scalar branch
+        const int lane = threadIdx.x;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        for (unsigned spin = 1;; ++spin) {
+            const int v = poll_load(s, lane);
+            if (__all(v != 0)) break;
+            if ((spin & poll_mask) == 0 && (flag_load(status) != 0 ||
+                                            __builtin_amdgcn_s_memrealtime() - t0 > spin_ticks)) {
+                ok = 0;
+                break;
+            }
+        }
+        if (lane == 0) {
+            if (!ok) flag_store(status, 1);
+            *lds_word = ok;
+        }
+    }
+    __syncthreads();
+    return *lds_word != 0;
+}
+
+// every storing wave has drained (all but its N youngest memory operations); one lane raises the flag, write-through
+template <int N>
+__device__ __forceinline__ void raise_flag(int* flag) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {   // wave 0 by a scalar branch (see the note on wave-granular conditions)
+        if ((threadIdx.x & 63) == 0) flag_store(flag, 1);
+    }
+}
+
+// The role descriptors live in device memory and are read with vector loads, so the compiler takes every value in them for
+// divergent: buffer descriptors built from such pointers get a waterfall loop per access, and loop bounds land in VGPRs.
+// One readfirstlane per field, once per role, puts them where kernel arguments would be: in SGPRs.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* ptr) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ FusedWait uni(const FusedWait& w) {
+    return FusedWait{uni(w.flags), uni(w.T), uni(w.n), uni(w.per_p), uni(w.t_shr), uni(w.t_add)};
+}
+__device__ __forceinline__ FusedRole uniform_role(const FusedRole& g) {
+    FusedRole r;
+    r.type = uni(g.type); r.ksx = uni(g.ksx); r.C = uni(g.C); r.T = uni(g.T); r.flags = uni(g.flags);
+    r.wait[0] = uni(g.wait[0]); r.wait[1] = uni(g.wait[1]); r.wait[2] = uni(g.wait[2]);
+    r.src_sc1 = uni(g.src_sc1);
+    r.G = uni(g.G); r.W = uni(g.W); r.h = uni(g.h); r.c = uni(g.c); r.x_in = uni(g.x_in); r.Wih = uni(g.Wih); r.bias = uni(g.bias);
+    r.src_h = uni(g.src_h); r.Wg = uni(g.Wg); r.out = uni(g.out); r.out_bm = uni(g.out_bm); r.out_dim = uni(g.out_dim); r.out_p = uni(g.out_p);
+    r.dh_ext = uni(g.dh_ext); r.dh_ext_half = uni(g.dh_ext_half); r.dh_ext_rows = uni(g.dh_ext_rows); r.dh_last = uni(g.dh_last);
+    r.dA_sc1 = uni(g.dA_sc1); r.xchg = uni(g.xchg); r.xchg_ext = uni(g.xchg_ext); r.xchg_mel = uni(g.xchg_mel);
+    return r;
+}
+
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, uint4 v) {
+    u32x4 d;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, kAuxSc1);
+}
+__device__ __forceinline__ void st16_sc1_so(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, uint4 v) {   // soff: wave-uniform part
+    u32x4 d;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, kAuxSc1);
+}
+__device__ __forceinline__ uint4 ld16_sc1_so(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxSc1);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, kAuxSc1);
+    return make_uint2(v[0], v[1]);
+}
+
+// the flags chain-step (group g, step t) of role R waits for (FusedWait, kernels.h)
+__device__ __forceinline__ const int* wait_addr(const FusedArgs& a, const FusedWait& w, int g, int t, int p, int& n) {
+    n = 0;
+    if (!w.flags) return nullptr;
+    const int tt = (t >> w.t_shr) + w.t_add;
+    if (tt < 0 || tt >= w.T) return nullptr;
+    n = w.per_p ? 1 : w.n;
+    return w.flags + ((size_t)g * w.T + tt) * a.flag_stride + (w.per_p ? p : 0);
+}
+struct Waits { FusedWait w0, w1, w2; };
+__device__ __forceinline__ FlagPoll step_flags(const FusedArgs& a, const Waits& W, int g, int t, int p) {
+    FlagPoll s{nullptr, 0, nullptr, 0, nullptr};
+    int n2 = 0;
+    s.fa = wait_addr(a, W.w0, g, t, p, s.na);
+    s.fb = wait_addr(a, W.w1, g, t, p, s.nb);
+    s.fc = wait_addr(a, W.w2, g, t, p, n2);
+    return s;
+}
+__device__ __forceinline__ bool poll_empty(const FlagPoll& s) { return s.na == 0 && s.nb == 0 && !s.fc; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward recurrence of one layer (arithmetic of lstm_fwd_sweep_kernel)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int KSX>
+struct LstmFwdLds {
+    static constexpr int Hp = 16 * KS;
+    static constexpr int RS = Hp * 2 + 16;        // h image row stride: odd number of 16-byte chunks -> conflict-free b128 reads
+    static constexpr int HRS = 64 + 16;           // outgoing tiles [32 rows][32 units] bf16
+    static constexpr int XRS = KSX * 32 + 16;
+    static constexpr int O_HIMG = 0;
+    static constexpr int O_HST = O_HIMG + 32 * RS;
+    static constexpr int O_XIMG = O_HST + 6 * 32 * HRS;
+    static constexpr int O_CST = O_XIMG + (KSX ? 32 * XRS : 16);
+    static constexpr int O_FLAG = O_CST + kFusedMaxChains * 256 * 16;
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+template <int KS, int KSX>
+__device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmFwdLds<KS, KSX>;
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp;
+    constexpr int ROWB = Hp * 2, RS = L::RS, HRS = L::HRS, XRS = L::XRS;
+    constexpr int CH = Hp / 8;                        // 16-byte chunks per h row
+    constexpr int NL = (32 * CH + 255) / 256;         // tile loads per thread
+    constexpr int PF = 6;                             // B-fragment read-ahead
+    constexpr int PK = KS * FUSED_POLL_NUM / 8;       // k-step at which wave 0 takes its first look at the next chain-step's flags
+    constexpr int INP = KSX ? 16 * KSX : 16, XC = INP / 8;
+    unsigned char* himg = lds + L::O_HIMG;
+    unsigned char* hst = lds + L::O_HST;
+    unsigned char* ximg = lds + L::O_XIMG;
+    float4* cst = reinterpret_cast<float4*>(lds + L::O_CST);
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);   // wave-uniform, and the compiler should know
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const bf16_t* __restrict__ W = static_cast<const bf16_t*>(R.W);
+
+    // weights -> registers: A-operand row (lane & 31) = gate (row >> 3), unit 32p + 8 wave + (row & 7)
+    uint4 wreg[KS];
+    {
+        const int ar = lane & 31;
+        const bf16_t* wrow = W + (size_t)((ar >> 3) * Hp + 32 * p + 8 * wave + (ar & 7)) * Hp + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { wreg[ks] = gld<uint4>(wrow + 16 * ks); pin(wreg[ks]); }
+    }
+    const int bl = lane & 31, hh = lane >> 5;
+    uint4 wx[KSX ? KSX : 1];
+    float bias_r[16];
+    if constexpr (KSX > 0) {
+        const int ar = lane & 31;
+        const bf16_t* xrow = static_cast<const bf16_t*>(R.Wih) + (size_t)((ar >> 3) * Hp + 32 * p + 8 * wave + (ar & 7)) * INP + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) { wx[ks] = gld<uint4>(xrow + 16 * ks); pin(wx[ks]); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[r] = gld<float>(R.bias + (r >> 2) * Hp + 32 * p + 8 * wave + 4 * hh + (r & 3));
+    }
+    const int j = 32 * p + 8 * wave + 4 * hh;     // this lane's 4 hidden units
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
+    bf16_t* __restrict__ Hs = static_cast<bf16_t*>(R.h);
+    bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c);
+    const bool src_sc1 = R.src_sc1 != 0;   // x / G rows come from a role of this launch: write-through loads
+    const bf16_t* const x_in = static_cast<const bf16_t*>(R.x_in);
+
+    // operands of the NEXT chain-step, in flight while the current one computes
+    uint4 hv[NL];
+    uint4 xv = make_uint4(0, 0, 0, 0);
+    uint2 gxn[4] = {};
+    auto issue_loads = [&](int g2, int t2) {
+        // the small x / projection rows first: vmcnt retires in order, and the cell update waits for them, not for the h tile
+        if constexpr (KSX > 0) {
+            if (wave < XC / 2) {   // 32 x XC threads = XC / 2 whole waves: a scalar branch
+                const int row = tid / XC, cc = tid % XC;
+                int rb = 32 * g2 + row;
+                rb = rb < Bp ? rb : Bp - 1;
+                const size_t eo = ((size_t)t2 * Bp + rb) * INP + cc * 8;
+                if (src_sc1) {
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x_in + (size_t)t2 * Bp * INP, (unsigned)((size_t)Bp * INP * 2));
+                    xv = ld16_sc1(rx, (unsigned)((rb * INP + cc * 8) * 2));
+                } else {
+                    xv = gld<uint4>(x_in + eo);
+                }
+            }
+        } else {
+            int b2 = 32 * g2 + bl;
+            b2 = b2 < Bp ? b2 : Bp - 1;
+            if (src_sc1) {
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t2 * slabG, (unsigned)(slabG * 2));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gxn[q] = ld8_sc1(rg, (unsigned)(((size_t)b2 * G4 + q * Hp + j) * 2));
+            } else {
+                const bf16_t* g_row = G + (size_t)t2 * slabG + (size_t)b2 * G4 + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gxn[q] = gld<uint2>(g_row + q * Hp);
+            }
+        }
+        if (t2 > 0) {
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hs + (size_t)(t2 - 1) * slabH, (unsigned)(slabH * 2));
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int q = tid + 256 * i;
+                const int row = q / CH, ch = q % CH;
+                const int rb = 32 * g2 + row;
+                hv[i] = ld16_sc1(rh, (q < 32 * CH && rb < Bp) ? (unsigned)(rb * ROWB + ch * 16) : kOob);
+            }
+        }
+    };
+
+    PL_ST_DECL
+    int c = 0, t = 0;
+    {   // operands of chain-step (0, 0)
+        const FlagPoll s0 = step_flags(a, WT_, set * RC, 0, p);
+        if (!poll_empty(s0) && !flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        issue_loads(set * RC, 0);
+    }
+    for (;;) {
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t + 1; }
+        const bool has_next = tn < T;
+        const int gn = set * RC + cn;
+        const int b = 32 * g + bl;
+        const bool ok = b < Bp;
+
+        // A. the prefetched operands of this chain-step -> LDS (the loads were issued one chain-step ago)
+        uint2 gx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gx[q] = gxn[q];
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int q = tid + 256 * i;
+                if (wave < 2 * KS - 4 * i) *reinterpret_cast<uint4*>(himg + (q / CH) * RS + (q % CH) * 16) = hv[i];   // 32 CH = 64 x 2 KS chunks: whole waves
+            }
+        }
+        if constexpr (KSX > 0) {
+            if (wave < XC / 2) *reinterpret_cast<uint4*>(ximg + (tid / XC) * XRS + (tid % XC) * 16) = xv;
+        }
+        __syncthreads();
+        PL_ST(0);   // operands landed + LDS image
+
+        // B. first look at the next chain-step's flags, answered while the MFMAs run
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
+        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        int pv = 1;
+        const bool poll_here = wave == 0 && has_next;
+        if (poll_here && t == 0) pv = poll_load(pn, lane);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // C. gates = W_hh h_{t-1} (+ W_ih x_t + b)
+        f32x16 acc;
+        if constexpr (KSX > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        if (t > 0) {
+            const unsigned char* bsrc = himg + bl * RS + hh * 16;
+            uint4 bq[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < KS) bq[i] = *reinterpret_cast<const uint4*>(bsrc + i * 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks]), __builtin_bit_cast(bf16x8, bq[ks % PF]), acc, 0, 0, 0);
+                if (ks + PF < KS) bq[ks % PF] = *reinterpret_cast<const uint4*>(bsrc + (ks + PF) * 32);
+                if (ks == PK && poll_here) pv = poll_load(pn, lane);   // late enough for flags raised at the top of this chain-step
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (KSX > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                const uint4 xb = *reinterpret_cast<const uint4*>(ximg + bl * XRS + ks * 32 + hh * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wx[ks]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+            }
+        }
+        PL_ST(1);   // MFMA chain
+
+        // D. has the next chain-step everything it waits for?  (uniform answer through LDS)
+        if (wave == 0) {
+            const bool rdy = __all(pv != 0);
+            if (lane == 0) lflag[0] = rdy ? 1 : 0;
+        }
+        __syncthreads();
+        const bool ready = has_next && lflag[0] != 0;
+        // E. then its operands start now and fly under the cell update and the stores of this one
+        if (ready) issue_loads(gn, tn);
+        PL_ST(2);   // flag answer + prefetch issue
+
+        // F. cell update: acc[4 * gate + unit]
+        float gxi[4], gxf[4], gxg[4], gxo[4];
+        unpack_bf16x4(gx[0], gxi);
+        unpack_bf16x4(gx[1], gxf);
+        unpack_bf16x4(gx[2], gxg);
+        unpack_bf16x4(gx[3], gxo);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t > 0) cs = cst[c * 256 + tid];
+        float c_state[4] = {cs.x, cs.y, cs.z, cs.w};
+        float vi[4], vf[4], vg[4], vo[4], vc[4], vh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            vi[u] = sigmoid_fast(acc[u] + gxi[u]);
+            vf[u] = sigmoid_fast(acc[4 + u] + gxf[u]);
+            vg[u] = tanh_fast(acc[8 + u] + gxg[u]);
+            vo[u] = sigmoid_fast(acc[12 + u] + gxo[u]);
+            c_state[u] = cell_c(vf[u], c_state[u], vi[u], vg[u]);
+            vc[u] = c_state[u];
+            vh[u] = vo[u] * tanh_fast(vc[u]);
+        }
+        cst[c * 256 + tid] = make_float4(c_state[0], c_state[1], c_state[2], c_state[3]);
+        // G. the h tile (hand-off) and the five stash arrays leave through LDS as whole 64-byte row pieces
+        {
+            unsigned char* o = hst + bl * HRS + (8 * wave + 4 * hh) * 2;
+            *reinterpret_cast<uint2*>(o) = pack_bf16x4(vh[0], vh[1], vh[2], vh[3]);
+            *reinterpret_cast<uint2*>(o + 32 * HRS) = pack_bf16x4(vi[0], vi[1], vi[2], vi[3]);
+            *reinterpret_cast<uint2*>(o + 2 * 32 * HRS) = pack_bf16x4(vf[0], vf[1], vf[2], vf[3]);
+            *reinterpret_cast<uint2*>(o + 3 * 32 * HRS) = pack_bf16x4(vg[0], vg[1], vg[2], vg[3]);
+            *reinterpret_cast<uint2*>(o + 4 * 32 * HRS) = pack_bf16x4(vo[0], vo[1], vo[2], vo[3]);
+            *reinterpret_cast<uint2*>(o + 5 * 32 * HRS) = pack_bf16x4(vc[0], vc[1], vc[2], vc[3]);
+        }
+        (void)ok;
+        __syncthreads();
+        if (wave < 2) {
+            const int row = tid >> 2, qt = tid & 3;
+            const int rb = 32 * g + row;
+            const uint4 hvv = *reinterpret_cast<const uint4*>(hst + row * HRS + qt * 16);
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+            st16_sc1(ro, rb < Bp ? (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2) : kOob, hvv);
+        }
+        asm volatile("" ::: "memory");   // keep the stash stores behind it
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + 256 * i;   // piece: array e / 128, row (e % 128) / 4, quarter e % 4
+            if (i < 2 || wave < 2) {   // 640 pieces: all threads twice, waves 0 and 1 a third time
+                const int arr = e >> 7, row = (e & 127) >> 2, qt = e & 3, rb = 32 * g + row;
+                const uint4 sv = *reinterpret_cast<const uint4*>(hst + (arr + 1) * 32 * HRS + row * HRS + qt * 16);
+                u32x4 d;
+                d[0] = sv.x; d[1] = sv.y; d[2] = sv.z; d[3] = sv.w;
+                if (i < 2) {   // pieces 0 .. 511: the four gate arrays (128 pieces = 2 waves each); 512 .. 639: c
+                    const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rg, rb < Bp ? (unsigned)(((size_t)rb * G4 + arr * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+                } else {
+                    const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rc, rb < Bp ? (unsigned)(((size_t)rb * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+                }
+            }
+        }
+        PL_ST(3);   // cell + store issue
+        raise_flag<3>(rflags + ((size_t)g * T + t) * a.flag_stride + p);   // the hand-off store is older than the (at most 3) stash stores
+        PL_ST(4);   // drain + barrier + flag
+
+        if (!has_next) break;
+        // H. the next chain-step was not ready at the first look (always so with one chain: it waits for the flag just raised)
+        if (!ready) {
+            if (!flags_wait(pn, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+            issue_loads(gn, tn);
+        }
+        PL_ST(5);   // blocking wait
+        c = cn;
+        t = tn;
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row-tile products on a producing layer's h: the input projection of the layer above (PROJ: G_t = h_t Wih^T + b, bf16)
+// and the mel head with its pooling (HEAD: mel = avg-pool-2(h_t Wlin^T + b)).  Arithmetic of gemm_nt_kernel (gemm.hip):
+// v_mfma_f32_16x16x32_bf16, A = activation rows, B = weight rows, k-step n covers k = 32 n .. 32 n + 31, accumulators start
+// at zero, bias added at the end -- so the outputs carry the same bits as the batched GEMM's.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+struct GemmFwdLds {
+    static constexpr int Hp = 16 * KS;
+    static constexpr int CH = Hp / 8;
+    static constexpr int IRS = (CH + ((CH % 4 == 0) ? 2 : 0)) * 16;   // chunk stride = 2 mod 4: conflict-free for (row lr, chunk 4n + kq) reads
+    static constexpr int ORS = 128 * 2 + 16;
+    static constexpr int O_IMG = 0;
+    static constexpr int O_OST = O_IMG + 32 * IRS;
+    static constexpr int O_YB = O_OST + 32 * ORS;
+    static constexpr int O_FLAG = O_YB + kFusedMaxChains * 256 * 32;
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+template <int KS, bool HEAD>
+__device__ __forceinline__ void fused_gemm_fwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = GemmFwdLds<KS>;
+    constexpr int Hp = 16 * KS, KB = KS / 2, CH = L::CH, IRS = L::IRS, ORS = L::ORS, ROWB = Hp * 2;
+    constexpr int NL = (32 * CH + 255) / 256;
+    constexpr int NJ = HEAD ? 1 : 2;
+    constexpr int PF = 4;
+    unsigned char* img = lds + L::O_IMG;
+    unsigned char* ost = lds + L::O_OST;
+    float4* yb = reinterpret_cast<float4*>(lds + L::O_YB);
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);   // wave-uniform, and the compiler should know
+    const int lr = lane & 15, kq = lane >> 4;
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const int G4 = 4 * Hp;   // PROJ: gate columns of the consuming layer (same hidden size)
+    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(R.Wg);
+    uint4 wreg[NJ][KB];
+    float bias_v[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int col = HEAD ? 16 * wave + lr : wave * Hp + 32 * p + 16 * jj + lr;
+        const bf16_t* wrow = Wg + (size_t)col * Hp + 8 * kq;
+#pragma unroll
+        for (int n = 0; n < KB; ++n) { wreg[jj][n] = gld<uint4>(wrow + 32 * n); pin(wreg[jj][n]); }
+        bias_v[jj] = R.bias ? gld<float>(R.bias + col) : 0.f;
+    }
+    const size_t slabH = (size_t)Bp * Hp;
+    const bf16_t* __restrict__ Hsrc = static_cast<const bf16_t*>(R.src_h);
+    const int out_dim = R.out_dim;
+    float* const out_bm = R.out_bm;
+    void* const out_ptr = R.out;
+
+    uint4 hv[NL];
+    auto issue_loads = [&](int g2, int t2) {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(Hsrc + (size_t)t2 * slabH, (unsigned)(slabH * 2));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int q = tid + 256 * i;
+            const int row = q / CH, ch = q % CH;
+            const int rb = 32 * g2 + row;
+            hv[i] = ld16_sc1(rh, (q < 32 * CH && rb < Bp) ? (unsigned)(rb * ROWB + ch * 16) : kOob);
+        }
+    };
+
+    PL_ST_DECL
+    int c = 0, t = 0;
+    {
+        const FlagPoll s0 = step_flags(a, WT_, set * RC, 0, p);
+        if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        issue_loads(set * RC, 0);
+    }
+    for (;;) {
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t + 1; }
+        const bool has_next = tn < T;
+        const int gn = set * RC + cn;
+
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int q = tid + 256 * i;
+            if (wave < 2 * KS - 4 * i) *reinterpret_cast<uint4*>(img + (q / CH) * IRS + (q % CH) * 16) = hv[i];   // whole waves
+        }
+        __syncthreads();
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
+        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        int pv = 1;
+        const bool poll_here = wave == 0 && has_next;
+        __builtin_amdgcn_sched_barrier(0);
+        PL_ST(0);
+
+        f32x4 acc[2][NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned char* a0 = img + lr * IRS + kq * 16;
+            const unsigned char* a1 = img + (16 + lr) * IRS + kq * 16;
+            uint4 f0[PF], f1[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < KB) {
+                    f0[i] = *reinterpret_cast<const uint4*>(a0 + i * 64);
+                    f1[i] = *reinterpret_cast<const uint4*>(a1 + i * 64);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < KB; ++n) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[n % PF]), __builtin_bit_cast(bf16x8, wreg[jj][n]), acc[0][jj], 0, 0, 0);
+                    acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[n % PF]), __builtin_bit_cast(bf16x8, wreg[jj][n]), acc[1][jj], 0, 0, 0);
+                }
+                if (n + PF < KB) {
+                    f0[n % PF] = *reinterpret_cast<const uint4*>(a0 + (n + PF) * 64);
+                    f1[n % PF] = *reinterpret_cast<const uint4*>(a1 + (n + PF) * 64);
+                }
+                if (n == KB * FUSED_POLL_NUM / 8 && poll_here) pv = poll_load(pn, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        PL_ST(1);
+        if (wave == 0) {
+            const bool rdy = __all(pv != 0);
+            if (lane == 0) lflag[0] = rdy ? 1 : 0;
+        }
+        __syncthreads();
+        const bool ready = has_next && lflag[0] != 0;
+        if (ready) issue_loads(gn, tn);
+        PL_ST(2);
+
+        // epilogue: D[row 16 i + 4 kq + r][column 16 jj + lr (of this wave's columns)]
+        if constexpr (!HEAD) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<bf16_t*>(ost + (16 * i + 4 * kq + r) * ORS + (32 * wave + 16 * jj + lr) * 2) = (bf16_t)(acc[i][jj][r] + bias_v[jj]);
+            __syncthreads();
+            bf16_t* Gout = static_cast<bf16_t*>(out_ptr);
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(Gout + (size_t)t * Bp * G4, (unsigned)((size_t)Bp * G4 * 2));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                const int rb = 32 * g + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(ost + row * ORS + (32 * gate + 8 * q4) * 2);
+                st16_sc1(ro, rb < Bp ? (unsigned)(((size_t)rb * G4 + gate * Hp + 32 * p + 8 * q4) * 2) : kOob, v);
+            }
+            raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
+        } else {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[4 * i + r] = acc[i][0][r] + bias_v[0];
+            if ((t & 1) == 0) {   // even frame: kept for its partner
+                yb[(c * 256 + tid) * 2] = make_float4(y[0], y[1], y[2], y[3]);
+                yb[(c * 256 + tid) * 2 + 1] = make_float4(y[4], y[5], y[6], y[7]);
+                __syncthreads();   // the image is rewritten at the top of the next chain-step
+            } else {
+                const float4 e0 = yb[(c * 256 + tid) * 2], e1 = yb[(c * 256 + tid) * 2 + 1];
+                const float ye[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                const int tp = t >> 1, Tp = T >> 1, col = 16 * wave + lr;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * kq + r, bb = 32 * g + row;
+                        const bool live = bb < a.B && col < out_dim;
+                        const float v = live ? 0.5f * (ye[4 * i + r] + y[4 * i + r]) : 0.f;
+                        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(out_bm, (unsigned)((size_t)a.B * Tp * out_dim * 4));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rb_, live ? (unsigned)((((size_t)bb * Tp + tp) * out_dim + col) * 4) : kOob, 0, 0);
+                        *reinterpret_cast<bf16_t*>(ost + row * ORS + col * 2) = (bf16_t)v;
+                    }
+                __syncthreads();
+                {   // pooled frame, time-major activation [tp][Bp][64]: the input of the embedder's first layer (hand-off)
+                    const int row = tid >> 3, q8 = tid & 7, rb = 32 * g + row;
+                    bf16_t* Mout = static_cast<bf16_t*>(out_ptr);
+                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(Mout + (size_t)tp * Bp * 64, (unsigned)((size_t)Bp * 64 * 2));
+                    const uint4 v = *reinterpret_cast<const uint4*>(ost + row * ORS + q8 * 16);
+                    st16_sc1(ro, rb < Bp ? (unsigned)((rb * 64 + 8 * q8) * 2) : kOob, v);
+                }
+                raise_flag<0>(rflags + ((size_t)g * Tp + tp) * a.flag_stride);
+            }
+        }
+        PL_ST(3);
+        if (!has_next) break;
+        if (!ready) {
+            if (!flags_wait(pn, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+            issue_loads(gn, tn);
+        }
+        PL_ST(5);
+        c = cn;
+        t = tn;
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward recurrence of one layer, reduce-scatter form (arithmetic of lstm_bwd_rs_sweep_kernel): a workgroup multiplies the dA
+// it produced itself with its 128 rows of W_hh^T and hands the P partial 32 x 32 tiles over; it sums the P tiles of its own
+// hidden units -- and, below the top layer, the P tiles of dL/dh from the layer above (FR_DX_BWD role of this launch).
+// The first layer of the embedder also multiplies its dA with its rows of W_ih^T (K = 128 -> out_p mel columns) and hands
+// those partial tiles to the backward mel head.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFusedMaxChainsBwd = 4;   // the backward roles keep their partial tiles in LDS (2 x 46 KB): less room for per-chain state
+template <int KS>
+struct LstmBwdLds {
+    static constexpr int Hp = 16 * KS, P = Hp / 32;
+    static constexpr int DRS = 128 * 2 + 16;      // dA^T image: [32 batch rows][128 local gate rows] bf16, odd chunk stride
+    static constexpr int TRS = 64 + 16;           // a wave's outgoing tile: [32 batch rows][32 columns] bf16
+    static constexpr int MRS = 64 * 2 + 16;       // backward mel head: dL/dY image [32 batch rows][64] bf16
+    static constexpr int O_DA = 0;
+    static constexpr int O_TST = O_DA + 32 * DRS;                    // [4 waves][32][TRS]
+    static constexpr int O_MEL = O_TST + 4 * 32 * TRS;
+    static constexpr int O_DC = O_MEL + 32 * MRS;
+    static constexpr int O_WM = O_DC + kFusedMaxChainsBwd * 256 * 16;   // W_ih^T rows of the slice for the input-gradient tiles: [64 columns][128 local gate rows]
+    static constexpr int O_XR = O_WM + 64 * DRS;                     // the P partial tiles of the recurrence, as they lie in the exchange (LDS-DMA)
+    static constexpr int O_XE = O_XR + P * 2048;                     // ... and of dL/dh from the layer above
+    static constexpr int O_FLAG = O_XE + P * 2048;
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+// LDS-DMA, write-through read (sc1): 64 lanes x 16 bytes land at lds_dst_uniform + 16 * lane.  Issued from inline asm: the
+// compiler does not see the LDS write (callers wait with s_waitcnt vmcnt and a barrier before reading the region) and does not
+// count the operation (its own counted waits only get more conservative: vmcnt retires in order).
+__device__ __forceinline__ void glds16_sc1(const void* gsrc_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 sc1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst_uniform)
+        : "memory");
+}
+typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+
+// one partial tile: 8 k-steps over the workgroup's 128 local gate rows; acc[r] = out[n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31]
+// -> bf16 image [batch][n], read back by rows by the same wave (a wave's LDS operations are ordered) and stored as 2 KB
+__device__ __forceinline__ void partial_tile(const uint4 (&w)[8], const unsigned char* bsrc, unsigned char* img_row0, int rs, int col0,
+                                             __amdgpu_buffer_rsrc_t ro, unsigned tile_off, int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    uint4 bfr[8];   // B fragments of the dA image, read per tile (kept for all tiles they crowd the vector registers)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const uint4*>(bsrc + ks * 32);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks]), __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+    unsigned char* orow = img_row0 + (lane & 31) * rs + (col0 + 4 * (lane >> 5)) * 2;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+        *reinterpret_cast<uint2*>(orow + rg * 16) = pack_bf16x4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int cidx = lane + 64 * q, r = cidx >> 2, c4 = cidx & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(img_row0 + r * rs + (col0 + 8 * c4) * 2);
+        st16_sc1_so(ro, (unsigned)(cidx * 16), tile_off, v);
+    }
+}
+
+template <int KS, bool EXT, bool MEL>   // EXT: partial tiles of dL/dh from the layer above; MEL: input-gradient tiles for the backward mel head
+__device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmBwdLds<KS>;
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32, NT = (P + 3) / 4;
+    constexpr int DRS = L::DRS, TRS = L::TRS;
+    constexpr size_t TILE = 32 * 32;
+    unsigned char* da_img = lds + L::O_DA;
+    unsigned char* xr_img = lds + L::O_XR;
+    unsigned char* xe_img = lds + L::O_XE;
+    float4* dcs = reinterpret_cast<float4*>(lds + L::O_DC);
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);   // wave-uniform, and the compiler should know
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(R.W);   // Whh^T packed [Hp][4 Hp]
+    uint4 wreg[NT][8];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nt = wave + 4 * i;
+        const int n = 32 * (nt < P ? nt : 0) + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+        {
+            wreg[i][ks] = gld<uint4>(WT + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
+            pin(wreg[i][ks]);
+        }
+    }
+    const int n_mel = MEL ? R.out_p / 32 : 0;   // input-gradient tiles (waves 0 .. n_mel-1 take one each)
+    unsigned char* wm_img = lds + L::O_WM;
+    if constexpr (MEL) {   // these weights live in LDS (16 KB): in registers, beside W_hh^T and two sets of partial tiles in flight, they spill
+        const bf16_t* WM = static_cast<const bf16_t*>(R.Wg);   // Wih^T packed [out_p][4 Hp]
+        for (int e = tid; e < 32 * n_mel * 16; e += 256) {
+            const int n = e >> 4, ks = (e >> 1) & 7, hf = e & 1;
+            *reinterpret_cast<uint4*>(wm_img + n * DRS + ks * 32 + hf * 16) =
+                gld<uint4>(WM + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * hf);
+        }
+        __syncthreads();
+    }
+
+    // cell ownership: thread -> batch row (tid >> 3), hidden units 32p + 4 (tid & 7) .. +3
+    const int erow = tid >> 3, jq = tid & 7;
+    const int j = 32 * p + 4 * jq;
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(R.c);
+    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(R.dh_ext);
+    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(R.dh_last);
+    bf16_t* __restrict__ X = static_cast<bf16_t*>(R.xchg);          // [2][groups][P dest][P src][32][32]
+    bf16_t* __restrict__ XE = static_cast<bf16_t*>(R.xchg_ext);     // [ring][groups][P dest][P src][32][32]
+    bf16_t* __restrict__ XM = static_cast<bf16_t*>(R.xchg_mel);     // [ring][groups][n_mel][P src][32][32]
+    const size_t grp_stride = (size_t)P * P * TILE, slot_stride = (size_t)a.n_groups * grp_stride;
+    const size_t mgrp_stride = (size_t)n_mel * P * TILE, mslot_stride = (size_t)a.n_groups * mgrp_stride;
+    const bool src_sc1 = R.src_sc1 != 0, dA_sc1 = R.dA_sc1 != 0;
+    const int dh_ext_half = R.dh_ext_half, dh_ext_rows = R.dh_ext_rows;
+
+    unsigned char* tst = lds + L::O_TST + wave * 32 * TRS;   // this wave's outgoing tile
+    const unsigned xr_lds = (unsigned)(uintptr_t)(lds_ptr_t)xr_img, xe_lds = (unsigned)(uintptr_t)(lds_ptr_t)xe_img;
+    // operands of the NEXT chain-step: the stash rows in registers, the partial tiles by LDS-DMA (held in registers across the
+    // tiles' MFMAs they cost 46 - 92 VGPRs, and the compiler parked them in AGPRs behind waits in the middle of the tiles)
+    uint2 sg[4] = {}, sc = make_uint2(0u, 0u), scp = make_uint2(0u, 0u), sdh = make_uint2(0u, 0u);
+    auto issue_loads = [&](int g2, int t2) {
+        int b2 = 32 * g2 + erow;
+        b2 = b2 < Bp ? b2 : Bp - 1;
+        const bf16_t* g_row = G + (size_t)t2 * slabG + (size_t)b2 * G4 + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sg[q] = gld<uint2>(g_row + q * Hp);
+        sc = gld<uint2>(Cs + (size_t)t2 * slabH + (size_t)b2 * Hp + j);
+        scp = make_uint2(0u, 0u);
+        if (t2 > 0) scp = gld<uint2>(Cs + (size_t)(t2 - 1) * slabH + (size_t)b2 * Hp + j);
+        sdh = make_uint2(0u, 0u);
+        if (dhe) {
+            const int row = dh_ext_half ? (t2 >> 1) : t2;
+            if (row < dh_ext_rows) {
+                if (src_sc1) {
+                    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dhe + (size_t)row * slabH, (unsigned)(slabH * 2));
+                    sdh = ld8_sc1(rd, (unsigned)(((size_t)b2 * Hp + j) * 2));
+                } else {
+                    sdh = gld<uint2>(dhe + (size_t)row * slabH + (size_t)b2 * Hp + j);
+                }
+            }
+        } else if (dhl && t2 == T - 1) {
+            sdh = gld<uint2>(dhl + (size_t)b2 * Hp + j);
+        }
+        constexpr int NPC = P * 2;   // 1-KB pieces of a destination's P tiles (contiguous in the exchange)
+        if (t2 + 1 < T) {   // the P partial tiles of step t2 + 1 that belong to this workgroup's cells
+            const unsigned char* xs = reinterpret_cast<const unsigned char*>(X + (size_t)((t2 + 1) & 1) * slot_stride + (size_t)g2 * grp_stride + (size_t)p * P * TILE);
+#pragma unroll
+            for (int k = 0; k < (NPC + 3) / 4; ++k) {
+                const int pc = wave + 4 * k;
+                if (pc < NPC) glds16_sc1(uni(xs + pc * 1024), (unsigned)(lane * 16), (unsigned)uni((int)(xr_lds + (unsigned)(pc * 1024))));
+            }
+        }
+        if constexpr (EXT) {   // ... and the P partial tiles of dL/dh_t2 from the layer above
+            const unsigned char* xs = reinterpret_cast<const unsigned char*>(XE + (size_t)(t2 % kFusedRing) * slot_stride + (size_t)g2 * grp_stride + (size_t)p * P * TILE);
+#pragma unroll
+            for (int k = 0; k < (NPC + 3) / 4; ++k) {
+                const int pc = wave + 4 * k;
+                if (pc < NPC) glds16_sc1(uni(xs + pc * 1024), (unsigned)(lane * 16), (unsigned)uni((int)(xe_lds + (unsigned)(pc * 1024))));
+            }
+        }
+    };
+
+    PL_ST_DECL
+    int c = 0, t = T - 1;
+    {
+        const FlagPoll s0 = step_flags(a, WT_, set * RC, t, p);
+        if (!poll_empty(s0) && !flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        issue_loads(set * RC, t);
+    }
+    for (;;) {
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t - 1; }
+        const bool has_next = tn >= 0;
+        const int gn = set * RC + cn;
+        const int b = 32 * g + erow;
+        const bool ok = b < Bp;
+
+        // first look at the next chain-step's flags, taken where NO store of this wave is in flight: vmcnt counts loads and stores
+        // together and in order, so a poll issued behind hand-off stores would only be answered after their write-through round trips
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
+        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        int pvl = 1;
+        if (wave == 0 && has_next) pvl = poll_load(pn, lane);
+        // A. dL/dh_t of this thread's cells: from above + the partial sums (fixed order).  Every wave's DMA pieces have landed:
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float dh[4];
+        unpack_bf16x4(sdh, dh);
+        if (t + 1 < T) {
+            const unsigned char* src = xr_img + erow * 64 + jq * 8;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                float f[4];
+                unpack_bf16x4(*reinterpret_cast<const uint2*>(src + s * 2048), f);
+                dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+            }
+        }
+        if constexpr (EXT) {
+            const unsigned char* src = xe_img + erow * 64 + jq * 8;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                float f[4];
+                unpack_bf16x4(*reinterpret_cast<const uint2*>(src + s * 2048), f);
+                dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+            }
+        }
+        bool early = true;
+        if (wave == 0 && has_next) {   // a second look if the first came too early (with two chains the flags were raised a moment ago)
+            early = __all(pvl != 0);
+            if (!early) pvl = poll_load(pn, lane);
+        }
+        PL_ST(0);   // operands landed + sums
+        // B. cell backward
+        float gi[4], gf[4], gg[4], go[4], cc[4], cp[4];
+        unpack_bf16x4(sg[0], gi);
+        unpack_bf16x4(sg[1], gf);
+        unpack_bf16x4(sg[2], gg);
+        unpack_bf16x4(sg[3], go);
+        unpack_bf16x4(sc, cc);
+        unpack_bf16x4(scp, cp);
+        float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t + 1 < T) dcv = dcs[c * 256 + tid];
+        float dc_next[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+        float dai[4], daf[4], dag[4], dao[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], cc[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
+        dcs[c * 256 + tid] = make_float4(dc_next[0], dc_next[1], dc_next[2], dc_next[3]);
+        const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
+        const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
+        if (wave == 0) {   // the answer, before this wave's first store
+            const bool rdy = early || __all(pvl != 0);
+            if (lane == 0) lflag[0] = rdy ? 1 : 0;
+        }
+        if (ok) {   // dA_t overwrites the gate stash in place: read by the dX product after the launch, or by the FR_DX_BWD role in it
+            if (dA_sc1) {
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+                const unsigned o = (unsigned)(((size_t)b * G4 + j) * 2);
+                st8_sc1(rg, o, pi);
+                st8_sc1(rg, o + Hp * 2, pf);
+                st8_sc1(rg, o + 2 * Hp * 2, pg);
+                st8_sc1(rg, o + 3 * Hp * 2, po);
+            } else {
+                bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                gst<uint2>(go_, pi);
+                gst<uint2>(go_ + Hp, pf);
+                gst<uint2>(go_ + 2 * Hp, pg);
+                gst<uint2>(go_ + 3 * Hp, po);
+            }
+        }
+        {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
+            unsigned char* drow = da_img + erow * DRS + jq * 8;
+            *reinterpret_cast<uint2*>(drow) = pi;
+            *reinterpret_cast<uint2*>(drow + 64) = pf;
+            *reinterpret_cast<uint2*>(drow + 128) = pg;
+            *reinterpret_cast<uint2*>(drow + 192) = po;
+        }
+        __syncthreads();
+        PL_ST(1);   // cell + stash stores + dA image
+        const unsigned char* bfr = da_img + (lane & 31) * DRS + (lane >> 5) * 16;
+        // the next chain-step's operands start now (older than every hand-off store below: the drain before the flag covers them,
+        // and by then the tiles' MFMAs have run beside their flight)
+        const bool ready = has_next && lflag[0] != 0;
+        if (ready) issue_loads(gn, tn);
+        PL_ST(6);   // prefetch issue
+        // C. partial tiles.  Nobody consumes the recurrence's partials of step 0.
+        if (t > 0) {
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int nt = wave + 4 * i;
+                if (nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
+            }
+        }
+        if constexpr (MEL) if (wave < n_mel) {
+            bf16_t* xd = XM + (size_t)(t % kFusedRing) * mslot_stride + (size_t)g * mgrp_stride + (size_t)p * TILE;   // [tile][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(n_mel - 1) * P + 1) * TILE * 2));
+            uint4 wmel[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wmel[ks] = *reinterpret_cast<const uint4*>(wm_img + (32 * wave + (lane & 31)) * DRS + ks * 32 + (lane >> 5) * 16);
+            partial_tile(wmel, bfr, tst, TRS, 0, ro, (unsigned)((size_t)wave * P * TILE * 2), lane);
+        }
+        PL_ST(2);   // MFMA + hand-off stores (+ flag answer, prefetch issue)
+        raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
+        PL_ST(3);   // drain + barrier + flag
+        if (!has_next) break;
+        if (!ready) {
+            if (!flags_wait(pn, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+            issue_loads(gn, tn);
+        }
+        PL_ST(5);   // blocking wait
+        c = cn;
+        t = tn;
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dL/dh of the layer below = dA W_ih of the layer above, reduce-scatter form like the recurrence: workgroup p takes the
+// dA slice its partner (slice p of the layer above's recurrence) has just written, multiplies it with its 128 rows of
+// W_ih^T and hands the P partial tiles to the layer below (ring of kFusedRing steps; a slot is rewritten only after every
+// consumer has raised its flag of the step that used it).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmBwdLds<KS>;
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32, NT = (P + 3) / 4;
+    constexpr int DRS = L::DRS, TRS = L::TRS;
+    constexpr size_t TILE = 32 * 32;
+    unsigned char* da_img = lds + L::O_DA;
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);   // wave-uniform, and the compiler should know
+    unsigned char* tst = lds + L::O_TST + wave * 32 * TRS;
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(R.Wg);   // Wih^T of the layer above, packed [Hp][4 Hp]
+    uint4 wreg[NT][8];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nt = wave + 4 * i;
+        const int n = 32 * (nt < P ? nt : 0) + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+        {
+            wreg[i][ks] = gld<uint4>(WT + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
+            pin(wreg[i][ks]);
+        }
+    }
+    const size_t slabG = (size_t)Bp * G4;
+    const bf16_t* __restrict__ G = static_cast<const bf16_t*>(R.G);   // dA stash of the layer above
+    bf16_t* __restrict__ XE = static_cast<bf16_t*>(R.xchg_ext);
+    const size_t grp_stride = (size_t)P * P * TILE, slot_stride = (size_t)a.n_groups * grp_stride;
+
+    uint4 dv[2];   // the partner's dA slice of the next chain-step: 32 rows x 4 gates x 64 bytes = 512 pieces
+    auto issue_loads = [&](int g2, int t2) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t2 * slabG, (unsigned)(slabG * 2));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+            const int rb = 32 * g2 + row;
+            dv[q] = rb < Bp ? ld16_sc1(rg, (unsigned)(((size_t)rb * G4 + gate * Hp + 32 * p + 8 * q4) * 2)) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    PL_ST_DECL
+    int c = 0, t = T - 1;
+    {
+        const FlagPoll s0 = step_flags(a, WT_, set * RC, t, p);
+        if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        issue_loads(set * RC, t);
+    }
+    for (;;) {
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t - 1; }
+        const bool has_next = tn >= 0;
+        const int gn = set * RC + cn;
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
+        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        int pvl = 1;
+        if (wave == 0 && has_next) pvl = poll_load(pn, lane);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+            *reinterpret_cast<uint4*>(da_img + row * DRS + gate * 64 + q4 * 16) = dv[q];
+        }
+        if (wave == 0) {   // answered before this wave's first store (see the recurrence role)
+            const bool rdy = __all(pvl != 0);
+            if (lane == 0) lflag[0] = rdy ? 1 : 0;
+        }
+        __syncthreads();
+        PL_ST(0);
+        const unsigned char* bfr = da_img + (lane & 31) * DRS + (lane >> 5) * 16;
+        const bool ready = has_next && lflag[0] != 0;
+        if (ready) issue_loads(gn, tn);
+        bf16_t* xd = XE + (size_t)(t % kFusedRing) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int nt = wave + 4 * i;
+            if (nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
+        }
+        PL_ST(2);
+        raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
+        PL_ST(3);
+        if (!has_next) break;
+        if (!ready) {
+            if (!flags_wait(pn, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+            issue_loads(gn, tn);
+        }
+        PL_ST(5);
+        c = cn;
+        t = tn;
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward mel head: dL/dmel_t = sum of the embedder's input-gradient partial tiles; dL/dY of the two frames pooled into t
+// = loss part (computed before the launch) + 0.5 dL/dmel_t; dL/dh of the predictor's top layer for those two frames =
+// dL/dY W_p (one row per pooled frame: both frames get the same)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmBwdLds<KS>;
+    constexpr int Hp = 16 * KS, P = Hp / 32, NT = (P + 3) / 4;
+    constexpr int TRS = L::TRS, MRS = L::MRS;
+    constexpr size_t TILE = 32 * 32;
+    unsigned char* dy_img = lds + L::O_MEL;     // [32 batch rows][64 mel columns] bf16
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);   // wave-uniform, and the compiler should know
+    unsigned char* tst = lds + L::O_TST + wave * 32 * TRS;
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(R.Wg);   // Wlin^T packed [Hp][64]
+    uint4 wreg[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nt = wave + 4 * i;
+        const int n = 32 * (nt < P ? nt : 0) + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { wreg[i][ks] = gld<uint4>(WT + (size_t)n * 64 + 16 * ks + 8 * (lane >> 5)); pin(wreg[i][ks]); }
+    }
+    const bf16_t* __restrict__ XM = static_cast<const bf16_t*>(R.xchg_mel);   // [ring][groups][2][P src][32][32]
+    const size_t mgrp_stride = (size_t)2 * P * TILE, mslot_stride = (size_t)a.n_groups * mgrp_stride;
+    const float* __restrict__ Yl = static_cast<const float*>(R.dh_ext);       // loss part of dL/dY, f32 [2 T][Bp][64]
+    bf16_t* __restrict__ Out = static_cast<bf16_t*>(R.out);                   // [T][Bp][Hp]
+    const size_t slabH = (size_t)Bp * Hp;
+    const int erow = tid >> 3, jq = tid & 7;   // thread -> batch row, mel columns 8 jq .. 8 jq + 7 (tile jq >> 2, columns 8 (jq & 3))
+    const int out_dim = R.out_dim;
+
+    uint4 pm[P];
+    float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
+    auto issue_loads = [&](int g2, int t2) {
+        const bf16_t* xs = XM + (size_t)(t2 % kFusedRing) * mslot_stride + (size_t)g2 * mgrp_stride + (size_t)(jq >> 2) * P * TILE;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+        const unsigned o0 = (unsigned)((erow * 32 + 8 * (jq & 3)) * 2);
+#pragma unroll
+        for (int s = 0; s < P; ++s) pm[s] = ld16_sc1_so(rx, o0, (unsigned)(s * TILE * 2));
+        int b2 = 32 * g2 + erow;
+        b2 = b2 < Bp ? b2 : Bp - 1;
+        const float* yr = Yl + ((size_t)(2 * t2) * Bp + b2) * 64 + 8 * jq;
+        y0 = gld<float4>(yr);
+        y1 = gld<float4>(yr + 4);
+    };
+    PL_ST_DECL
+    int c = 0, t = T - 1;
+    {
+        const FlagPoll s0 = step_flags(a, WT_, set * RC, t, p);
+        if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        issue_loads(set * RC, t);
+    }
+    for (;;) {
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t - 1; }
+        const bool has_next = tn >= 0;
+        const int gn = set * RC + cn;
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
+        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        int pvl = 1;
+        if (wave == 0 && has_next) pvl = poll_load(pn, lane);
+        {
+            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                float f[4];
+                unpack_bf16x4(make_uint2(pm[s].x, pm[s].y), f);
+                sum[0] += f[0]; sum[1] += f[1]; sum[2] += f[2]; sum[3] += f[3];
+                unpack_bf16x4(make_uint2(pm[s].z, pm[s].w), f);
+                sum[4] += f[0]; sum[5] += f[1]; sum[6] += f[2]; sum[7] += f[3];
+            }
+            const float yl[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+            const bool live = 32 * g + erow < a.B;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (live && 8 * jq + k < out_dim) ? yl[k] + 0.5f * sum[k] : 0.f;
+            unsigned char* d = dy_img + erow * MRS + jq * 16;
+            *reinterpret_cast<uint2*>(d) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(d + 8) = pack_bf16x4(v[4], v[5], v[6], v[7]);
+        }
+        if (wave == 0) {
+            const bool rdy = __all(pvl != 0);
+            if (lane == 0) lflag[0] = rdy ? 1 : 0;
+        }
+        __syncthreads();
+        PL_ST(0);
+        uint4 bfr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bfr[ks] = *reinterpret_cast<const uint4*>(dy_img + (lane & 31) * MRS + ks * 32 + (lane >> 5) * 16);
+        const bool ready = has_next && lflag[0] != 0;
+        if (ready) issue_loads(gn, tn);
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(Out + (size_t)t * slabH, (unsigned)(slabH * 2));
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int nt = wave + 4 * i;
+            if (nt < P) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i][ks]), __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+                unsigned char* orow = tst + (lane & 31) * TRS + (4 * (lane >> 5)) * 2;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<uint2*>(orow + rg * 16) = pack_bf16x4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {   // the wave's own tile, by rows: 64 bytes of a dL/dh row per 4 lanes
+                    const int cidx = lane + 64 * q, r = cidx >> 2, c4 = cidx & 3;
+                    const int rb = 32 * g + r;
+                    if (rb < Bp) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(tst + r * TRS + (8 * c4) * 2);
+                        st16_sc1(ro, (unsigned)(((size_t)rb * Hp + 32 * nt + 8 * c4) * 2), v);
+                    }
+                }
+            }
+        }
+        PL_ST(2);
+        raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride);
+        PL_ST(3);
+        if (!has_next) break;
+        if (!ready) {
+            if (!flags_wait(pn, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+            issue_loads(gn, tn);
+        }
+        PL_ST(5);
+        c = cn;
+        t = tn;
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(LstmBwdLds<KS>::BYTES + 15) / 16 * 16];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    // readfirstlane: the table is read with vector loads, and a role index the compiler takes for divergent turns every access
+    // to the role's descriptor into a vector load with an s_waitcnt vmcnt(0) -- which also waits for the prefetched tiles
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    // the role's descriptor stays in (constant) device memory: uniform address -> scalar loads; the role functions copy what
+    // their loops use into locals (the whole struct held in SGPRs crowds them out, read through LDS it costs a round trip per use)
+    const FusedRole R = uniform_role(a.roles[role]);
+    switch (R.type) {
+        case FR_LSTM_BWD:
+            if (R.xchg_mel && R.xchg_ext) fused_lstm_bwd<KS, true, true>(a, R, set, p, lds);
+            else if (R.xchg_mel) fused_lstm_bwd<KS, false, true>(a, R, set, p, lds);
+            else if (R.xchg_ext) fused_lstm_bwd<KS, true, false>(a, R, set, p, lds);
+            else fused_lstm_bwd<KS, false, false>(a, R, set, p, lds);
+            break;
+        case FR_DX_BWD: fused_dx_bwd<KS>(a, R, set, p, lds); break;
+        case FR_HEAD_BWD: fused_head_bwd<KS>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
+template <int KS>
+constexpr int fused_fwd_lds_bytes() {
+    int m = LstmFwdLds<KS, 0>::BYTES;
+    m = m > LstmFwdLds<KS, 2>::BYTES ? m : LstmFwdLds<KS, 2>::BYTES;
+    m = m > LstmFwdLds<KS, 4>::BYTES ? m : LstmFwdLds<KS, 4>::BYTES;
+    m = m > GemmFwdLds<KS>::BYTES ? m : GemmFwdLds<KS>::BYTES;
+    return (m + 15) / 16 * 16;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[fused_fwd_lds_bytes<KS>()];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    // readfirstlane: the table is read with vector loads, and a role index the compiler takes for divergent turns every access
+    // to the role's descriptor into a vector load with an s_waitcnt vmcnt(0) -- which also waits for the prefetched tiles
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    // the role's descriptor stays in (constant) device memory: uniform address -> scalar loads; the role functions copy what
+    // their loops use into locals (the whole struct held in SGPRs crowds them out, read through LDS it costs a round trip per use)
+    const FusedRole R = uniform_role(a.roles[role]);
+    switch (R.type) {
+        case FR_LSTM_FWD:
+            if (R.ksx == 2) fused_lstm_fwd<KS, 2>(a, R, set, p, lds);
+            else if (R.ksx == 4) fused_lstm_fwd<KS, 4>(a, R, set, p, lds);
+            else fused_lstm_fwd<KS, 0>(a, R, set, p, lds);
+            break;
+        case FR_PROJ_FWD: fused_gemm_fwd<KS, false>(a, R, set, p, lds); break;
+        case FR_HEAD_FWD: fused_gemm_fwd<KS, true>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
+}  // namespace
+
+#define PL_FUSED_KS_LIST(X) X(4) X(46)
+
+bool fused_supported(int Hp) {
+#define PL_CASE(K) if (Hp == 16 * K) return true;
+    PL_FUSED_KS_LIST(PL_CASE)
+#undef PL_CASE
+    return false;
+}
+
+void launch_fused_fwd(hipStream_t stream, int Hp, const FusedArgs& a) {
+#define PL_CASE(K)                                                                              \
+    if (Hp == 16 * K) {                                                                         \
+        hipLaunchKernelGGL(fused_fwd_kernel<K>, dim3(a.grid), dim3(256), 0, stream, a);         \
+        return;                                                                                 \
+    }
+    PL_FUSED_KS_LIST(PL_CASE)
+#undef PL_CASE
+}
+
+void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a) {
+#define PL_CASE(K)                                                                              \
+    if (Hp == 16 * K) {                                                                         \
+        hipLaunchKernelGGL(fused_bwd_kernel<K>, dim3(a.grid), dim3(256), 0, stream, a);         \
+        return;                                                                                 \
+    }
+    PL_FUSED_KS_LIST(PL_CASE)
+#undef PL_CASE
+}
+
+}  // namespace pl

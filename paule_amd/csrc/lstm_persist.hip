@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_sweep_kernel(LstmSweepArgs a)
                 vf[u] = sigmoid_fast(acc[4 + u] + gxf[u]);
                 vg[u] = tanh_fast(acc[8 + u] + gxg[u]);
                 vo[u] = sigmoid_fast(acc[12 + u] + gxo[u]);
-                c_state[u] = vf[u] * c_state[u] + vi[u] * vg[u];
+                c_state[u] = cell_c(vf[u], c_state[u], vi[u], vg[u]);
                 vc[u] = c_state[u];
                 vh[u] = vo[u] * tanh_fast(vc[u]);
             }

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
             for (int jt = 0; jt < 2; ++jt) {
                 const float vi = sigmoid_fast(acc[jt][0] + gx[jt][0]), vf = sigmoid_fast(acc[jt][1] + gx[jt][1]);
                 const float vg = tanh_fast(acc[jt][2] + gx[jt][2]), vo = sigmoid_fast(acc[jt][3] + gx[jt][3]);
-                c_state[jt] = vf * c_state[jt] + vi * vg;
+                c_state[jt] = cell_c(vf, c_state[jt], vi, vg);
                 const float vh = vo * tanh_fast(c_state[jt]);
                 unsigned char* o = ost + lr * ORS + ul[jt] * 2;
                 *reinterpret_cast<unsigned short*>(o) = bf16_bits(vh);

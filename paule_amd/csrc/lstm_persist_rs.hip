@@ -122,15 +122,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
             unpack_bf16x4(scp, cp);
             float dai[4], daf[4], dag[4], dao[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float tc = tanh_fast(c[u]);
-                const float dc = dc_next[u] + dh[u] * go[u] * (1.f - tc * tc);
-                dai[u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
-                daf[u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
-                dag[u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
-                dao[u] = dh[u] * tc * go[u] * (1.f - go[u]);
-                dc_next[u] = dc * gf[u];
-            }
+            for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
             const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
             const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
             if (ok) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)

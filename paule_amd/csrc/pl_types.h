@@ -31,8 +31,11 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float tanh_fast(float x) {   // 1 - 2 / (1 + e^{2x}); saturates cleanly at +-1
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)), 1.0f);
 }
+// c_t = f c_{t-1} + i g with the rounding spelled out: left to the compiler, WHICH product is fused into the FMA differs from
+// kernel to kernel, and the per-layer and the fused sweeps (lstm_persist.hip, lstm_fused.hip) are compared bit for bit
+__device__ __forceinline__ float cell_c(float f, float c_prev, float i, float g) { return __builtin_fmaf(f, c_prev, i * g); }
 
 
 // activation functions by arithmetic type: exact libm forms on the f32 path (parity bar 1e-5), hardware forms on bf16

@@ -6,6 +6,7 @@
 // counters, so the captured graph is static.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <unordered_map>
@@ -223,6 +224,20 @@ struct pl_handle {
     bool small_grid = true;     // PAULE_HIP_SMALL_GRID: batches of fewer than 8 groups still launch 8 group slots, which keeps each
                                 // group on one XCD (B = 8: 5.40 -> 4.98 ms per iteration, profiles/r01_ab_small_batch_grid.txt)
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
+    // fused acoustic sweeps (lstm_fused.hip): one persistent launch per direction, workgroups take roles from these tables
+    bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
+    int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles
+    short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
+    int fused_grid_fwd = 0;
+    bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
+    short* fused_tab_bwd = nullptr;
+    int fused_grid_bwd = 0;
+    void* fused_xchg[kFusedMaxRoles] = {};      // recurrence exchange of every backward LSTM role (they run side by side)
+    void* fused_xchg_ext[kFusedMaxRoles] = {};  // ring of dL/dh partial tiles written by the FR_DX_BWD role with this index
+    void* fused_xchg_mel = nullptr;             // ring of the embedder's input-gradient partial tiles
+    FusedRole* fused_roles_fwd = nullptr;       // role tables in device memory (static for the life of the handle: every pointer is the
+    FusedRole* fused_roles_bwd = nullptr;       // handle's own buffer, the flag slices are the last 2 n_roles of the iteration's slices)
+    int fused_n_roles = 0;
     unsigned long long spin_ticks = 200000000ull;   // 2 s
     unsigned poll_mask = 63u;
     double* past = nullptr;
@@ -1185,6 +1200,276 @@ void tube_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs
     launch_gemm_nt(st, h->dt, true, l0.G, 4 * u.Hp, l0.WihT, 4 * u.Hp, nullptr, h->dX2, l0.in_p, T * Bp, l0.in_p, 4 * u.Hp);
 }
 
+// ---- fused acoustic sweeps (lstm_fused.hip) ------------------------------------------------------------------------------
+// Roles of the forward launch, in table order: 0 predictor recurrence, 1 mel head (post_linear + pooling), 2 embedder layer 1,
+// then per further embedder layer l its input projection (3 + 2 (l - 1)) and its recurrence (4 + 2 (l - 1)).
+// Placement (speed only): the grid has one block per CU, block b sits on XCD b % 8 (observed dealing); a recurrence set's
+// P workgroups take consecutive depths of ONE XCD slot while one has room, everything else fills what is left.
+struct FusedSet { int role, set, P; bool together; };
+
+std::vector<short> fused_block_table(int n_cu, const std::vector<FusedSet>& sets, int* grid_out) {
+    const int slots = 8, depth = n_cu / slots;
+    std::vector<short> tab((size_t)slots * depth * 4, -1);
+    std::vector<int> used(slots, 0);
+    auto put = [&](int slot, const FusedSet& fs, int p) {
+        const int b = used[slot]++ * slots + slot;
+        tab[(size_t)b * 4] = (short)fs.role; tab[(size_t)b * 4 + 1] = (short)fs.set; tab[(size_t)b * 4 + 2] = (short)p; tab[(size_t)b * 4 + 3] = 0;
+    };
+    for (int pass = 0; pass < 2; ++pass)
+        for (const FusedSet& fs : sets) {
+            if ((pass == 0) != fs.together) continue;
+            int best = -1;
+            if (fs.together)
+                for (int s = 0; s < slots; ++s)
+                    if (depth - used[s] >= fs.P && (best < 0 || used[s] < used[best])) best = s;
+            if (best >= 0) {
+                for (int p = 0; p < fs.P; ++p) put(best, fs, p);
+            } else {
+                for (int p = 0; p < fs.P; ++p) {
+                    int s = 0;
+                    for (int k = 1; k < slots; ++k)
+                        if (used[k] < used[s]) s = k;
+                    if (used[s] >= depth) { *grid_out = 0; return tab; }
+                    put(s, fs, p);
+                }
+            }
+        }
+    int top = 0;
+    for (int s = 0; s < slots; ++s) top = used[s] > top ? used[s] : top;
+    *grid_out = top * slots;
+    return tab;
+}
+
+// chains per workgroup for the predictor's (Cp) and the embedder's (Ce) roles: the fewest CUs' worth of latency.  A
+// chain-step keeps a workgroup busy ~2.1 us, a group's own step-to-step latency is ~4.2 us; the embedder has half the steps.
+int plan_fused(pl_handle* h) {
+    h->fused_fwd_ok = h->fused_bwd_ok = false;
+    int mode = 1;   // bit 0: fused forward launch (default), bit 1: fused backward launch (experimental: slower than the per-layer sweeps so far)
+    if (const char* z = std::getenv("PAULE_HIP_FUSED")) mode = std::atoi(z);
+    int min_rows = 129;   // smaller batches: the 16-row kernels and their chunk pipelines (4.1a, 4.1f) are faster
+    if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
+    const Model &p = h->pred, &e = h->emb;
+    if (!(mode & 3) || h->dt != BF16 || !h->use_sweep || !h->fuse_input || h->Bp < min_rows) return PL_OK;
+    if (p.L != 1 || e.L < 1 || e.L > 4 || p.Hp != e.Hp || !fused_supported(p.Hp) || p.Hp / 32 > 31) return PL_OK;
+    if (p.layers[0].in_p != 32 || e.layers[0].in_p != 64 || h->Mp != 64 || h->emb_post > 0 || h->emb_blocks > 0) return PL_OK;
+    if (!h->need_emb_in_step() || h->n_cu % 8 != 0) return PL_OK;
+    const int P = p.Hp / 32, ng = (h->Bp + 31) / 32, n_emb_roles = 2 * e.L - 1;
+    if (3 + 2 * (e.L - 1) > kFusedMaxRoles) return PL_OK;
+    int forced_p = 0, forced_e = 0;
+    if (const char* z = std::getenv("PAULE_HIP_FUSED_CP")) forced_p = std::atoi(z);
+    if (const char* z = std::getenv("PAULE_HIP_FUSED_CE")) forced_e = std::atoi(z);
+    double best_cost = 1e30;
+    int best_cp = 0, best_ce = 0;
+    const int cmax = ((mode & 2) && h->bwd_mode == 1) ? 4 : kFusedMaxChains;   // the backward roles have LDS for 4 chains (lstm_fused.hip)
+    for (int cp = 1; cp <= cmax; ++cp)
+        for (int ce = 1; ce <= cmax; ++ce) {
+            if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
+            const int sp = (ng + cp - 1) / cp, se = (ng + ce - 1) / ce;
+            if (sp * (P + 1) + se * P * n_emb_roles > h->n_cu || sp * P + se * (1 + P * n_emb_roles) > h->n_cu) continue;
+            const double tp = std::max(cp * 2.1, 4.2), te = std::max(ce * 2.1, 4.2) / 2.0;
+            const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
+            if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
+        }
+    if (!best_cp) return PL_OK;
+    const int sp = (ng + best_cp - 1) / best_cp, se = (ng + best_ce - 1) / best_ce;
+    h->fused_Cp = best_cp; h->fused_Ce = best_ce;
+    h->fused_n_roles = 3 + 2 * (e.L - 1);
+    int rc;
+    if (mode & 1) {
+        std::vector<FusedSet> sets;
+        for (int s = 0; s < sp; ++s) sets.push_back({0, s, P, true});
+        for (int s = 0; s < se; ++s) sets.push_back({2, s, P, true});
+        for (int l = 1; l < e.L; ++l)
+            for (int s = 0; s < se; ++s) sets.push_back({4 + 2 * (l - 1), s, P, true});
+        for (int l = 1; l < e.L; ++l)
+            for (int s = 0; s < se; ++s) sets.push_back({3 + 2 * (l - 1), s, P, false});
+        for (int s = 0; s < sp; ++s) sets.push_back({1, s, 1, false});
+        int grid = 0;
+        std::vector<short> tab = fused_block_table(h->n_cu, sets, &grid);
+        if (grid > 0 && grid <= h->n_cu) {
+            if ((rc = dev_alloc(h, &h->fused_tab_fwd, (size_t)h->n_cu * 4))) return rc;
+            PL_HIP(hipMemcpyAsync(h->fused_tab_fwd, tab.data(), sizeof(short) * (size_t)grid * 4, hipMemcpyHostToDevice, h->stream));
+            PL_HIP(hipStreamSynchronize(h->stream));   // tab is a local
+            h->fused_grid_fwd = grid;
+            h->fused_fwd_ok = true;
+        }
+    }
+    if ((mode & 2) && h->bwd_mode == 1) {
+        // backward roles: 0 predictor, 1 backward mel head, 2 embedder layer 1; per further layer l: 3 + 2 (l - 1) its dL/dh product for
+        // the layer below, 4 + 2 (l - 1) its recurrence
+        std::vector<FusedSet> sets;
+        for (int s = 0; s < sp; ++s) sets.push_back({0, s, P, true});
+        for (int s = 0; s < se; ++s) sets.push_back({2, s, P, true});
+        for (int l = 1; l < e.L; ++l)
+            for (int s = 0; s < se; ++s) sets.push_back({4 + 2 * (l - 1), s, P, true});
+        for (int l = 1; l < e.L; ++l)
+            for (int s = 0; s < se; ++s) sets.push_back({3 + 2 * (l - 1), s, P, false});
+        for (int s = 0; s < se; ++s) sets.push_back({1, s, 1, false});
+        int grid = 0;
+        std::vector<short> tab = fused_block_table(h->n_cu, sets, &grid);
+        if (grid > 0 && grid <= h->n_cu) {
+            if ((rc = dev_alloc(h, &h->fused_tab_bwd, (size_t)h->n_cu * 4))) return rc;
+            PL_HIP(hipMemcpyAsync(h->fused_tab_bwd, tab.data(), sizeof(short) * (size_t)grid * 4, hipMemcpyHostToDevice, h->stream));
+            PL_HIP(hipStreamSynchronize(h->stream));
+            const size_t tile = 32 * 32 * 2, rec = 2 * (size_t)ng * P * P * tile, ring = (size_t)kFusedRing * ng * P * P * tile;
+            if ((rc = raw_alloc(h, &h->fused_xchg[0], rec))) return rc;
+            if ((rc = raw_alloc(h, &h->fused_xchg[2], rec))) return rc;
+            for (int l = 1; l < e.L; ++l) {
+                if ((rc = raw_alloc(h, &h->fused_xchg[4 + 2 * (l - 1)], rec))) return rc;
+                if ((rc = raw_alloc(h, &h->fused_xchg_ext[3 + 2 * (l - 1)], ring))) return rc;
+            }
+            if ((rc = raw_alloc(h, &h->fused_xchg_mel, (size_t)kFusedRing * ng * (h->Mp / 32) * P * tile))) return rc;
+            h->fused_grid_bwd = grid;
+            h->fused_bwd_ok = true;
+        }
+    }
+    return PL_OK;
+}
+
+void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, const FusedRole* roles, bool bwd) {
+    a.Bp = h->Bp; a.B = h->B; a.n_groups = (h->Bp + 31) / 32; a.flag_stride = h->flag_stride; a.n_roles = h->fused_n_roles;
+    a.grid = grid;
+    a.status = h->sweep_status; a.spin_ticks = h->spin_ticks; a.poll_mask = h->poll_mask;
+    a.block_tab = tab;
+    a.roles = roles;
+    a.stamps = h->sweep_stamps ? h->sweep_stamps + (bwd ? 256 * 8 : 0) : nullptr;
+}
+
+// flag slice of role r of the fused forward (bwd = false) / backward launch: the last 2 n_roles slices of an iteration
+int* fused_slice(pl_handle* h, int r, bool bwd) {
+    const size_t ints = h->sweep_cnt_bytes / sizeof(int);
+    return h->sweep_cnt + (size_t)(h->n_sweep_slots - 2 * h->fused_n_roles + (bwd ? h->fused_n_roles : 0) + r) * ints;
+}
+
+// the role tables (called once, at the end of pl_create: every buffer exists)
+int build_fused_roles(pl_handle* h) {
+    Model &p = h->pred, &e = h->emb;
+    const int n_roles = h->fused_n_roles, T = h->T, Tp = h->Tp, P = p.Hp / 32;
+    int rc;
+    if (h->fused_fwd_ok) {
+        std::vector<FusedRole> roles(n_roles);
+        int* fl[kFusedMaxRoles];
+        for (int r = 0; r < n_roles; ++r) fl[r] = fused_slice(h, r, false);
+        {   // 0: predictor recurrence, CP input fused
+            FusedRole& R = roles[0];
+            LstmLayer& ly = p.layers[0];
+            R.type = FR_LSTM_FWD; R.ksx = ly.in_p / 16; R.C = h->fused_Cp; R.T = T; R.flags = fl[0];
+            R.wait[0] = FusedWait{fl[0], T, P, 0, 0, -1};
+            R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c; R.x_in = h->X0; R.Wih = ly.Wih; R.bias = ly.bias;
+        }
+        {   // 1: mel head on every predictor step, pooled pairs out
+            FusedRole& R = roles[1];
+            R.type = FR_HEAD_FWD; R.C = h->fused_Cp; R.T = 2 * Tp; R.flags = fl[1];
+            R.wait[0] = FusedWait{fl[0], T, P, 0, 0, 0};
+            R.src_h = p.layers[0].h; R.Wg = p.Wlin; R.bias = p.blin; R.out = h->mel_tm; R.out_bm = h->mel_bm; R.out_dim = h->M; R.out_p = h->Mp;
+        }
+        {   // 2: embedder layer 1, pooled mel input fused
+            FusedRole& R = roles[2];
+            LstmLayer& ly = e.layers[0];
+            R.type = FR_LSTM_FWD; R.ksx = ly.in_p / 16; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[2];
+            R.wait[0] = FusedWait{fl[2], Tp, P, 0, 0, -1};
+            R.wait[1] = FusedWait{fl[1], Tp, 1, 0, 0, 0};
+            R.src_sc1 = 1;
+            R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c; R.x_in = h->mel_tm; R.Wih = ly.Wih; R.bias = ly.bias;
+        }
+        for (int l = 1; l < e.L; ++l) {
+            LstmLayer& ly = e.layers[l];
+            const int rp = 3 + 2 * (l - 1), rl = rp + 1, rsrc = l == 1 ? 2 : rl - 2;
+            FusedRole& Rp = roles[rp];
+            Rp.type = FR_PROJ_FWD; Rp.C = h->fused_Ce; Rp.T = Tp; Rp.flags = fl[rp];
+            Rp.wait[0] = FusedWait{fl[rsrc], Tp, P, 0, 0, 0};
+            Rp.src_h = e.layers[l - 1].h; Rp.Wg = ly.Wih; Rp.bias = ly.bias; Rp.out = ly.G;
+            FusedRole& Rl = roles[rl];
+            Rl.type = FR_LSTM_FWD; Rl.ksx = 0; Rl.C = h->fused_Ce; Rl.T = Tp; Rl.flags = fl[rl];
+            Rl.wait[0] = FusedWait{fl[rl], Tp, P, 0, 0, -1};
+            Rl.wait[2] = FusedWait{fl[rp], Tp, 1, 1, 0, 0};
+            Rl.src_sc1 = 1;
+            Rl.G = ly.G; Rl.W = ly.Whh; Rl.h = ly.h; Rl.c = ly.c;
+        }
+        if ((rc = dev_alloc(h, &h->fused_roles_fwd, (size_t)n_roles))) return rc;
+        PL_HIP(hipMemcpyAsync(h->fused_roles_fwd, roles.data(), sizeof(FusedRole) * n_roles, hipMemcpyHostToDevice, h->stream));
+        PL_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (h->fused_bwd_ok) {
+        std::vector<FusedRole> roles(n_roles);
+        int* fl[kFusedMaxRoles];
+        for (int r = 0; r < n_roles; ++r) fl[r] = fused_slice(h, r, true);
+        {   // 0: predictor recurrence; dL/dh from the backward mel head, one row per pooled frame
+            FusedRole& R = roles[0];
+            LstmLayer& ly = p.layers[0];
+            R.type = FR_LSTM_BWD; R.C = h->fused_Cp; R.T = T; R.flags = fl[0];
+            R.wait[0] = FusedWait{fl[0], T, P, 0, 0, 1};
+            R.wait[2] = FusedWait{fl[1], Tp, 1, 0, 1, 0};
+            R.src_sc1 = 1;
+            R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.dh_ext = p.dh_ext; R.dh_ext_half = 1; R.dh_ext_rows = Tp; R.xchg = h->fused_xchg[0];
+        }
+        {   // 1: backward mel head
+            FusedRole& R = roles[1];
+            R.type = FR_HEAD_BWD; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[1];
+            R.wait[0] = FusedWait{fl[2], Tp, P, 0, 0, 0};
+            R.Wg = p.WlinT; R.out = p.dh_ext; R.dh_ext = h->Y; R.out_dim = h->M; R.out_p = h->Mp; R.xchg_mel = h->fused_xchg_mel;
+        }
+        for (int l = 0; l < e.L; ++l) {
+            LstmLayer& ly = e.layers[l];
+            const int rl = l == 0 ? 2 : 4 + 2 * (l - 1);
+            const bool top = l == e.L - 1;
+            FusedRole& R = roles[rl];
+            R.type = FR_LSTM_BWD; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[rl];
+            R.wait[0] = FusedWait{fl[rl], Tp, P, 0, 0, 1};
+            R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
+            if (top) R.dh_last = h->dv;
+            else {   // dL/dh partial tiles from the layer above's product role
+                const int rdx = 3 + 2 * l;
+                R.wait[1] = FusedWait{fl[rdx], Tp, P, 0, 0, 0};
+                R.xchg_ext = h->fused_xchg_ext[rdx];
+            }
+            if (l == 0) {   // input-gradient tiles for the backward mel head; a ring slot is free once the head has finished the step that used it
+                R.wait[2] = FusedWait{fl[1], Tp, 1, 0, 0, kFusedRing};
+                R.Wg = ly.WihT; R.out_p = h->Mp; R.xchg_mel = h->fused_xchg_mel;
+            } else {        // this layer's dA feeds its product role
+                R.dA_sc1 = 1;
+                const int rdx = 3 + 2 * (l - 1), rbelow = l == 1 ? 2 : 4 + 2 * (l - 2);
+                FusedRole& D = roles[rdx];
+                D.type = FR_DX_BWD; D.C = h->fused_Ce; D.T = Tp; D.flags = fl[rdx];
+                D.wait[0] = FusedWait{fl[rbelow], Tp, P, 0, 0, kFusedRing};
+                D.wait[2] = FusedWait{fl[rl], Tp, 1, 1, 0, 0};
+                D.G = ly.G; D.Wg = ly.WihT; D.xchg_ext = h->fused_xchg_ext[rdx];
+            }
+        }
+        if ((rc = dev_alloc(h, &h->fused_roles_bwd, (size_t)n_roles))) return rc;
+        PL_HIP(hipMemcpyAsync(h->fused_roles_bwd, roles.data(), sizeof(FusedRole) * n_roles, hipMemcpyHostToDevice, h->stream));
+        PL_HIP(hipStreamSynchronize(h->stream));
+    }
+    return PL_OK;
+}
+
+// predictor + mel head + embedder LSTM layers as one launch; false = not taken (the caller runs the per-layer path)
+bool fused_acoustic_forward(pl_handle* h, hipStream_t st) {
+    if (!h->fused_fwd_ok || h->sweep_slot < 0) return false;   // the flag slices are zeroed at the top of an iteration only
+    launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
+    FusedArgs a{};
+    fused_common_args(h, a, h->fused_grid_fwd, h->fused_tab_fwd, h->fused_roles_fwd, false);
+    launch_fused_fwd(st, h->pred.Hp, a);
+    return true;
+}
+
+// embedder layers, their dL/dh products, the backward mel head and the predictor's recurrence as one launch.  Before it: dL/dsem
+// -> dL/dh at the embedder's last step (h->dv), and the loss part of dL/dY in f32 (h->Y is free in the fused forward: the mel
+// head there pools without storing Y).  After it: dL/dCP = dA W_ih of the predictor, one product.
+bool fused_acoustic_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
+    Model& p = h->pred;
+    if (!h->fused_bwd_ok || h->sweep_slot < 0) return false;
+    launch_dsem(st, h->dt, la, h->dsem);
+    emb_head_backward(h, st);
+    launch_dy(st, F32, la, nullptr, h->Y);
+    FusedArgs a{};
+    fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
+    launch_fused_bwd(st, p.Hp, a);
+    LstmLayer& l0 = p.layers[0];
+    launch_gemm_nt(st, h->dt, true, l0.G, 4 * p.Hp, l0.WihT, 4 * p.Hp, nullptr, h->dX, l0.in_p, h->T * h->Bp, l0.in_p, 4 * p.Hp);
+    return true;
+}
+
 LossArgs loss_args(pl_handle* h, bool with_sem) {
     LossArgs a{};
     a.B = h->B; a.T = h->T; a.Tp = h->Tp; a.C = h->C; a.M = h->M; a.S = h->S;
@@ -1225,9 +1510,15 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     const int pipe_nc = acoustic_pipeline_chunks(h);
     if (pipe_nc) {
         acoustic_forward_pipeline(h, st, pipe_nc);
+    } else if (fused_acoustic_forward(h, st)) {
+        emb_head_forward(h, st, nullptr);
     } else {
         pred_forward(h, st);
         if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
+    }
+    if (std::getenv("PAULE_HIP_STOP_AFTER_FWD")) {   // diagnostic: leave the forward stashes as they are (tools/fused_check.py)
+        h->sweep_slot = -1;
+        return;
     }
     const int tube_nc = tube_pipeline_chunks(h);
     if (tube_nc) tube_forward_pipeline(h, st, tube_nc);
@@ -1237,6 +1528,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     launch_loss_finalize(st, la);
     if (pipe_nc) {
         acoustic_backward_pipeline(h, st, pipe_nc, la);
+    } else if (with_sem && fused_acoustic_backward(h, st, la)) {
     } else {
         const float* dmel_e = nullptr;
         if (with_sem) {
@@ -1267,6 +1559,13 @@ int check_launch() {
 static const bool g_dbg_graph = std::getenv("PAULE_HIP_DEBUG_GRAPH") != nullptr;
 #define DBG_G(msg) do { if (g_dbg_graph) { fprintf(stderr, "[pl] %s\n", msg); fflush(stderr); } } while (0)
 void drop_graph(pl_handle* h) {
+    if (!h->graph_exec && !h->graph) return;
+    // pl_step is asynchronous: a launch of this exec may still be in flight.  Nothing of it may be retired under a running
+    // launch -- and the branches of a wavefront graph run on streams of the runtime's own, so for those the whole device is
+    // drained, not just the handle's stream (PAULE_HIP_DESTROY_BRANCHED=2: destroy them after that; see below)
+    DeviceGuard guard(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    if (!h->wf_regions.empty()) (void)hipDeviceSynchronize();
     DBG_G("drop: exec destroy");
     // A graph exec with parallel branches (layer wavefront) is NOT destroyed: after hipGraphExecDestroy of such execs, the first
     // hipGraphLaunch of a later branched exec crashed inside the runtime about once in a hundred handles (ROCm 7.2;
@@ -1628,7 +1927,9 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->flag_stride = (pmax + 15) / 16 * 16;
         const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
-        h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers);   // forward + backward sweep of every layer of an iteration
+        // forward + backward sweep of every layer of an iteration, + the head / projection roles of the fused launches
+        h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers) +
+                           2 * (cfg->emb_layers > 0 ? 3 + 2 * (cfg->emb_layers - 1) : 0);
         if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
 #ifdef PL_STAMPS
@@ -1636,6 +1937,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
 #endif
     }
     if ((rc = dev_alloc(h, &h->past, B * T * h->C))) return bail(rc);
+    if ((rc = plan_fused(h))) return bail(rc);
+    if ((rc = build_fused_roles(h))) return bail(rc);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { bail(PL_ERR_HIP); return fail(PL_ERR_HIP, std::string("pl_create: ") + hipGetErrorString(e)); }
     *out = h;
@@ -1861,6 +2164,19 @@ int pl_get_pred(pl_handle* h, float* pred_mel_out, float* pred_semvec_out) {
         emb_forward(h, st, nullptr, h->mel_bm);
         launch_unpad_rows(st, h->sem, h->B, h->S, h->Sp, pred_semvec_out);
     }
+    return check_launch();
+}
+
+// the predictive model WITHOUT the half sequence: post_linear(lstm(cp)) for every frame, [B, n_frames, mel_dim]
+// (ForwardModel(apply_half_sequence=False).forward, paule/models.py:348-356; how the reference builds cp_tube_model, paule/paule.py:232-237)
+int pl_get_pred_frames(pl_handle* h, float* frames_out) {
+    if (!h || !frames_out) return fail(PL_ERR_INVALID, "pl_get_pred_frames: NULL argument");
+    int rc = check_ready(h, false, "pl_get_pred_frames");
+    if (rc) return rc;
+    DeviceGuard guard(h->cfg.device);
+    SweepChain chain(h->cfg.device, h->stream);
+    pred_forward(h, h->stream);
+    launch_tm_to_bm(h->stream, h->Y, h->B, h->T, h->M, h->Bp, h->Mp, frames_out);
     return check_launch();
 }
 

@@ -129,6 +129,20 @@ __device__ __forceinline__ void publish(int* flag, bool same_xcd) {
     }
 }
 
+// backward of one LSTM cell (backward-data): dA of the four gates and the running dL/dc handed to step t - 1.  The roundings
+// are spelled out (which product the compiler fuses differs from kernel to kernel; lstm_persist_rs.hip and lstm_fused.hip are
+// compared bit for bit).
+__device__ __forceinline__ void cell_bwd(float dh, float dc_in, float gi, float gf, float gg, float go, float c, float cp,
+                                         float& dai, float& daf, float& dag, float& dao, float& dc_out) {
+    const float tc = tanh_fast(c);
+    const float dc = __builtin_fmaf(dh * go, __builtin_fmaf(-tc, tc, 1.f), dc_in);
+    dai = dc * gg * gi * (1.f - gi);
+    daf = dc * cp * gf * (1.f - gf);
+    dag = dc * gi * __builtin_fmaf(-gg, gg, 1.f);
+    dao = dh * tc * go * (1.f - go);
+    dc_out = dc * gf;
+}
+
 #ifdef PL_STAMPS
 #define PL_ST(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
 #define PL_ST_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();

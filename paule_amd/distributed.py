@@ -39,10 +39,14 @@ def plan_sharded(make_planner, cp0, target_mel, target_semvec, n_iters: int):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = cp0.shape[0]
+    if n < world:   # a rank without utterances could not build a planner while the others wait in the gather: refuse on EVERY rank
+        raise ValueError(f"plan_sharded: {n} utterances cannot be sharded over {world} ranks (need at least one per rank)")
     lo, hi = shard_bounds(n, rank, world)
     planner = make_planner(batch=hi - lo)
     planner.set_targets(target_mel[lo:hi], None if target_semvec is None else target_semvec[lo:hi])
     planner.set_cp(cp0[lo:hi])
     loss = planner.step(n_iters)
+    if hasattr(planner, "check"):
+        planner.check()   # a timed-out device-side wait must not be gathered as if it were a plan
     cp = planner.get_cp()
     return gather_final_cp(cp if isinstance(cp, torch.Tensor) else torch.as_tensor(cp), n), loss

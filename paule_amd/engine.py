@@ -459,6 +459,10 @@ class HipPlanner:
             return loss, grad
         return loss
 
+    def check(self):
+        """Raises if a device-side bounded wait of a persistent sweep timed out (the results would be garbage); synchronises."""
+        self.synchronize()
+
     def get_cp(self):
         out = torch.empty((self.B, self.T, self.C), dtype=torch.float32, device=self.device)
         self._call(self.lib.pl_get_cp, out.data_ptr())
@@ -471,6 +475,13 @@ class HipPlanner:
         sem = torch.empty((self.B, self.S), dtype=torch.float32, device=self.device) if with_semvec else None
         self._call(self.lib.pl_get_pred, mel.data_ptr(), sem.data_ptr() if sem is not None else None)
         return mel, sem
+
+    def get_pred_frames(self):
+        """post_linear(lstm(cp)) of every frame, (B, T, mel_dim): the predictive model without the half sequence
+        (``ForwardModel(apply_half_sequence=False)``, paule/models.py:348-356)."""
+        y = torch.empty((self.B, self.T, self.M), dtype=torch.float32, device=self.device)
+        self._call(self.lib.pl_get_pred_frames, y.data_ptr())
+        return y
 
     def embed_mel(self, mel, lens=None):
         m = self._dev(mel, (self.B, self.Tp, self.M))

@@ -61,9 +61,7 @@ class ForwardModel(_HipModule):
     def __init__(self, input_size=30, output_size=60, hidden_size=180, num_lstm_layers=4,
                  apply_half_sequence=True):
         super().__init__()
-        if not apply_half_sequence:
-            raise NotImplementedError("apply_half_sequence=False is not used on the planning path")
-        self.apply_half_sequence = apply_half_sequence
+        self.apply_half_sequence = apply_half_sequence   # False: every frame's output (how Paule builds cp_tube_model, paule/paule.py:232-237)
         self.lstm = torch.nn.LSTM(input_size, hidden_size, num_layers=num_lstm_layers, batch_first=True)
         self.post_linear = torch.nn.Linear(hidden_size, output_size)
 
@@ -77,6 +75,8 @@ class ForwardModel(_HipModule):
         eng = self._engine(key, lambda: HipPlanner(self.state_dict(), None, batch=B, n_frames=T,
                                                    dtype=self.compute_dtype, device=x.device))
         eng.set_cp(x)
+        if not self.apply_half_sequence:
+            return eng.get_pred_frames().to(x.dtype)
         mel, _ = eng.get_pred(with_semvec=False)
         return mel.to(x.dtype)
 

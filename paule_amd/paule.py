@@ -223,6 +223,43 @@ class Paule():
         self.best_synthesis_acoustic = None
         self.best_synthesis_semantic = None
         self.planner = None
+        self._planners = {}   # handles of earlier plan_resynth calls, reused when batch, length, objective, dtype, lr and models agree
+
+    def _get_planner(self, inv_sd=None, **kw):
+        """The engine handle for this plan: a new one, or the one an earlier call with the same shape built (the reference's
+        notebook plans utterance after utterance, paule/gradient_planning.ipynb cell 28: a handle per call would allocate, capture
+        and retire one each time).  A reused handle gets the models' CURRENT weights (continued learning changes them between calls)
+        and a clean slate for everything a call sets."""
+        tube = kw.get("tube_models")
+        key = (kw["batch"], kw["n_frames"], kw["objective"], kw["dtype"], float(kw["lr"]), bool(kw["smiling"]), str(kw["device"]),
+               id(self.pred_model), id(self.embedder), inv_sd is not None, None if tube is None else tuple(id(m) for m in tube))
+        planner = self._planners.get(key)
+        if planner is not None and hasattr(planner, "set_weights"):
+            planner.set_weights(pred_model=self.pred_model, embedder=self.embedder)
+            if tube is not None and hasattr(planner, "set_tube_weights"):
+                planner.set_tube_weights(*tube)
+            if inv_sd is not None and hasattr(planner, "set_inverse_weights"):
+                planner.set_inverse_weights(inv_sd)
+            planner.set_past_cp(None)
+            if hasattr(planner, "set_speech_classifier"):
+                planner.set_speech_classifier(None)
+            return planner
+        planner = self._planner_factory(self.pred_model, self.embedder, **kw, **({"inv_model": inv_sd} if inv_sd is not None else {}))
+        if hasattr(planner, "set_weights"):
+            if len(self._planners) >= 8:   # a few shapes stay resident (each holds its activations: 1.9 GB at B = 256 x 300); oldest out
+                old = self._planners.pop(next(iter(self._planners)))
+                if hasattr(old, "close"):
+                    old.close()
+            self._planners[key] = planner
+        return planner
+
+    def release_planners(self):
+        """Frees the cached engine handles (device memory)."""
+        for pl_ in self._planners.values():
+            if hasattr(pl_, "close"):
+                pl_.close()
+        self._planners = {}
+        self.planner = None
 
     def plan_iterative(self, *, target_acoustic=None, target_semvecs=None, target_seq_lengths=None, overlap=8, **kwargs):
         pass   # a stub in the reference too (paule/paule.py:383-388)
@@ -522,9 +559,9 @@ class Paule():
                     # the inverse model runs on the device, inside the planner's handle (pl_inverse_forward): the planner is
                     # built first; its length is known: past_cp + 2 x target mel frames (paule/paule.py:553, :582-583)
                     n_past = 0 if past_cp is None else np.asarray(_np(past_cp)).shape[0]
-                    planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=n_past + 2 * target_mel.shape[1],
-                                                    objective=objective, dtype=self.compute_dtype, lr=learning_rate_planning,
-                                                    smiling=self.smiling, device=self.device, inv_model=inv_sd, **tube_kw)
+                    planner = self._get_planner(inv_sd=inv_sd, batch=B, n_frames=n_past + 2 * target_mel.shape[1],
+                                                objective=objective, dtype=self.compute_dtype, lr=learning_rate_planning,
+                                                smiling=self.smiling, device=self.device, **tube_kw)
                     initial_cp = _np(planner.inverse_forward(target_mel, clip=True))
                 else:
                     with torch.no_grad():
@@ -572,9 +609,8 @@ class Paule():
 
         # ---- engine ----
         if planner is None:
-            planner = self._planner_factory(self.pred_model, self.embedder, batch=B, n_frames=T, objective=objective,
-                                            dtype=self.compute_dtype, lr=learning_rate_planning, smiling=self.smiling,
-                                            device=self.device, **tube_kw)
+            planner = self._get_planner(batch=B, n_frames=T, objective=objective, dtype=self.compute_dtype, lr=learning_rate_planning,
+                                        smiling=self.smiling, device=self.device, **tube_kw)
         self.planner = planner
         if continue_learning and hasattr(planner, "set_pred_optimizer_state"):   # the optimiser outlives a plan (paule/paule.py:284-287)
             planner.set_pred_optimizer_state(self.pred_optimizer.state_dict())
@@ -813,6 +849,8 @@ class Paule():
             print("--- %.2f min ---" % ((time.time() - start_time) / 60))
 
         # ---- results (paule/paule.py:1456-1550): CP AFTER the last step, predictions recomputed from it ----
+        if hasattr(planner, "check"):
+            planner.check()   # a device-side wait that timed out must surface here, not as a plan of garbage
         planned_cp = _np(planner.get_cp())
         pm, ps = planner.get_pred()
         pred_mel, pred_semvec = _np(pm), _np(ps)

@@ -313,6 +313,64 @@ def test_full_size_properties_bf16(HipPlanner, monkeypatch):
     eng.synchronize()
 
 
+# ---- fused acoustic launches (lstm_fused.hip): one persistent launch per direction, roles by workgroup ---------------------
+FWD_BUFFERS = ["pred.h0", "pred.c0", "pred.G0", "mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0", "emb.h1", "emb.c1", "emb.G1"]
+
+
+def _fused_pair(HipPlanner, monkeypatch, wl, B, T, modes, iters, use_graph, extra_env=None):
+    """The same plan on the per-layer path (PAULE_HIP_FUSED=0) and with the fused launches; returns {mode: engine}."""
+    out = {}
+    for mode in modes:
+        monkeypatch.setenv("PAULE_HIP_FUSED", mode)
+        monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
+        for k, v in (extra_env or {}).items():
+            monkeypatch.setenv(k, v)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=use_graph)
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        eng.losses = _n(eng.step(iters))
+        eng.synchronize()
+        out[mode] = eng
+    return out
+
+
+@pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720, graph=True), dict(B=144, T=61, H=720, graph=False),
+                                   dict(B=40, T=50, H=64, graph=False), dict(B=33, T=31, H=64, graph=True, chains=dict(PAULE_HIP_FUSED_CP="1", PAULE_HIP_FUSED_CE="2"))])
+def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
+    """The fused forward launch (predictor recurrence, mel head + pooling, embedder layer 1, layer-2 projection, layer 2 as
+    roles of one grid, several batch groups per workgroup) computes what the per-layer sweeps and GEMMs compute, bit for bit:
+    every forward stash, the pooled mel, and with them the losses and the CP trajectory.  Ragged batches (a last group of 16
+    rows, fewer groups than chains), odd T, a one-group-per-workgroup table."""
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, shape.get("chains"))
+    for name in FWD_BUFFERS:
+        np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
+    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 4, shape["graph"], shape.get("chains"))
+    np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
+    np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
+    assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
+
+
+@pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720), dict(B=48, T=41, H=64)])
+def test_fused_backward_matches_per_layer_path(HipPlanner, monkeypatch, shape):
+    """The fused backward launch (PAULE_HIP_FUSED=3: embedder recurrences, their dL/dh product and the backward mel head in
+    reduce-scatter form, the predictor's recurrence) against the per-layer path.  The embedder's top layer is the same
+    arithmetic (its dA stash is bit-identical); below it dL/dh crosses the exchange as 23 bf16 partial tiles instead of one f32
+    sum rounded once, so the model gradient agrees to bf16 noise: cosine >= 0.99999, and the plans stay together."""
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "3"), 1, False)
+    np.testing.assert_array_equal(_n(e["3"].debug_read("emb.G1")), _n(e["0"].debug_read("emb.G1")))
+    assert _cos(e["3"].debug_read("dX"), e["0"].debug_read("dX")) >= 0.99999
+    assert _cos(e["3"].debug_read("emb.G0"), e["0"].debug_read("emb.G0")) >= 0.9999
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "3"), 6, True)
+    np.testing.assert_allclose(e["3"].losses, e["0"].losses, rtol=1e-4, atol=1e-6)
+    assert np.abs(_n(e["3"].get_cp()) - _n(e["0"].get_cp())).max() <= 2e-4   # lr = 0.01: 2 % of one step
+
+
 # ---- continued learning of the predictive model (SURVEY 8f rank 2; paule/paule.py:1353-1379) --------------------------
 def _unpad_grad(flat, nblk, R, C, Rp, Cp):
     a = _n(flat).reshape(nblk, Rp, Cp)[:, :R, :C]
@@ -1227,3 +1285,22 @@ def test_random_shapes_f32_vs_oracle(HipPlanner):
         eng.close()
 
     check()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 started without a launcher: it spawns its two ranks itself; here they share the one GPU of the box (gloo
+    collectives on host copies; the RCCL path needs a GPU per rank), plan the small `rehearsal` workload and rank 0 prints the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "rehearsal", "--dist-backend", "gloo",
+                        "--device-index", "0", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["finite"] and out["scaling"] == "weak" and out["final_cp_all_gather_ms"] > 0
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]

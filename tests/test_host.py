@@ -408,3 +408,22 @@ def test_sharded_planning_world2_gloo(tmp_path):
     eng.set_cp(wl.cp0)
     eng.step(4)
     np.testing.assert_allclose(cp_all.numpy(), eng.get_cp().numpy(), atol=1e-13)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside a torch.distributed launcher starts N ranks itself (child processes), they meet, take the
+    max over ranks of the timed region, gather CP-shaped tensors and rank 0 prints ONE JSON line.  Here without an engine
+    (--plumbing-only: no GPU in this container); tests/test_hip_parity.py::test_bench_two_ranks_on_one_gpu runs the real thing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "rehearsal", "--plumbing-only", "--steps", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["plumbing_only"] and out["n_gpus"] == 2 and out["gathered_rows"] == 16 and out["gathered_ranks_ok"]
+    assert out["ms_per_step"] >= 0.02 * 1e3 / 2   # the slowest rank's time, not rank 0's
