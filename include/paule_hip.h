@@ -151,7 +151,16 @@ int pl_reset_optimizer(pl_handle *h);
 int pl_step(pl_handle *h, int n_iters, float *loss_log, float *grad_out);
 
 /* Waits for everything enqueued on the handle's stream and reports device-side failures that cannot be returned
- * asynchronously (a bounded in-kernel wait of a persistent LSTM sweep timed out -> PL_ERR_HIP). */
+ * asynchronously (a bounded in-kernel wait of a persistent LSTM sweep timed out -> PL_ERR_HIP).
+ *
+ * ONE PROCESS PER GPU.  The LSTM sweeps are persistent launches whose workgroups wait for each other inside the launch
+ * (one workgroup per CU; the fused acoustic launches take up to all 256 CUs).  They finish only when all their workgroups
+ * are resident at the same time.  Handles of ONE process are safe: every entry point that launches sweeps chains behind the
+ * previous one on the same device, whatever stream it runs on.  A SECOND process on the same GPU can hold CUs a launch is
+ * waiting for: both then run into the bounded wait (PAULE_HIP_SPIN_MS, default 2 s) and this call returns PL_ERR_HIP -- the
+ * plan of that pl_step is not valid, call pl_set_cp / pl_reset_optimizer and step again once the GPU is yours.  Host code
+ * must call this (or pl_get_cp, which a caller follows with it) before it trusts results: the Python layers do
+ * (Paule.plan_resynth, plan_sharded). */
 int pl_synchronize(pl_handle *h);
 
 int pl_get_cp(pl_handle *h, float *cp_out);

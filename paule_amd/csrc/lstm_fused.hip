@@ -207,7 +207,8 @@ struct LstmFwdLds {
     static constexpr int O_HIMG = 0;
     static constexpr int O_HST = O_HIMG + 32 * RS;
     static constexpr int O_XIMG = O_HST + 6 * 32 * HRS;
-    static constexpr int O_CST = O_XIMG + (KSX ? 32 * XRS : 16);
+    static constexpr int GRS = 4 * 64 + 16;       // KSX = 0: the workgroup's projection rows [32 rows][4 gates x 32 units] bf16
+    static constexpr int O_CST = O_XIMG + (KSX ? 32 * XRS : 32 * GRS);
     static constexpr int O_FLAG = O_CST + kFusedMaxChains * 256 * 16;
     static constexpr int BYTES = O_FLAG + 64;
 };
@@ -268,6 +269,7 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
     uint4 hv[NL];
     uint4 xv = make_uint4(0, 0, 0, 0);
     uint2 gxn[4] = {};
+    uint4 gv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};   // KSX = 0, rows from a role of this launch: 16-byte pieces, through LDS
     auto issue_loads = [&](int g2, int t2) {
         // the small x / projection rows first: vmcnt retires in order, and the cell update waits for them, not for the h tile
         if constexpr (KSX > 0) {
@@ -287,9 +289,15 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
             int b2 = 32 * g2 + bl;
             b2 = b2 < Bp ? b2 : Bp - 1;
             if (src_sc1) {
+                // the slice's 32 rows x 4 gates x 64 bytes as 512 pieces of 16 bytes (4 lanes per 64-byte run): read lane by lane as
+                // 8-byte cells they were 32 separate segments per wave instruction and cost as much memory-pipe time as the h tile
                 const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t2 * slabG, (unsigned)(slabG * 2));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gxn[q] = ld8_sc1(rg, (unsigned)(((size_t)b2 * G4 + q * Hp + j) * 2));
+                for (int q = 0; q < 2; ++q) {
+                    const int e = tid + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                    const int rb = 32 * g2 + row;
+                    gv[q] = ld16_sc1(rg, rb < Bp ? (unsigned)(((size_t)rb * G4 + gate * Hp + 32 * p + 8 * q4) * 2) : kOob);
+                }
             } else {
                 const bf16_t* g_row = G + (size_t)t2 * slabG + (size_t)b2 * G4 + j;
 #pragma unroll
@@ -325,9 +333,18 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
         const bool ok = b < Bp;
 
         // A. the prefetched operands of this chain-step -> LDS (the loads were issued one chain-step ago)
-        uint2 gx[4];
+        // the projection rows of this chain-step, widened NOW: the registers they arrived in are free for the next prefetch, and the
+        // cell update below does not have to wait for those loads (it did when it unpacked them after the prefetch issue)
+        float gxi[4], gxf[4], gxg[4], gxo[4];
+        if constexpr (KSX == 0) {
+            if (src_sc1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gx[q] = gxn[q];
+                for (int q = 0; q < 2; ++q) {
+                    const int e = tid + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                    *reinterpret_cast<uint4*>(ximg + row * L::GRS + gate * 64 + q4 * 16) = gv[q];
+                }
+            }
+        }
         if (t > 0) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
@@ -339,6 +356,21 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
             if (wave < XC / 2) *reinterpret_cast<uint4*>(ximg + (tid / XC) * XRS + (tid % XC) * 16) = xv;
         }
         __syncthreads();
+        if constexpr (KSX == 0) {
+            if (src_sc1) {
+                const unsigned char* gsrc = ximg + bl * L::GRS + (8 * wave + 4 * hh) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const uint2*>(gsrc + q * 64);
+            }
+        }
+        unpack_bf16x4(gxn[0], gxi);
+        unpack_bf16x4(gxn[1], gxf);
+        unpack_bf16x4(gxn[2], gxg);
+        unpack_bf16x4(gxn[3], gxo);
+        if constexpr (KSX == 0) {   // pin the widened values before the prefetch below reuses registers
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(gxi[u]), "+v"(gxf[u]), "+v"(gxg[u]), "+v"(gxo[u]));
+        }
         PL_ST(0);   // operands landed + LDS image
 
         // B. first look at the next chain-step's flags, answered while the MFMAs run
@@ -394,11 +426,6 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
         PL_ST(2);   // flag answer + prefetch issue
 
         // F. cell update: acc[4 * gate + unit]
-        float gxi[4], gxf[4], gxg[4], gxo[4];
-        unpack_bf16x4(gx[0], gxi);
-        unpack_bf16x4(gx[1], gxf);
-        unpack_bf16x4(gx[2], gxg);
-        unpack_bf16x4(gx[3], gxo);
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t > 0) cs = cst[c * 256 + tid];
         float c_state[4] = {cs.x, cs.y, cs.z, cs.w};
@@ -718,14 +745,11 @@ typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
 // one partial tile: 8 k-steps over the workgroup's 128 local gate rows; acc[r] = out[n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31]
 // -> bf16 image [batch][n], read back by rows by the same wave (a wave's LDS operations are ordered) and stored as 2 KB
-__device__ __forceinline__ void partial_tile(const uint4 (&w)[8], const unsigned char* bsrc, unsigned char* img_row0, int rs, int col0,
+__device__ __forceinline__ void partial_tile(const uint4 (&w)[8], const uint4 (&bfr)[8], unsigned char* img_row0, int rs, int col0,
                                              __amdgpu_buffer_rsrc_t ro, unsigned tile_off, int lane) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    uint4 bfr[8];   // B fragments of the dA image, read per tile (kept for all tiles they crowd the vector registers)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const uint4*>(bsrc + ks * 32);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks]), __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
@@ -868,11 +892,11 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
         // together and in order, so a poll issued behind hand-off stores would only be answered after their write-through round trips
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
         if (has_next) pn = step_flags(a, WT_, gn, tn, p);
-        int pvl = 1;
-        if (wave == 0 && has_next) pvl = poll_load(pn, lane);
         // A. dL/dh_t of this thread's cells: from above + the partial sums (fixed order).  Every wave's DMA pieces have landed:
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        int pvl = 1;
+        if (wave == 0 && has_next) pvl = poll_load(pn, lane);   // behind the wait above: that one must not wait for this round trip
         float dh[4];
         unpack_bf16x4(sdh, dh);
         if (t + 1 < T) {
@@ -945,7 +969,9 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
         }
         __syncthreads();
         PL_ST(1);   // cell + stash stores + dA image
-        const unsigned char* bfr = da_img + (lane & 31) * DRS + (lane >> 5) * 16;
+        uint4 bfr[8];   // B fragments of the dA image, shared by all tiles of the wave
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const uint4*>(da_img + (lane & 31) * DRS + ks * 32 + (lane >> 5) * 16);
         // the next chain-step's operands start now (older than every hand-off store below: the drain before the flag covers them,
         // and by then the tiles' MFMAs have run beside their flight)
         const bool ready = has_next && lflag[0] != 0;
@@ -1062,7 +1088,9 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
         }
         __syncthreads();
         PL_ST(0);
-        const unsigned char* bfr = da_img + (lane & 31) * DRS + (lane >> 5) * 16;
+        uint4 bfr[8];   // B fragments of the dA image, shared by all tiles of the wave
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const uint4*>(da_img + (lane & 31) * DRS + ks * 32 + (lane >> 5) * 16);
         const bool ready = has_next && lflag[0] != 0;
         if (ready) issue_loads(gn, tn);
         bf16_t* xd = XE + (size_t)(t % kFusedRing) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;

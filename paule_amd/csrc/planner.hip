@@ -6,6 +6,10 @@
 // counters, so the captured graph is static.
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1550,6 +1554,18 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     h->sweep_slot = -1;
 }
 
+// PAULE_HIP_SEGV_TRACE=1 (diagnostic): print the native frames of a segmentation fault before dying -- the crash inside
+// hipGraphLaunch after branched graph execs were destroyed (drop_graph) leaves no other trace
+void segv_trace(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "[pl] SIGSEGV, native frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PL_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1733,6 +1749,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(PL_ERR_INVALID, "pl_create: no such HIP device");
     DeviceGuard guard(cfg->device);
 
+    if (std::getenv("PAULE_HIP_SEGV_TRACE")) signal(SIGSEGV, segv_trace);
     pl_handle* h = new pl_handle();
     h->cfg = *cfg;
     h->stream = static_cast<hipStream_t>(cfg->stream);

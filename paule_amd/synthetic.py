@@ -104,3 +104,39 @@ def make_workload(batch, n_frames, model_set="A", *, pred=None, emb=None, cp_dim
         # smooth start, like the inverse model's output clipped to [-1, 1] (paule/paule.py:555)
         cp0 = smooth_time(2.0 * torch.rand(batch, n_frames, cp_dim, dtype=dtype) - 1.0, 25)
     return Workload(pred_sd, emb_sd, target_mel, target_semvec, cp0, batch, n_frames)
+
+
+def make_models_frozen(model_set="A", *, cp_dim=30, mel_dim=60, sem_dim=300, dtype=torch.float64, seed=SEED):
+    """State dicts of (ForwardModel, EmbeddingModel) drawn from numpy's FROZEN legacy generator (``RandomState``: its stream is
+    guaranteed never to change), U(-1/sqrt(H), 1/sqrt(H)) like torch's default init, parameters in the reference's creation
+    order.  For fixtures that must reproduce their weights on any torch version (tests/golden/set_a_h720.npz)."""
+    import numpy as np
+    spec = MODEL_SETS[model_set]
+    rs = np.random.RandomState(seed)
+
+    def lstm_linear(in_size, hidden, layers, out_size, lin_name):
+        k = 1.0 / np.sqrt(hidden)
+        sd = {}
+        for l in range(layers):
+            i = in_size if l == 0 else hidden
+            for name, shape in ((f"lstm.weight_ih_l{l}", (4 * hidden, i)), (f"lstm.weight_hh_l{l}", (4 * hidden, hidden)),
+                                (f"lstm.bias_ih_l{l}", (4 * hidden,)), (f"lstm.bias_hh_l{l}", (4 * hidden,))):
+                sd[name] = torch.from_numpy(rs.uniform(-k, k, size=shape)).to(dtype)
+        sd[f"{lin_name}.weight"] = torch.from_numpy(rs.uniform(-k, k, size=(out_size, hidden))).to(dtype)
+        sd[f"{lin_name}.bias"] = torch.from_numpy(rs.uniform(-k, k, size=(out_size,))).to(dtype)
+        return sd
+
+    p, e = spec["pred"], spec["emb"]
+    return (lstm_linear(cp_dim, p["hidden_size"], p["num_lstm_layers"], mel_dim, "post_linear"),
+            lstm_linear(mel_dim, e["hidden_size"], e["num_lstm_layers"], sem_dim, "linear_mapping"))
+
+
+def make_inputs_frozen(batch, n_frames, *, cp_dim=30, mel_dim=60, sem_dim=300, dtype=torch.float64, seed=SEED + 1):
+    """(target_mel, target_semvec, cp0) from the frozen generator: smooth like make_workload's."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    tp = n_frames // 2
+    target_mel = smooth_time(torch.from_numpy(rs.uniform(0, 1, size=(batch, tp, mel_dim))).to(dtype), 5)
+    target_semvec = torch.from_numpy(0.1 * rs.standard_normal(size=(batch, sem_dim))).to(dtype)
+    cp0 = smooth_time(torch.from_numpy(rs.uniform(-1, 1, size=(batch, n_frames, cp_dim))).to(dtype), 25)
+    return target_mel, target_semvec, cp0

@@ -247,18 +247,23 @@ def main():
     np.savez_compressed(os.path.join(HERE, "small_stacked.npz"), **out)
     print("small_stacked.npz:", len(out), "arrays")
 
-    # ---- fixture 2: the Paule default models (set A, H = 720), weights regenerated from the seed --
+    # ---- fixture 2: the Paule default models (set A, H = 720).  8.8 M parameters are too many to store, so the test regenerates
+    # them: from numpy's FROZEN RandomState stream (synthetic.make_models_frozen), which no torch upgrade can change -- the fixture
+    # never has to be skipped.  (The reference's constructors under torch's seed give make_workload's weights: checked here too.)
     B, T = 2, 32
-    wl = synthetic.make_workload(B, T, "A")
+    wl_t = synthetic.make_workload(B, T, "A")
     pspec, espec = synthetic.MODEL_SETS["A"]["pred"], synthetic.MODEL_SETS["A"]["emb"]
-    # the reference's own constructors under the same seed must give the same weights (default torch init)
     torch.manual_seed(synthetic.SEED)
     pm_seed = ref_models.ForwardModel(**pspec).double()
     em_seed = ref_models.EmbeddingModel(**espec).double()
     for k, v in pm_seed.state_dict().items():
-        assert torch.equal(v, wl.pred_sd[k]), k
+        assert torch.equal(v, wl_t.pred_sd[k]), k
     for k, v in em_seed.state_dict().items():
-        assert torch.equal(v, wl.emb_sd[k]), k
+        assert torch.equal(v, wl_t.emb_sd[k]), k
+    pred_sd, emb_sd = synthetic.make_models_frozen("A")
+    assert set(pred_sd) == set(pm_seed.state_dict()) and set(emb_sd) == set(em_seed.state_dict())
+    tm, ts, c0 = synthetic.make_inputs_frozen(B, T)
+    wl = synthetic.Workload(pred_sd, emb_sd, tm, ts, c0, B, T)
     pm, em = build_ref_models(ref_models, pspec, espec, wl.pred_sd, wl.emb_sd)
     out = dict(B=B, T=T, seed=synthetic.SEED, target_mel=wl.target_mel.numpy(), target_semvec=wl.target_semvec.numpy(),
                cp0=wl.cp0.numpy())

@@ -108,15 +108,14 @@ def test_adam_clamp(golden_small):
 
 @pytest.mark.parametrize("name", ["acoustic", "acoustic_semvec"])
 def test_trajectories_set_a(golden_set_a, name):
-    """Paule's default architecture (H = 720); weights regenerated from the seed, guarded by a checksum."""
+    """Paule's default architecture (H = 720).  The 8.8 M weights are regenerated, from numpy's frozen RandomState stream
+    (synthetic.make_models_frozen): no torch upgrade changes them, so this test cannot be skipped; the checksum pins them."""
     g = golden_set_a
-    wl = synthetic.make_workload(int(g["B"]), int(g["T"]), "A")
-    chk = np.array([float(sum(v.double().abs().sum() for v in wl.pred_sd.values())),
-                    float(sum(v.double().abs().sum() for v in wl.emb_sd.values()))])
-    if not np.allclose(chk, g["weights_checksum"], rtol=1e-13):
-        pytest.skip("torch RNG stream differs from the one the fixture was generated with")
-    _close(wl.cp0, g["cp0"])
-    P = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+    pred_sd, emb_sd = synthetic.make_models_frozen("A")
+    chk = np.array([float(sum(v.double().abs().sum() for v in pred_sd.values())), float(sum(v.double().abs().sum() for v in emb_sd.values()))])
+    np.testing.assert_allclose(chk, g["weights_checksum"], rtol=1e-13)
+    _close(synthetic.make_inputs_frozen(int(g["B"]), int(g["T"]))[2], g["cp0"])
+    P = op.OraclePlanner(op.forward_model_from_state_dict(pred_sd), op.embedding_model_from_state_dict(emb_sd),
                          objective=name)
     P.set_targets(g["target_mel"], g["target_semvec"])
     P.set_cp(g["cp0"])
