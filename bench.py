@@ -332,6 +332,12 @@ def main():
         eng.synchronize()
         ms, fl = roof[names[0]]
         ms_f, fl_f = roof[names[1]]
+        fused = None   # the fused forward launch (all forward LSTM layers + the mel head as roles of one grid), when the handle runs it
+        try:
+            fused = eng.bench_kernel("fused_fwd", "pred", reps=5)
+            eng.synchronize()
+        except ValueError:
+            fused = None
         rs = os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1"   # reduce-scatter form is the library default
         if not swept:
             kname = "lstm_bwd_step_kernel"
@@ -388,7 +394,10 @@ def main():
                          "avg_launch_us": ms * 1e3, "flops_per_launch": fl,
                          "us_per_time_step": ms * 1e3 / (T - 1) if swept else ms * 1e3,
                          "fwd_kernel_avg_launch_us": ms_f * 1e3,
-                         "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12},
+                         "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12,
+                         "fused_fwd_kernel": None if fused is None else {
+                             "kernel": "fused_fwd_kernel", "avg_launch_us": fused[0] * 1e3, "flops_per_launch": fused[1],
+                             "achieved": fused[1] / (fused[0] * 1e-3) / 1e12, "frac": fused[1] / (fused[0] * 1e-3) / 1e12 / peak}},
         }
         if gather_ms is not None:
             out["final_cp_all_gather_ms"] = gather_ms

@@ -259,7 +259,11 @@ int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems,
  * and the algorithmic FLOPs of one launch (2 * B * 4H * H).  Clobbers only scratch that every pl_step rebuilds. */
 enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1,
        /* persistent sweeps: one launch = all T steps of layer 0 (+ its ~5 us counter-zeroing launch); FLOPs = 2*B*4H*H*(T-1) */
-       PL_KERNEL_LSTM_FWD_SWEEP = 2, PL_KERNEL_LSTM_BWD_SWEEP = 3 };
+       PL_KERNEL_LSTM_FWD_SWEEP = 2, PL_KERNEL_LSTM_BWD_SWEEP = 3,
+       /* the fused acoustic forward launch (predictor + mel head + embedder layers as roles of one grid; bf16, batches of 129+
+        * rows): one launch = all steps of all its layers (+ the flag-zeroing launch); FLOPs = 2 * B * sum over layers of
+        * 4H (in + H) T_layer + 2 * B * H * mel_dim * T; PL_ERR_UNSUPPORTED when the handle does not use it; model_id ignored */
+       PL_KERNEL_FUSED_FWD = 4 };
 int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg_ms_out /* host */,
                     double *flops_per_launch_out /* host */);
 

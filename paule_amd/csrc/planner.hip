@@ -2585,7 +2585,33 @@ int pl_inverse_forward(pl_handle* h, const float* mel, int n_mel_frames, float* 
 
 int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg_ms_out, double* flops_per_launch_out) {
     if (!h || !avg_ms_out || reps < 1) return fail(PL_ERR_INVALID, "pl_bench_kernel: bad argument");
-    if (kernel < PL_KERNEL_LSTM_FWD_STEP || kernel > PL_KERNEL_LSTM_BWD_SWEEP) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
+    if (kernel < PL_KERNEL_LSTM_FWD_STEP || kernel > PL_KERNEL_FUSED_FWD) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
+    if (kernel == PL_KERNEL_FUSED_FWD) {
+        if (!h->fused_fwd_ok || !h->pred.ready() || !h->emb.ready())
+            return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: this handle does not run the fused forward launch");
+        DeviceGuard guard(h->cfg.device);
+        SweepChain chain(h->cfg.device, h->stream);
+        hipEvent_t e0, e1;
+        PL_HIP(hipEventCreate(&e0));
+        PL_HIP(hipEventCreate(&e1));
+        PL_HIP(hipEventRecord(e0, h->stream));
+        for (int i = 0; i < reps; ++i) {
+            zero_all_sweep_slots(h, h->stream);
+            (void)fused_acoustic_forward(h, h->stream);
+            h->sweep_slot = -1;
+        }
+        PL_HIP(hipEventRecord(e1, h->stream));
+        PL_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms_out = ms / reps;
+        if (flops_per_launch_out)
+            *flops_per_launch_out = (double)h->B * ((lstm_flops_per_step(h->pred.L, h->pred.H, h->C) + 2.0 * h->pred.H * h->M) * h->T +
+                                                    lstm_flops_per_step(h->emb.L, h->emb.H, h->M) * h->Tp);
+        return check_launch();
+    }
     Model& md = model_id == PL_MODEL_EMBED ? h->emb : h->pred;
     if (md.L == 0 || !md.ready()) return fail(PL_ERR_STATE, "pl_bench_kernel: model weights are not set");
     DeviceGuard guard(h->cfg.device);

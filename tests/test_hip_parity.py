@@ -14,6 +14,7 @@ from oracle import planner as op
 from paule_amd import synthetic
 
 pytestmark = pytest.mark.gpu
+_ORACLE_CACHE = {}
 
 CP_ATOL_F32, LOSS_RTOL_F32, FWD_ATOL_F32 = 1e-5, 1e-5, 2e-5
 LOSS_RTOL_BF16, COS_BF16 = 2e-2, 0.999
@@ -772,15 +773,19 @@ def test_long_sequences_set_a_vs_oracle(HipPlanner, dtype):
     compared with the reference arithmetic, not only checked for its properties.  f32: the f32 bars; bf16: the bf16 bars."""
     B, T = 2, 2000
     wl = synthetic.make_workload(B, T, "A")
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
-                           objective="acoustic_semvec")
+    if "long_set_a" not in _ORACLE_CACHE:   # the float64 oracle takes its seconds once for both dtypes
+        orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                               objective="acoustic_semvec")
+        orc.set_targets(wl.target_mel, wl.target_semvec)
+        orc.set_cp(wl.cp0)
+        _ORACLE_CACHE["long_set_a"] = (_n(orc.step(2)), _n(orc.get_cp()))
+    lo, cpo = _ORACLE_CACHE["long_set_a"]
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype=dtype)
-    for pl in (orc, eng):
-        pl.set_targets(wl.target_mel, wl.target_semvec)
-        pl.set_cp(wl.cp0)
-    lo, lh = _n(orc.step(2)), _n(eng.step(2))
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    lh = _n(eng.step(2))
     eng.synchronize()
-    dcp = np.abs(_n(eng.get_cp()) - _n(orc.get_cp()))
+    dcp = np.abs(_n(eng.get_cp()) - cpo)
     if dtype == "f32":
         np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
         assert dcp.max() <= CP_ATOL_F32
