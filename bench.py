@@ -33,6 +33,11 @@ CONFIGS = {
     "cfg3_setC": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="C"),   # older embedder (8f rank 4)
     "cfg3_soma": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A", tube=True),   # + somatosensory path
     "cfg5": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+    # cfg5's whole batch (128 utterances) on ONE GPU: a 2000-step sweep costs about the same for 128 rows as for 16 (step latency),
+    # so sharding cfg5 over 8 GPUs buys little over this (Measured)
+    "cfg5_128": dict(batch=128, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="A"),
+    "cfg2_setB": dict(batch=64, frames=300, objective="acoustic", dtype="f32", model_set="B"),
+    "cfg5_setB": dict(batch=16, frames=2000, objective="acoustic_semvec", dtype="bf16", model_set="B"),
     # small enough for several ranks to share ONE GPU (two persistent sweeps side by side need all their workgroups resident):
     # used with --dist-backend gloo --device-index 0 to rehearse the multi-rank path on a one-GPU box
     "rehearsal": dict(batch=8, frames=60, objective="acoustic_semvec", dtype="bf16", model_set="A"),

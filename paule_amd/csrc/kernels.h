@@ -111,6 +111,7 @@ struct FusedRole {
     int C;                 // chains (batch groups of 32 rows) per workgroup; set s serves groups s * C .. s * C + C - 1
     int T;                 // time steps of the role
     int* flags;            // the role's own arrival flags [groups][T][flag_stride] (zeroed before the launch)
+    int* flags2;           // FR_DX_BWD: second set, raised when the role's REDUCED dL/dh rows of a step are in place
     FusedWait wait[3];     // [0]: <= 32 flags, [1]: <= 31 flags, [2]: one flag
     int src_sc1;           // LSTM roles: x / G / dh_ext rows are produced by a role of this launch: load them write-through (sc1)
     // LSTM roles
@@ -147,6 +148,9 @@ struct FusedArgs {
     unsigned long long spin_ticks;
     unsigned poll_mask;
     const short* block_tab;   // [grid][4]: role, set, slice p, unused  (role < 0: the block leaves at once)
+    int* census;              // residency check: every role-bearing workgroup signs in here first (zeroed with the flags) ...
+    int n_active;             // ... and waits, briefly, until all n_active have: a launch that is not wholly resident (another process
+    unsigned long long census_ticks;   // holds CUs) sets status 2 and leaves within census_ticks instead of spinning for seconds in its waits
     unsigned long long* stamps;
     const FusedRole* roles;   // [n_roles] in device memory (a table in the kernel arguments would have to be indexed dynamically,
                               // which makes the compiler copy it to scratch)

@@ -131,6 +131,33 @@ __device__ __forceinline__ void raise_flag(int* flag) {
     }
 }
 
+// Residency census at the top of a fused launch: the roles wait for each other inside the launch, so all role-bearing workgroups
+// have to be resident together.  Every one signs in and waits for the others with a SHORT bound; if they do not all show up
+// (a second process on the GPU holds CUs: the launches of one process are chained) the launch gives up at once with status 2.
+__device__ __forceinline__ bool census_ok(const FusedArgs& a, int* lds_word) {
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        const int lane = threadIdx.x;
+        int ok = 1;
+        if (lane == 0) __hip_atomic_fetch_add((PL_GLOBAL int*)a.census, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 1;; ++spin) {
+            const int v = flag_load(a.census);
+            if (v >= a.n_active) break;
+            if ((spin & 15u) == 0 && (flag_load(a.status) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > a.census_ticks)) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (lane == 0) {
+            if (!ok && flag_load(a.status) == 0) flag_store(a.status, 2);
+            *lds_word = ok;
+        }
+    }
+    __syncthreads();
+    return *lds_word != 0;
+}
+
 // The role descriptors live in device memory and are read with vector loads, so the compiler takes every value in them for
 // divergent: buffer descriptors built from such pointers get a waterfall loop per access, and loop bounds land in VGPRs.
 // One readfirstlane per field, once per role, puts them where kernel arguments would be: in SGPRs.
@@ -146,7 +173,7 @@ __device__ __forceinline__ FusedWait uni(const FusedWait& w) {
 }
 __device__ __forceinline__ FusedRole uniform_role(const FusedRole& g) {
     FusedRole r;
-    r.type = uni(g.type); r.ksx = uni(g.ksx); r.C = uni(g.C); r.T = uni(g.T); r.flags = uni(g.flags);
+    r.type = uni(g.type); r.ksx = uni(g.ksx); r.C = uni(g.C); r.T = uni(g.T); r.flags = uni(g.flags); r.flags2 = uni(g.flags2);
     r.wait[0] = uni(g.wait[0]); r.wait[1] = uni(g.wait[1]); r.wait[2] = uni(g.wait[2]);
     r.src_sc1 = uni(g.src_sc1);
     r.G = uni(g.G); r.W = uni(g.W); r.h = uni(g.h); r.c = uni(g.c); r.x_in = uni(g.x_in); r.Wih = uni(g.Wih); r.bias = uni(g.bias);
@@ -1050,6 +1077,42 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
     bf16_t* __restrict__ XE = static_cast<bf16_t*>(R.xchg_ext);
     const size_t grp_stride = (size_t)P * P * TILE, slot_stride = (size_t)a.n_groups * grp_stride;
 
+    // phase 2 of a chain-step, one chain-step later: once all P workgroups of the set have handed over their partial tiles of
+    // (group, step), this one sums the P tiles of ITS 32 hidden units and writes the rows of dL/dh the layer below reads -- the
+    // layer below then takes 2 KB per step from here instead of 46 KB of partial tiles (it is the role with the most to move)
+    unsigned char* xr_img = lds + L::O_XR;
+    const unsigned xr_lds = (unsigned)(uintptr_t)(lds_ptr_t)xr_img;
+    int* const rflags2 = R.flags2;
+    bf16_t* __restrict__ Dred = static_cast<bf16_t*>(R.out);   // [T][Bp][Hp]
+    const size_t slabH = (size_t)Bp * Hp;
+    auto reduce = [&](int g2, int t2) -> bool {
+        const FlagPoll peers{rflags + ((size_t)g2 * T + t2) * a.flag_stride, P, nullptr, 0, nullptr};
+        if (!flags_wait(peers, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return false;
+        constexpr int NPC = P * 2;
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(XE + (size_t)(t2 % kFusedRing) * slot_stride + (size_t)g2 * grp_stride + (size_t)p * P * TILE);
+#pragma unroll
+        for (int k = 0; k < (NPC + 3) / 4; ++k) {
+            const int pc = wave + 4 * k;
+            if (pc < NPC) glds16_sc1(uni(xs + pc * 1024), (unsigned)(lane * 16), (unsigned)uni((int)(xr_lds + (unsigned)(pc * 1024))));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int erow = tid >> 3, jq = tid & 7;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned char* src = xr_img + erow * 64 + jq * 8;
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            float f[4];
+            unpack_bf16x4(*reinterpret_cast<const uint2*>(src + s * 2048), f);
+            s4[0] += f[0]; s4[1] += f[1]; s4[2] += f[2]; s4[3] += f[3];
+        }
+        const int rb = 32 * g2 + erow;
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(Dred + (size_t)t2 * slabH, (unsigned)(slabH * 2));
+        st8_sc1(rd, rb < Bp ? (unsigned)(((size_t)rb * Hp + 32 * p + 4 * jq) * 2) : kOob, pack_bf16x4(s4[0], s4[1], s4[2], s4[3]));
+        raise_flag<0>(rflags2 + ((size_t)g2 * T + t2) * a.flag_stride + p);
+        return true;
+    };
+
     uint4 dv[2];   // the partner's dA slice of the next chain-step: 32 rows x 4 gates x 64 bytes = 512 pieces
     auto issue_loads = [&](int g2, int t2) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t2 * slabG, (unsigned)(slabG * 2));
@@ -1061,7 +1124,7 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
         }
     };
     PL_ST_DECL
-    int c = 0, t = T - 1;
+    int c = 0, t = T - 1, pg = -1, pt = -1;
     {
         const FlagPoll s0 = step_flags(a, WT_, set * RC, t, p);
         if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
@@ -1103,6 +1166,10 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
         PL_ST(2);
         raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
         PL_ST(3);
+        if (pg >= 0 && !reduce(pg, pt)) return;
+        pg = g;
+        pt = t;
+        PL_ST(4);   // reduction of the chain-step before
         if (!has_next) break;
         if (!ready) {
             if (!flags_wait(pn, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
@@ -1112,6 +1179,7 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
         c = cn;
         t = tn;
     }
+    if (!reduce(pg, pt)) return;
     PL_ST_DUMP(a.stamps);
 }
 
@@ -1267,6 +1335,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedArgs a) {
     if (role < 0 || role >= a.n_roles) return;
     // the role's descriptor stays in (constant) device memory: uniform address -> scalar loads; the role functions copy what
     // their loops use into locals (the whole struct held in SGPRs crowds them out, read through LDS it costs a round trip per use)
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
     const FusedRole R = uniform_role(a.roles[role]);
     switch (R.type) {
         case FR_LSTM_BWD:
@@ -1302,6 +1372,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
     if (role < 0 || role >= a.n_roles) return;
     // the role's descriptor stays in (constant) device memory: uniform address -> scalar loads; the role functions copy what
     // their loops use into locals (the whole struct held in SGPRs crowds them out, read through LDS it costs a round trip per use)
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
     const FusedRole R = uniform_role(a.roles[role]);
     switch (R.type) {
         case FR_LSTM_FWD:
@@ -1317,7 +1389,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
 
 }  // namespace
 
-#define PL_FUSED_KS_LIST(X) X(4) X(46)
+#define PL_FUSED_KS_LIST(X) X(6) X(46)
 
 bool fused_supported(int Hp) {
 #define PL_CASE(K) if (Hp == 16 * K) return true;

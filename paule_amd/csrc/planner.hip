@@ -242,6 +242,8 @@ struct pl_handle {
     FusedRole* fused_roles_fwd = nullptr;       // role tables in device memory (static for the life of the handle: every pointer is the
     FusedRole* fused_roles_bwd = nullptr;       // handle's own buffer, the flag slices are the last 2 n_roles of the iteration's slices)
     int fused_n_roles = 0;
+    int fused_active_fwd = 0, fused_active_bwd = 0;   // role-bearing workgroups of the two launches (residency census)
+    unsigned long long census_ticks = 5000000ull;     // 50 ms (PAULE_HIP_CENSUS_MS)
     unsigned long long spin_ticks = 200000000ull;   // 2 s
     unsigned poll_mask = 63u;
     double* past = nullptr;
@@ -1295,6 +1297,8 @@ int plan_fused(pl_handle* h) {
             PL_HIP(hipMemcpyAsync(h->fused_tab_fwd, tab.data(), sizeof(short) * (size_t)grid * 4, hipMemcpyHostToDevice, h->stream));
             PL_HIP(hipStreamSynchronize(h->stream));   // tab is a local
             h->fused_grid_fwd = grid;
+            h->fused_active_fwd = 0;
+            for (int b = 0; b < grid; ++b) h->fused_active_fwd += tab[(size_t)b * 4] >= 0 ? 1 : 0;
             h->fused_fwd_ok = true;
         }
     }
@@ -1324,25 +1328,37 @@ int plan_fused(pl_handle* h) {
             }
             if ((rc = raw_alloc(h, &h->fused_xchg_mel, (size_t)kFusedRing * ng * (h->Mp / 32) * P * tile))) return rc;
             h->fused_grid_bwd = grid;
+            h->fused_active_bwd = 0;
+            for (int b = 0; b < grid; ++b) h->fused_active_bwd += tab[(size_t)b * 4] >= 0 ? 1 : 0;
             h->fused_bwd_ok = true;
         }
     }
     return PL_OK;
 }
 
+int* fused_slice(pl_handle* h, int r, bool bwd);
 void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, const FusedRole* roles, bool bwd) {
     a.Bp = h->Bp; a.B = h->B; a.n_groups = (h->Bp + 31) / 32; a.flag_stride = h->flag_stride; a.n_roles = h->fused_n_roles;
     a.grid = grid;
     a.status = h->sweep_status; a.spin_ticks = h->spin_ticks; a.poll_mask = h->poll_mask;
     a.block_tab = tab;
     a.roles = roles;
+    // the last word of role 0's flag slice (inside its XCD-id table, which the fused launches do not use): zeroed with the flags
+    a.census = fused_slice(h, 0, bwd) + h->sweep_cnt_bytes / sizeof(int) - 1;
+    a.n_active = bwd ? h->fused_active_bwd : h->fused_active_fwd;
+    if (const char* z = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA")) a.n_active += std::atoi(z);   // test hook: a workgroup that never shows up
+    a.census_ticks = h->census_ticks;
+    if (std::getenv("PAULE_HIP_DEBUG_FUSED"))
+        fprintf(stderr, "[pl] fused %s launch: grid %d, %d role-bearing workgroups expected, census word at slice int %zu, bound %llu ticks, Cp %d Ce %d\n",
+                bwd ? "backward" : "forward", grid, a.n_active, (size_t)(a.census - h->sweep_cnt), a.census_ticks, h->fused_Cp, h->fused_Ce);
     a.stamps = h->sweep_stamps ? h->sweep_stamps + (bwd ? 256 * 8 : 0) : nullptr;
 }
 
 // flag slice of role r of the fused forward (bwd = false) / backward launch: the last 2 n_roles slices of an iteration
-int* fused_slice(pl_handle* h, int r, bool bwd) {
+int* fused_slice(pl_handle* h, int r, bool bwd) {   // backward: r >= n_roles are the second flag sets of the product roles
     const size_t ints = h->sweep_cnt_bytes / sizeof(int);
-    return h->sweep_cnt + (size_t)(h->n_sweep_slots - 2 * h->fused_n_roles + (bwd ? h->fused_n_roles : 0) + r) * ints;
+    const int n_fused = 2 * h->fused_n_roles + (h->emb.L - 1);
+    return h->sweep_cnt + (size_t)(h->n_sweep_slots - n_fused + (bwd ? h->fused_n_roles : 0) + r) * ints;
 }
 
 // the role tables (called once, at the end of pl_create: every buffer exists)
@@ -1422,10 +1438,11 @@ int build_fused_roles(pl_handle* h) {
             R.wait[0] = FusedWait{fl[rl], Tp, P, 0, 0, 1};
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
             if (top) R.dh_last = h->dv;
-            else {   // dL/dh partial tiles from the layer above's product role
+            else {   // dL/dh rows from the layer above's product role (reduced there): this slice's columns come from its slice-p workgroup
                 const int rdx = 3 + 2 * l;
-                R.wait[1] = FusedWait{fl[rdx], Tp, P, 0, 0, 0};
-                R.xchg_ext = h->fused_xchg_ext[rdx];
+                R.wait[1] = FusedWait{fused_slice(h, n_roles + l, true), Tp, 1, 1, 0, 0};
+                R.dh_ext = e.dh_ext; R.dh_ext_rows = Tp; R.src_sc1 = 1;
+                (void)rdx;
             }
             if (l == 0) {   // input-gradient tiles for the backward mel head; a ring slot is free once the head has finished the step that used it
                 R.wait[2] = FusedWait{fl[1], Tp, 1, 0, 0, kFusedRing};
@@ -1435,9 +1452,12 @@ int build_fused_roles(pl_handle* h) {
                 const int rdx = 3 + 2 * (l - 1), rbelow = l == 1 ? 2 : 4 + 2 * (l - 2);
                 FusedRole& D = roles[rdx];
                 D.type = FR_DX_BWD; D.C = h->fused_Ce; D.T = Tp; D.flags = fl[rdx];
-                D.wait[0] = FusedWait{fl[rbelow], Tp, P, 0, 0, kFusedRing};
+                D.flags2 = fused_slice(h, n_roles + (l - 1), true);
+                // a ring slot of partial tiles is free once every workgroup of the set has reduced the step that used it
+                D.wait[0] = FusedWait{D.flags2, Tp, P, 0, 0, kFusedRing};
                 D.wait[2] = FusedWait{fl[rl], Tp, 1, 1, 0, 0};
-                D.G = ly.G; D.Wg = ly.WihT; D.xchg_ext = h->fused_xchg_ext[rdx];
+                D.G = ly.G; D.Wg = ly.WihT; D.xchg_ext = h->fused_xchg_ext[rdx]; D.out = e.dh_ext;
+                (void)rbelow;
             }
         }
         if ((rc = dev_alloc(h, &h->fused_roles_bwd, (size_t)n_roles))) return rc;
@@ -1511,7 +1531,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     h->wf_next = 0;
     h->wf_stream_next = 0;
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
-    const int pipe_nc = acoustic_pipeline_chunks(h);
+    const int pipe_nc = h->fused_fwd_ok ? 0 : acoustic_pipeline_chunks(h);   // the fused launches (batches of 129+ rows) come first
     if (pipe_nc) {
         acoustic_forward_pipeline(h, st, pipe_nc);
     } else if (fused_acoustic_forward(h, st)) {
@@ -1934,6 +1954,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             h->wf_next = 0;
         }
         if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
+        if (const char* ms = std::getenv("PAULE_HIP_CENSUS_MS")) h->census_ticks = 100000ull * (unsigned long long)std::atoll(ms);
         const size_t n_groups_max = (Bp + 7) / 8;   // groups hold >= 8 rows
         const int slice = h->dt == F32 ? 16 : 32;   // hidden units per workgroup
         int pmax = h->pred.Hp / slice;
@@ -1946,7 +1967,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
         // forward + backward sweep of every layer of an iteration, + the head / projection roles of the fused launches
         h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers) +
-                           2 * (cfg->emb_layers > 0 ? 3 + 2 * (cfg->emb_layers - 1) : 0);
+                           (cfg->emb_layers > 0 ? 2 * (3 + 2 * (cfg->emb_layers - 1)) + (cfg->emb_layers - 1) : 0);
         if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
 #ifdef PL_STAMPS
@@ -2151,6 +2172,11 @@ int pl_synchronize(pl_handle* h) {
     int st = 0;
     PL_HIP(hipMemcpyAsync(&st, h->sweep_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PL_HIP(hipStreamSynchronize(h->stream));
+    if (st == 2) {   // the residency census of a fused launch: not all of its workgroups got a CU
+        (void)hipMemsetAsync(h->sweep_status, 0, sizeof(int), h->stream);
+        return fail(PL_ERR_STATE, "fused LSTM launch: its workgroups were not all resident within the census bound -- something else holds "
+                                  "CUs of this GPU (one process per GPU, see paule_hip.h); results of the last pl_step are invalid");
+    }
     if (st != 0) {
         (void)hipMemsetAsync(h->sweep_status, 0, sizeof(int), h->stream);
         return fail(PL_ERR_HIP, "persistent LSTM sweep: a bounded in-kernel wait timed out (workgroups of one batch group were not "

@@ -323,6 +323,7 @@ def _fused_pair(HipPlanner, monkeypatch, wl, B, T, modes, iters, use_graph, extr
     for mode in modes:
         monkeypatch.setenv("PAULE_HIP_FUSED", mode)
         monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
+        monkeypatch.setenv("PAULE_HIP_SWEEP16", "0")   # small batches: the per-layer reference on the 32-row kernels too (the 16-row ones sum in another order)
         for k, v in (extra_env or {}).items():
             monkeypatch.setenv(k, v)
         eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=use_graph)
@@ -335,7 +336,7 @@ def _fused_pair(HipPlanner, monkeypatch, wl, B, T, modes, iters, use_graph, extr
 
 
 @pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720, graph=True), dict(B=144, T=61, H=720, graph=False),
-                                   dict(B=40, T=50, H=64, graph=False), dict(B=33, T=31, H=64, graph=True, chains=dict(PAULE_HIP_FUSED_CP="1", PAULE_HIP_FUSED_CE="2"))])
+                                   dict(B=40, T=50, H=96, graph=False), dict(B=33, T=31, H=96, graph=True, chains=dict(PAULE_HIP_FUSED_CP="1", PAULE_HIP_FUSED_CE="2"))])
 def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     """The fused forward launch (predictor recurrence, mel head + pooling, embedder layer 1, layer-2 projection, layer 2 as
     roles of one grid, several batch groups per workgroup) computes what the per-layer sweeps and GEMMs compute, bit for bit:
@@ -354,7 +355,7 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
 
 
-@pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720), dict(B=48, T=41, H=64)])
+@pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720), dict(B=48, T=41, H=96)])
 def test_fused_backward_matches_per_layer_path(HipPlanner, monkeypatch, shape):
     """The fused backward launch (PAULE_HIP_FUSED=3: embedder recurrences, their dL/dh product and the backward mel head in
     reduce-scatter form, the predictor's recurrence) against the per-layer path.  The embedder's top layer is the same
@@ -1332,3 +1333,26 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["finite"] and out["scaling"] == "weak" and out["final_cp_all_gather_ms"] > 0
     assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+
+
+def test_fused_launch_residency_census(HipPlanner, monkeypatch):
+    """A fused launch whose workgroups are not all resident gives up within the census bound and pl_synchronize says so
+    (PL_ERR_STATE -> ValueError), instead of spinning in its waits: here one expected workgroup never signs in (test hook)."""
+    B, T, H = 40, 30, 96
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    monkeypatch.setenv("PAULE_HIP_FUSED", "1")
+    monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
+    monkeypatch.setenv("PAULE_HIP_CENSUS_MS", "20")
+    monkeypatch.setenv("PAULE_HIP_CENSUS_EXPECT_EXTRA", "1")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    eng.step(1, return_loss=False)
+    with pytest.raises(ValueError, match="not all resident"):
+        eng.synchronize()
+    monkeypatch.delenv("PAULE_HIP_CENSUS_EXPECT_EXTRA")
+    eng.set_cp(wl.cp0)            # the handle is usable again once the GPU is its own
+    eng.reset_optimizer()
+    loss = _n(eng.step(2))
+    eng.synchronize()
+    assert np.isfinite(loss).all()

@@ -32,6 +32,7 @@ for B in batches:
     for fused in ("0", os.environ.get("FC_MODE", "3")):
         os.environ["PAULE_HIP_FUSED"] = fused
         os.environ["PAULE_HIP_FUSED_MIN_B"] = "1"
+        os.environ["PAULE_HIP_SWEEP16"] = "0"   # the per-layer reference on the 32-row kernels whatever the batch
         e = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=frames, objective="acoustic_semvec", dtype="bf16",
                        use_graph=os.environ.get("FC_GRAPH", "0") != "0")
         e.set_targets(wl.target_mel, wl.target_semvec)

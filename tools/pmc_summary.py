@@ -26,7 +26,10 @@ def main():
     out_path = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, write = per_kernel(dfetch, "FETCH_SIZE"), per_kernel(dwrite, "WRITE_SIZE")
     res = {}
-    for kname, key in (("lstm_bwd_rs_sweep_kernel", "lstm_bwd_rs_sweep_kernel"), ("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"),
+    for kname, key in (("fused_fwd_kernel", "fused_fwd_kernel"), ("fused_bwd_kernel", "fused_bwd_kernel"),
+                       ("lstm_bwd16_rs_sweep_kernel", "lstm_bwd16_rs_sweep_kernel"), ("lstm_fwd16_sweep_kernel", "lstm_fwd16_sweep_kernel"),
+                       ("lstm_bwd_sweep_f32_kernel", "lstm_bwd_sweep_f32_kernel"), ("lstm_fwd_sweep_f32_kernel", "lstm_fwd_sweep_f32_kernel"),
+                       ("lstm_bwd_rs_sweep_kernel", "lstm_bwd_rs_sweep_kernel"), ("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"),
                        ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
                        ("lstm_bwd_step_kernel", "lstm_bwd_step_kernel"), ("lstm_fwd_step_kernel", "lstm_fwd_step_kernel"),
                        ("gemm_nt_kernel", "gemm_nt_kernel")):
@@ -51,6 +54,9 @@ def main():
         if os.path.exists(out_path):
             data = json.load(open(out_path))
         data[config] = res
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench   # noqa: E402  (source_digest: the kernel sources these counters were taken on)
+        data["source_digest"] = bench.source_digest()
         json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
 
 
