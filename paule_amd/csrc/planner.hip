@@ -1250,9 +1250,13 @@ std::vector<short> fused_block_table(int n_cu, const std::vector<FusedSet>& sets
 // chain-step keeps a workgroup busy ~2.1 us, a group's own step-to-step latency is ~4.2 us; the embedder has half the steps.
 int plan_fused(pl_handle* h) {
     h->fused_fwd_ok = h->fused_bwd_ok = false;
-    int mode = 1;   // bit 0: fused forward launch (default), bit 1: fused backward launch (experimental: slower than the per-layer sweeps so far)
+    // bit 0: fused forward launch, bit 1: fused backward launch.  Measured (profiles/r02_ab_fused_range.txt): up to 128 rows both
+    // win (B = 64: 4.53 -> 3.33 ms per iteration, T = 2000: 30.4 -> 21.3; one or two chains per workgroup, the roles overlap and the
+    // step latency hides); from 129 rows on the backward launch needs 2 - 4 chains per workgroup, its chain-step is bound by the
+    // CU's memory pipe and the per-layer backward sweeps are faster (B = 256: 5.82 vs 7.19 ms) -- forward launch only.
+    int mode = h->Bp >= 129 ? 1 : 3;
     if (const char* z = std::getenv("PAULE_HIP_FUSED")) mode = std::atoi(z);
-    int min_rows = 129;   // smaller batches: the 16-row kernels and their chunk pipelines (4.1a, 4.1f) are faster
+    int min_rows = 49;   // up to 48 rows the 16-row kernels' chunk pipelines (4.1f) are as fast or faster (T = 2000, B = 32: 19.2 vs 20.8 ms)
     if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
     const Model &p = h->pred, &e = h->emb;
     if (!(mode & 3) || h->dt != BF16 || !h->use_sweep || !h->fuse_input || h->Bp < min_rows) return PL_OK;
@@ -1531,7 +1535,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     h->wf_next = 0;
     h->wf_stream_next = 0;
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
-    const int pipe_nc = h->fused_fwd_ok ? 0 : acoustic_pipeline_chunks(h);   // the fused launches (batches of 129+ rows) come first
+    const int pipe_nc = h->fused_fwd_ok ? 0 : acoustic_pipeline_chunks(h);   // the fused launches (batches of 49+ rows) come first
     if (pipe_nc) {
         acoustic_forward_pipeline(h, st, pipe_nc);
     } else if (fused_acoustic_forward(h, st)) {
