@@ -29,7 +29,10 @@
 #define FUSED_BWD_ANSWER_AT 1   // backward recurrence: next chain-step's flag answer + prefetch issue 0 before / 1 half way through / 2 after the tiles
 #endif
 #ifndef FUSED_POLL_NUM
-#define FUSED_POLL_NUM 4   // first look at the next chain-step's flags after FUSED_POLL_NUM / 8 of the MFMA chain
+#define FUSED_POLL_NUM 4   // wave 0's look at the next chain-step's flags after FUSED_POLL_NUM / 8 of the MFMA chain (answered after the chain)
+#endif
+#ifndef FUSED_POLL_EARLY
+#define FUSED_POLL_EARLY -1   // wave 0's EARLY look after FUSED_POLL_EARLY / 8 of the MFMA chain: if it finds the flags up, the late look's answer is not waited for (-1: off, the default: measured slower)
 #endif
 
 namespace pl {
@@ -248,7 +251,12 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
     constexpr int CH = Hp / 8;                        // 16-byte chunks per h row
     constexpr int NL = (32 * CH + 255) / 256;         // tile loads per thread
     constexpr int PF = 6;                             // B-fragment read-ahead
-    constexpr int PK = KS * FUSED_POLL_NUM / 8;       // k-step at which wave 0 takes its first look at the next chain-step's flags
+    constexpr int PK = KS * FUSED_POLL_NUM / 8;       // k-step at which wave 0 takes its look at the next chain-step's flags
+    // a poll's answer takes ~1.2 us (write-through flags: the memory side answers), as long as the whole MFMA chain: the look at PK is
+    // late enough to see flags raised at the top of this chain-step but is answered ~0.6 us after the chain.  An EARLY look at k-step
+    // PK0 has its answer by the end of the chain; only if that one fails is the late one waited for.  (Issuing the operand loads
+    // from inside the chain on an early answer was measured: the wait for the answer then sits in the chain, +0.75 us per chain-step.)
+    constexpr int PK0 = FUSED_POLL_EARLY >= 0 && KS >= 16 ? KS * FUSED_POLL_EARLY / 8 : -1;
     constexpr int INP = KSX ? 16 * KSX : 16, XC = INP / 8;
     unsigned char* himg = lds + L::O_HIMG;
     unsigned char* hst = lds + L::O_HST;
@@ -403,7 +411,7 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
         // B. first look at the next chain-step's flags, answered while the MFMAs run
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
         if (has_next) pn = step_flags(a, WT_, gn, tn, p);
-        int pv = 1;
+        int pv = 1, pv0 = 0;
         const bool poll_here = wave == 0 && has_next;
         if (poll_here && t == 0) pv = poll_load(pn, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -428,6 +436,7 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
             for (int ks = 0; ks < KS; ++ks) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks]), __builtin_bit_cast(bf16x8, bq[ks % PF]), acc, 0, 0, 0);
                 if (ks + PF < KS) bq[ks % PF] = *reinterpret_cast<const uint4*>(bsrc + (ks + PF) * 32);
+                if (PK0 >= 0 && ks == PK0 && poll_here) pv0 = poll_load(pn, lane);
                 if (ks == PK && poll_here) pv = poll_load(pn, lane);   // late enough for flags raised at the top of this chain-step
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -443,7 +452,8 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
 
         // D. has the next chain-step everything it waits for?  (uniform answer through LDS)
         if (wave == 0) {
-            const bool rdy = __all(pv != 0);
+            bool rdy = PK0 >= 0 && __all(pv0 != 0);
+            if (!rdy) rdy = __all(pv != 0);
             if (lane == 0) lflag[0] = rdy ? 1 : 0;
         }
         __syncthreads();
