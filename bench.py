@@ -347,7 +347,10 @@ def main():
         if not swept:
             kname = "lstm_bwd_step_kernel"
         elif cfg["dtype"] == "f32":
-            kname = "lstm_bwd_sweep_f32_kernel"
+            # more 16-row groups than the chip holds at once (256 CUs / (Hp / 16) workgroups per group): the chains kernels
+            hp = -(-int(eng.pred_hidden) // 16) * 16
+            chained = -(-cfg["batch"] // 16) > 256 // (hp // 16) and os.environ.get("PAULE_HIP_F32_CHAINS", "-1") != "0" and hp in (96, 736)
+            kname = "lstm_bwd_chain_f32_kernel" if chained else "lstm_bwd_sweep_f32_kernel"
         else:
             kname = "lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel"
         achieved = fl / (ms * 1e-3) / 1e12

@@ -69,6 +69,7 @@ struct LstmSweepArgs {
     // f32 FMAs on those rows only (the 16x16x4 MFMA costs the same for 1 row as for 16 and bounds the step); 0 = MFMA
     int n_valid;
     int stash_via_lds;     // forward, 32-row kernel: 1 = the five stash arrays leave through LDS as 64-byte row pieces
+    int chains;            // lstm_chain_f32.hip: batch groups a workgroup serves in turn with one copy of its weights
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit
@@ -87,6 +88,10 @@ bool lstm_sweep_f32_supported(int Hp);
 int lstm_sweep_f32_grid(int Hp, int Bp, int n_cu);
 size_t lstm_f32_exchange_bytes(int Hp, int Bp);
 void launch_lstm_sweep_f32(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
+// f32 chains (lstm_chain_f32.hip): more 16-row groups than the chip holds at once.  plan: chains per workgroup (0 = not this path)
+bool lstm_chain_f32_supported(int Hp);
+int lstm_chain_f32_plan(int Hp, int Bp, int n_cu, int forced_chains, int* grid);
+void launch_lstm_chain_f32(hipStream_t stream, bool backward, int Hp, int grid, const LstmSweepArgs& a);
 // ---- lstm_fused.hip ------------------------------------------------------------------------
 // The acoustic path's LSTM sweeps of one direction as ONE persistent launch (bf16, all models of one hidden size): the
 // workgroups of the grid take ROLES (a layer's recurrence, a layer's input projection, the mel head with its pooling, ...)

@@ -201,6 +201,7 @@ struct pl_handle {
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
+    int f32_chains = -1;        // PAULE_HIP_F32_CHAINS: f32 batches of more groups than fit the chip: -1 auto, 0 off (groups take turns / launch-per-step), N forced
     bool stash_lds = true;      // PAULE_HIP_STASH_LDS: forward stash stores staged through LDS (whole 64-byte row pieces)
     bool xcd_fast16 = true;     // PAULE_HIP_XCD_FAST16: forward same-XCD hand-off for the 16-row kernels
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
@@ -354,9 +355,21 @@ bool use_sweep16(pl_handle* h, int Hp, bool bwd) {
     if (h->dt != BF16 || !h->sweep16 || !lstm_sweep_supported(h->dt, Hp) || !lstm_sweep16_wanted(Hp, h->Bp, h->n_cu)) return false;
     return !bwd || (h->bwd_mode == 1 && h->sweep_xchg);
 }
+// f32 batches whose 16-row groups do not all fit the chip: chains (lstm_chain_f32.hip) instead of groups taking turns.
+// PAULE_HIP_F32_CHAINS: 0 off, N > 0 force N chains per workgroup (tests), unset: as many as make every group resident
+int f32_chains_for(pl_handle* h, int Hp, int* grid) {
+    *grid = 0;
+    if (h->f32_chains == 0 || h->dt != F32) return 0;
+    return lstm_chain_f32_plan(Hp, h->Bp, h->n_cu, h->f32_chains > 0 ? h->f32_chains : 0, grid);
+}
 int sweep_grid_for(pl_handle* h, int Hp, bool bwd = false) {
     if (!h->use_sweep) return 0;
-    if (h->dt == F32) return (h->f32_sweep && lstm_sweep_f32_supported(Hp)) ? lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu) : 0;
+    if (h->dt == F32) {
+        if (!h->f32_sweep || !lstm_sweep_f32_supported(Hp)) return 0;
+        int cgrid = 0;
+        if (f32_chains_for(h, Hp, &cgrid)) return cgrid;
+        return lstm_sweep_f32_grid(Hp, h->Bp, h->n_cu);
+    }
     if (use_sweep16(h, Hp, bwd)) return lstm_sweep16_grid(Hp, h->Bp, h->n_cu, h->small_grid);
     return lstm_sweep_supported(h->dt, Hp) ? lstm_sweep_grid(Hp, h->Bp, h->n_cu, h->small_grid) : 0;
 }
@@ -365,8 +378,17 @@ int sweep_group_rows_for(pl_handle* h, int Hp, bool bwd = false) {
     return lstm_sweep_group_rows(Hp, h->Bp, h->n_cu);
 }
 void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, const LstmSweepArgs& s) {
-    if (h->dt == F32)
-        launch_lstm_sweep_f32(st, bwd, Hp, grid, s);
+    if (h->dt == F32) {
+        int cgrid = 0;
+        const int C = f32_chains_for(h, Hp, &cgrid);
+        if (C > 0 && s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T)) {
+            LstmSweepArgs sc = s;
+            sc.chains = C;
+            launch_lstm_chain_f32(st, bwd, Hp, cgrid, sc);
+        } else {
+            launch_lstm_sweep_f32(st, bwd, Hp, grid, s);
+        }
+    }
     else if (use_sweep16(h, Hp, bwd))
         launch_lstm_sweep16(st, bwd, Hp, grid, s);
     else if (bwd && h->bwd_mode == 1 && h->sweep_xchg)
@@ -1895,6 +1917,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_F32_CHAINS")) h->f32_chains = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_SMALL_GRID")) h->small_grid = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_SWEEP16")) h->sweep16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST16")) h->wide_ingest16 = std::atoi(z) != 0;

@@ -64,6 +64,7 @@ class HipPlanner:
         _capi.check(self.lib, self.lib.pl_default_config(C.byref(cfg)), "pl_default_config")
         cfg.batch, cfg.n_frames, cfg.cp_dim, cfg.mel_dim = self.B, self.T, self.C, self.M
         cfg.pred_layers, cfg.pred_hidden = lay_p, hid_p
+        self.pred_hidden = int(hid_p)
         if emb_sd is not None:
             in_e, hid_e, lay_e = _lstm_dims(emb_sd)
             if in_e != self.M:

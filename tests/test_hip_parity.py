@@ -183,6 +183,37 @@ def test_f32_sweep_many_groups_vs_oracle_and_per_step(shape, monkeypatch):
     np.testing.assert_allclose(outs[0], outs[1], rtol=LOSS_RTOL_F32, atol=1e-7)
 
 
+@pytest.mark.parametrize("shape", [dict(B=100, T=21, H=720, chains=("0", "-1", "3")), dict(B=150, T=30, H=96, chains=("0", "2", "5")),
+                                   dict(B=256, T=16, H=720, chains=("-1",))])
+def test_f32_chains_equal_groups_taking_turns(shape, monkeypatch):
+    """f32 batches of more 16-row groups than the chip holds at once (lstm_chain_f32.hip): a workgroup serves several groups in
+    turn with one copy of its weights, per time step, instead of sweeping them one after the other.  Same MFMA order per output
+    element and the same fixed-order sum of the partial tiles as lstm_persist_f32.hip, so the plans are bit-identical to
+    PAULE_HIP_F32_CHAINS=0 (at B = 256, where that means the launch-per-step kernels, to the f32 bars); forced chain counts
+    cover ragged sets (7 groups in sets of 3, 10 groups in sets of 5 and 2)."""
+    from paule_amd.engine import HipPlanner
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    outs = {}
+    for ch in ("0",) + tuple(c for c in shape["chains"] if c != "0"):
+        monkeypatch.setenv("PAULE_HIP_F32_CHAINS", ch)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        loss = _n(eng.step(4))
+        eng.synchronize()
+        outs[ch] = (loss, _n(eng.get_cp()))
+    for ch, (loss, cp) in outs.items():
+        if ch == "0":
+            continue
+        if B <= 240:   # the reference run is the sweeps with the groups taking turns: same bits
+            np.testing.assert_array_equal(loss, outs["0"][0], err_msg=f"chains={ch}")
+            np.testing.assert_array_equal(cp, outs["0"][1], err_msg=f"chains={ch}")
+        else:          # the reference run is the launch-per-step kernels: dh summation order differs
+            np.testing.assert_allclose(loss, outs["0"][0], rtol=LOSS_RTOL_F32, atol=1e-7)
+            np.testing.assert_allclose(cp, outs["0"][1], atol=CP_ATOL_F32, rtol=0)
+
+
 def test_optimizer_state_persists_and_resets(HipPlanner, golden_small):
     """Adam state continues across pl_step calls (= outer iterations, paule/paule.py:797) and resets on request."""
     g = golden_small
