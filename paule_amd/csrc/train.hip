@@ -10,6 +10,8 @@
 // f32 MFMA (v_mfma_f32_16x16x4_f32) whatever the activation type: the operand of that instruction is one element per
 // lane per k, so a k-major LDS image feeds it without a transpose, and weight gradients summed over thousands of
 // (t, b) terms want f32 products anyway.  bf16 activations are widened while they are staged into LDS.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "pl_types.h"
 
@@ -247,6 +249,118 @@ __global__ void adam_bias_kernel(const float* __restrict__ grad, int nblk, int R
     packed[blk * Rp + r] = (float)s;
 }
 
+
+// bf16 activations: the same product on the bf16 MFMA (v_mfma_f32_16x16x32_bf16, 16x the f32 instruction's rate).  Its operands
+// want 8 consecutive k per lane while both matrices are k-major -- gfx950's transposed LDS read (ds_read_b64_tr_b16: a 16-lane
+// group reads a block of 4 rows x 16 columns and every lane receives one COLUMN) delivers exactly that from a plain [k][m] image.
+// K tile = 32 rows (two 16-row pieces of the (t, b) enumeration; an odd last piece is zero-filled).  Lane group g takes image
+// rows 4g .. 4g+3 as its k elements 0..3 and rows 16+4g .. 16+4g+3 as elements 4..7 -- the same (arbitrary) assignment of rows
+// to k slots for both operands, which is all a sum over k needs -- so that the two groups of a 32-lane half read 8 consecutive
+// rows: with a row stride of 256 + 32 bytes they cover all 64 banks exactly once.  bf16 x bf16 products are exact in f32 and
+// accumulate in f32, as before; only the summation order over k differs from the f32-MFMA kernel.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Bm, int ldb,
+                                                           float* __restrict__ C, int ldc, int M, int N, int Bp, int nb, int Tk,
+                                                           int tA0, int tB0) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int SA = BM * 2 + 32, SB = BN * 2 + 32;   // bytes per image row
+    constexpr int TN = BN / 32;                         // MFMA tiles per wave along n
+    constexpr int CB = BN / 8;                          // 16-byte chunks per B row
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][BK * SA];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[2][BK * SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tiles_per_t = nb / 16, tiles_all = Tk * tiles_per_t;
+    const int kt0 = (int)((long long)tiles_all * blockIdx.z / gridDim.z), kt1 = (int)((long long)tiles_all * (blockIdx.z + 1) / gridDim.z);
+    const int n_super = (kt1 - kt0 + 1) / 2;            // K tiles of 32 rows
+    C += (size_t)blockIdx.z * M * ldc;
+
+    // staging: A tile 32 rows x 16 chunks = 2 per thread (rows tid >> 4 and 16 + (tid >> 4)); B tile 32 rows x CB chunks
+    const int ar = tid >> 4, ac = tid & 15;
+    constexpr int BPT = (BK * CB + 255) / 256;          // B chunks per thread (BN = 128: 2, BN = 64: 1)
+    uint4 ra[2], rb[BPT];
+    auto load = [&](int st) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kt = kt0 + 2 * st + half;
+            const int t = kt / tiles_per_t, b0 = (kt % tiles_per_t) * 16;
+            const size_t rowA = (size_t)(tA0 + t) * Bp + b0 + ar;
+            ra[half] = (kt < kt1 && m0 + ac * 8 < M) ? *reinterpret_cast<const uint4*>(A + rowA * lda + m0 + ac * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int e = tid + 256 * i, row = e / CB, ch = e % CB;
+            const int kt = kt0 + 2 * st + (row >> 4);
+            const int t = kt / tiles_per_t, b0 = (kt % tiles_per_t) * 16;
+            const size_t rowB = (size_t)(tB0 + t) * Bp + b0 + (row & 15);
+            rb[i] = (kt < kt1 && n0 + ch * 8 < N) ? *reinterpret_cast<const uint4*>(Bm + rowB * ldb + n0 + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage = [&](int buf) {
+        *reinterpret_cast<uint4*>(sA[buf] + ar * SA + ac * 16) = ra[0];
+        *reinterpret_cast<uint4*>(sA[buf] + (16 + ar) * SA + ac * 16) = ra[1];
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int e = tid + 256 * i, row = e / CB, ch = e % CB;
+            *reinterpret_cast<uint4*>(sB[buf] + row * SB + ch * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (n_super > 0) {
+        load(0);
+        stage(0);
+    }
+    __syncthreads();
+    // transposed-read address of this lane: group g = lane >> 4, in-group lane 4 q + p -> image row 4 g + q, columns 4 p .. 4 p + 3
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int offA = (4 * g + q) * SA + (wm * 64 + 4 * pp) * 2;
+    const int offB = (4 * g + q) * SB + (wn * (BN / 2) + 4 * pp) * 2;
+    for (int st = 0; st < n_super; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < n_super) load(st + 1);
+        bf16x8 fa[4], fb[TN];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(sA[buf] + offA + i * 32));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(sA[buf] + offA + 16 * SA + i * 32));
+            fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(sB[buf] + offB + j * 32));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(sB[buf] + offB + 16 * SB + j * 32));
+            fb[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (st + 1 < n_super) stage(buf ^ 1);   // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    // C layout: column n = lane & 15, row m = 4 (lane >> 4) + reg
+    const int lr = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + kq * 4 + r;
+                if (m < M && n < N) C[(size_t)m * ldc + n] = acc[i][j][r];
+            }
+        }
+}
+
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -277,7 +391,16 @@ void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const vo
             hipLaunchKernelGGL((gemm_tn_kernel<AT_, 128>), grid, dim3(256), 0, stream, static_cast<const AT_*>(A), lda,         \
                                static_cast<const AT_*>(B), ldb, dst, ldc, M, N, Bp, nb, Tk, tA0, tB0);                          \
     } while (0)
-    if (dt == BF16) PL_TN(bf16_t);
+    const char* tn_env = std::getenv("PAULE_HIP_TN_BF16");   // 0: the f32-MFMA form for bf16 operands too (A/B, tests)
+    const bool tn_bf16 = !(tn_env && std::atoi(tn_env) == 0);
+    if (dt == BF16 && tn_bf16) {
+        if (narrow)
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<64>), grid, dim3(256), 0, stream, static_cast<const bf16_t*>(A), lda,
+                               static_cast<const bf16_t*>(B), ldb, dst, ldc, M, N, Bp, nb, Tk, tA0, tB0);
+        else
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<128>), grid, dim3(256), 0, stream, static_cast<const bf16_t*>(A), lda,
+                               static_cast<const bf16_t*>(B), ldb, dst, ldc, M, N, Bp, nb, Tk, tA0, tB0);
+    } else if (dt == BF16) PL_TN(bf16_t);
     else PL_TN(float);
 #undef PL_TN
     if (S > 1) {

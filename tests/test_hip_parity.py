@@ -504,6 +504,28 @@ def test_train_pred_bf16_vs_reference_fixture(HipPlanner, golden_train):
         assert d.max() <= 0.5 * 1e-3 * n_steps and d.mean() <= 0.05 * 1e-3 * n_steps, (name, d.max(), d.mean())
 
 
+def test_weight_gradients_bf16_mfma_equals_f32_mfma(HipPlanner, monkeypatch):
+    """The weight-gradient products of a bf16 training step on the bf16 MFMA (gemm_tn_bf16_kernel: transposed LDS reads of the
+    k-major operands) against the same products on the exact f32 MFMA (PAULE_HIP_TN_BF16=0): products of bf16 values are exact
+    in f32 either way and both accumulate in f32, so the gradients agree to summation order -- 1e-5 of each tensor's largest
+    entry; H = 720 (split-K, the 128-wide tiles) and a ragged small model (64-wide tiles, partial tiles in m and n)."""
+    for kw, B, T, n in ((dict(set="A"), 24, 60, 8), (dict(pred=dict(num_lstm_layers=2, hidden_size=40)), 5, 31, 5)):
+        wl = synthetic.make_workload(B, T, kw.get("set"), pred=kw.get("pred"), emb=dict(num_lstm_layers=1, hidden_size=24)) if "pred" in kw \
+            else synthetic.make_workload(B, T, "A")
+        grads = {}
+        for form in ("1", "0"):
+            monkeypatch.setenv("PAULE_HIP_TN_BF16", form)
+            eng = HipPlanner(wl.pred_sd, None, batch=B, n_frames=T, objective="acoustic", dtype="bf16")
+            eng.train_pred_step(wl.cp0[:n], wl.target_mel[:n])
+            eng.synchronize()
+            L = sum(1 for k in wl.pred_sd if k.startswith("lstm.weight_hh_l"))
+            grads[form] = {f"{kind}{l}": _n(eng.debug_read(f"pred.{kind}{l}")) for l in range(L) for kind in ("i", "r")}
+        for name, g1 in grads["1"].items():
+            g0 = grads["0"][name]
+            assert np.abs(g0).max() > 0, name
+            assert np.abs(g1 - g0).max() <= 1e-5 * np.abs(g0).max(), (name, np.abs(g1 - g0).max(), np.abs(g0).max())
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_train_pred_set_a_vs_oracle(HipPlanner, dtype):
     """Paule's default ForwardModel (L = 1, H = 720: persistent sweeps, 46 / 23 workgroups per group) trained for 3

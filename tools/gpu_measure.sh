@@ -1,6 +1,6 @@
 #!/bin/bash
 # Measurement session of a round on the GPU box: bench lines, kernel stats, PMC passes (separate FETCH_SIZE / WRITE_SIZE runs, the
-# profiler in front of the program itself).  usage: tools/gpu_measure.sh TAG [part ...]   parts: bench stats pmc pmc_xcd others
+# profiler in front of the program itself).  usage: tools/gpu_measure.sh TAG [part ...]   parts: bench cpufull stats pmc pmc_xcd pmc_others others trainstats
 set -o pipefail
 tag=$1; shift
 parts=${@:-bench stats pmc}
@@ -35,10 +35,13 @@ for part in $parts; do
              pmc_pair cfg3 _unfused PAULE_HIP_FUSED=0 ;;
     pmc_others) pmc_pair cfg2 "" PAULE_HIP_XCD_FAST=2
                 pmc_pair cfg5 "" PAULE_HIP_XCD_FAST=2 ;;
-    others) for c in cfg1 cfg2 cfg2_setB cfg3_setB cfg3_setC cfg3_f32 cfg5 cfg5_setB cfg5_128 cfg4_1gpu cfg3_soma train8; do
+    others) for c in cfg1 cfg2 cfg2_setB cfg3_setB cfg3_setC cfg3_f32 cfg5 cfg5_setB cfg5_128 cfg4_1gpu cfg3_soma train8; do   # train8 etc. print one JSON line each
               run bench_$c 400 python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline
               grep '^{' gpurun_out/${tag}_bench_$c.log > gpurun_out/${tag}_bench_$c.json
             done ;;
+    trainstats) rm -rf gpurun_out/prof_t
+           run rocprof_train8 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_t -- python3 tools/train_bench.py 8 8 bf16 20
+           cp $(find gpurun_out/prof_t -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_train8_kernel_stats.csv ;;
     *) echo "unknown part $part" ;;
   esac
 done
