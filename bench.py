@@ -348,9 +348,11 @@ def main():
             kname = "lstm_bwd_step_kernel"
         elif cfg["dtype"] == "f32":
             # more 16-row groups than the chip holds at once (256 CUs / (Hp / 16) workgroups per group): the chains kernels
-            hp = -(-int(eng.pred_hidden) // 16) * 16
+            hp = -(-int(eng.pred_hidden) // 32) * 32   # feature dimensions are padded to multiples of 32
             chained = -(-cfg["batch"] // 16) > 256 // (hp // 16) and os.environ.get("PAULE_HIP_F32_CHAINS", "-1") != "0" and hp in (96, 736)
             kname = "lstm_bwd_chain_f32_kernel" if chained else "lstm_bwd_sweep_f32_kernel"
+        elif -(-cfg["batch"] // 16) * 16 <= 128 and os.environ.get("PAULE_HIP_SWEEP16", "1") != "0" and rs:
+            kname = "lstm_bwd16_rs_sweep_kernel"   # batches of up to 128 rows: the 16-row kernels (what pl_bench_kernel launches there)
         else:
             kname = "lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel"
         achieved = fl / (ms * 1e-3) / 1e12
@@ -401,6 +403,10 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": ms * 1e3, "flops_per_launch": fl,
                          "us_per_time_step": ms * 1e3 / (T - 1) if swept else ms * 1e3,
+                         # batches of 49 .. 128 rows run BOTH passes as fused launches by default: the per-layer kernel timed above is
+                         # then the A/B reference (PAULE_HIP_FUSED=0), not a kernel of the timed iteration
+                         "note": ("the timed iteration runs the backward pass as fused_bwd_kernel; the per-layer kernel named here was timed on its own"
+                                  if fused is not None and -(-cfg["batch"] // 16) * 16 <= 128 and os.environ.get("PAULE_HIP_FUSED") in (None, "3") else None),
                          "fwd_kernel_avg_launch_us": ms_f * 1e3,
                          "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12,
                          "fused_fwd_kernel": None if fused is None else {
