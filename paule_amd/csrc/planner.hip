@@ -1576,9 +1576,10 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     LossArgs la = loss_args(h, with_sem);
     launch_loss_reduce(st, la);
     launch_loss_finalize(st, la);
-    if (pipe_nc) {
+    // the fused backward launch does not care how the stashes were made: it also follows a chunk-pipelined forward pass
+    if (with_sem && fused_acoustic_backward(h, st, la)) {
+    } else if (pipe_nc) {
         acoustic_backward_pipeline(h, st, pipe_nc, la);
-    } else if (with_sem && fused_acoustic_backward(h, st, la)) {
     } else {
         const float* dmel_e = nullptr;
         if (with_sem) {
