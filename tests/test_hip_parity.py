@@ -1242,6 +1242,34 @@ def test_full_size_cfg2_f32_against_oracle_rows(HipPlanner):
     np.testing.assert_array_equal(_n(sub.get_cp()), cp[16:32])
 
 
+def test_full_size_cfg3_f32_against_oracle_rows(HipPlanner):
+    """cfg3 in f32 at full size (B = 256 x 300 frames, `acoustic_semvec`, Paule's default models): 16 groups of 16 rows run as four
+    chains per workgroup (lstm_chain_f32.hip) in all three LSTM layers; the first and the last utterance against a float64 oracle
+    run on those two alone at the f32 bars, and rows 32..47 (one whole group, the third chain of its set) bit-equal to a
+    16-utterance engine -- the same MFMA order per element, no coupling between the chains of a workgroup."""
+    B, T, n = 256, 300, 2
+    wl = synthetic.make_workload(B, T, "A")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(n))
+    cp = _n(eng.get_cp())
+    eng.synchronize()
+    rows = [0, B - 1]
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec")
+    orc.set_targets(wl.target_mel[rows], wl.target_semvec[rows])
+    orc.set_cp(wl.cp0[rows])
+    lo = _n(orc.step(n))
+    np.testing.assert_allclose(loss[:, rows], lo, rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(cp[rows], _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+    sub = HipPlanner(wl.pred_sd, wl.emb_sd, batch=16, n_frames=T, objective="acoustic_semvec")
+    sub.set_targets(wl.target_mel[32:48], wl.target_semvec[32:48])
+    sub.set_cp(wl.cp0[32:48])
+    np.testing.assert_array_equal(_n(sub.step(n)), loss[:, 32:48])
+    np.testing.assert_array_equal(_n(sub.get_cp()), cp[32:48])
+
+
 @pytest.mark.parametrize("B", [256, 100])
 def test_full_size_cfg3_bf16_against_oracle_rows(HipPlanner, B):
     """cfg3 at full size (B = 256 x 300 frames, `acoustic_semvec`, bf16, Paule's default models): the first and the last utterance
