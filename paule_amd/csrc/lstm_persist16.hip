@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
     constexpr int ORS = Hp * 2 + 16;             // partial image [16 batch rows][Hp] bf16
     constexpr int NST = (P * 64 + 255) / 256;    // hand-off stores (16 B) per thread per step
     __shared__ __attribute__((aligned(16))) unsigned char da_img[16 * DRS];
-    __shared__ __attribute__((aligned(16))) unsigned char out_img[16 * ORS];
+    // the wide ingest also uses this image for the four waves' f32 sums ([4][16 rows][36] floats = 9216 bytes): narrow models
+    // (Hp < 288) need it larger than the partial image itself -- it was not, and their sums ran past the end of the array
+    constexpr int RED_BYTES = 4 * 16 * 36 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char out_img[16 * ORS > RED_BYTES ? 16 * ORS : RED_BYTES];
     __shared__ int lds_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
