@@ -2824,6 +2824,7 @@ int pl_debug_read(pl_handle* h, const char* name, float* out, int64_t max_elems,
     else if (nm == "mel_tm") { src = h->mel_tm; n = (int64_t)h->Tp * h->Bp * h->Mp; kind = 0; ok = true; }
     else if (nm == "dY") { src = h->dY; n = (int64_t)h->T * h->Bp * h->Mp; kind = 0; ok = true; }
     else if (nm == "dX") { src = h->dX; n = (int64_t)h->T * h->Bp * h->Cp; kind = 1; ok = true; }
+    else if (nm == "dX2" && h->dX2) { src = h->dX2; n = (int64_t)h->T * h->Bp * h->Cp; kind = 1; ok = true; }
     else if (nm == "sem" && h->sem) { src = h->sem; n = (int64_t)h->Bp * h->Sp; kind = 1; ok = true; }
     else if (nm == "dsem" && h->dsem) { src = h->dsem; n = (int64_t)h->Bp * h->Sp; kind = 0; ok = true; }
     else if (nm == "dv" && h->dv) { src = h->dv; n = (int64_t)h->Bp * h->emb.Hp; kind = 0; ok = true; }

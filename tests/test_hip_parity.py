@@ -504,6 +504,29 @@ def test_train_pred_bf16_vs_reference_fixture(HipPlanner, golden_train):
         assert d.max() <= 0.5 * 1e-3 * n_steps and d.mean() <= 0.05 * 1e-3 * n_steps, (name, d.max(), d.mean())
 
 
+@pytest.mark.parametrize("spec", [dict(L=1, H=96), dict(L=2, H=192), dict(L=1, H=256), dict(L=1, H=720)])
+def test_train_pred_bf16_weight_gradients_across_widths(HipPlanner, spec):
+    """W_hh / W_ih gradients of one bf16 continued-learning step against the oracle trainer (torch autograd, float64) for narrow
+    and wide predictive models: relative error <= 2 % per tensor (the backward-data recurrence that feeds these products is the
+    planner's own; see test_bf16_model_gradient_across_hidden_sizes for why widths below Hp = 288 get their own case)."""
+    L, H, B, T, n = spec["L"], spec["H"], 16, 40, 8
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=L, hidden_size=H), emb=dict(num_lstm_layers=1, hidden_size=24))
+    tr = op.OracleTrainer(op.forward_model_from_state_dict(wl.pred_sd))
+    tr.train_pred_step(wl.cp0[:n], wl.target_mel[:n])
+    ref = {k: _n(v) for k, v in tr.gradients().items()}
+    eng = HipPlanner(wl.pred_sd, None, batch=B, n_frames=T, objective="acoustic", dtype="bf16")
+    eng.train_pred_step(wl.cp0[:n], wl.target_mel[:n])
+    eng.synchronize()
+    Hp = -(-H // 32) * 32
+    for l in range(L):
+        in_dim = 30 if l == 0 else H
+        in_p = 32 if l == 0 else Hp
+        for kind, name, cols, cols_p in (("r", f"lstm.weight_hh_l{l}", H, Hp), ("i", f"lstm.weight_ih_l{l}", in_dim, in_p)):
+            got = _unpad_grad(eng.debug_read(f"pred.{kind}{l}"), 4, H, cols, Hp, cols_p)
+            err = np.linalg.norm(got - ref[name]) / np.linalg.norm(ref[name])
+            assert err <= 2e-2, (name, err)
+
+
 def test_weight_gradients_bf16_mfma_equals_f32_mfma(HipPlanner, monkeypatch):
     """The weight-gradient products of a bf16 training step on the bf16 MFMA (gemm_tn_bf16_kernel: transposed LDS reads of the
     k-major operands) against the same products on the exact f32 MFMA (PAULE_HIP_TN_BF16=0): products of bf16 values are exact
@@ -1358,6 +1381,36 @@ def test_bf16_model_gradient_across_kernel_families(HipPlanner, case, monkeypatc
     Bp = -(-B // 16) * 16
     dX = _n(eng.debug_read("dX")).reshape(T, Bp, 32)[:, :B, :30].transpose(1, 0, 2)
     err = np.linalg.norm(dX - px["grad_model"]) / np.linalg.norm(px["grad_model"])
+    assert err <= 2e-2, err
+
+
+@pytest.mark.parametrize("tube_hidden", [(360, 360, 720), (96, 128, 192), (64, 48, 256)])
+def test_bf16_somatosensory_model_gradient_vs_oracle(HipPlanner, tube_hidden):
+    """The model part of dL/dCP with somatosensory feedback (acoustic path + cp -> tube -> mel / semantic vector) in bf16 against the
+    torch float64 oracle (autograd gradient minus the smoothness terms' gradient): Paule's tube-model sizes and narrow ones (the width
+    classes below Hp = 288 that the trajectory-level bars cannot tell apart from a wrong gradient): relative error <= 2 %."""
+    from oracle import manual as mo
+    B, T = 6, 40
+    wl = synthetic.make_workload(B, T, "A")
+    specs = {"cp_tube": dict(num_lstm_layers=1, hidden_size=tube_hidden[0]), "tube_mel": dict(num_lstm_layers=1, hidden_size=tube_hidden[1]),
+             "tube_emb": dict(num_lstm_layers=2, hidden_size=tube_hidden[2])}
+    tube = synthetic.make_tube_models(specs=specs)
+    ora_tube = (op.forward_model_from_state_dict(tube[0], apply_half_sequence=False), op.forward_model_from_state_dict(tube[1]),
+                op.embedding_model_from_state_dict(tube[2]))
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
+                           objective="acoustic_semvec", tube_models=ora_tube)
+    orc.set_targets(wl.target_mel, wl.target_semvec)
+    orc.set_cp(wl.cp0)
+    orc.step(1)
+    g_model = _n(orc.last_grad) - mo.smoothness_loss_grad(_n(wl.cp0))[3]
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", tube_models=tube)
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    eng.step(1, return_loss=False)
+    eng.synchronize()
+    rd = lambda name: _n(eng.debug_read(name)).reshape(T, 16, 32)[:, :B, :30].transpose(1, 0, 2)
+    got = rd("dX") + rd("dX2")
+    err = np.linalg.norm(got - g_model) / np.linalg.norm(g_model)
     assert err <= 2e-2, err
 
 
