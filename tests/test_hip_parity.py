@@ -1045,6 +1045,34 @@ def test_embedder_variant_full_size_vs_oracle_rows(HipPlanner):
     np.testing.assert_allclose(_n(eng.get_cp())[rows], _n(P.get_cp()), atol=2e-4, rtol=0)
 
 
+def test_embedder_variant_bf16_model_gradient_vs_oracle(HipPlanner):
+    """The class-default MelEmbeddingModelMelSmoothResidualUpsampling embedder (mel blocks, LSTM 4 x 180 = the narrow width class,
+    head 8192) in bf16: the model part of dL/dCP of one iteration against the torch float64 oracle, relative error <= 2 %."""
+    from oracle import manual as mo
+    from paule_amd import models
+    torch.manual_seed(5)
+    emb = models.MelEmbeddingModelMelSmoothResidualUpsampling()
+    B, T = 12, 60
+    wl = synthetic.make_workload(B, T, "A")
+    emb_sd = {k: v.detach().clone() for k, v in emb.state_dict().items()}
+    ora_e = op.embedding_model_from_state_dict(emb_sd)
+    with torch.no_grad():
+        target_sem = ora_e(wl.target_mel.double(), [torch.tensor(T // 2)] * B) + 0.02
+    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), ora_e, objective="acoustic_semvec")
+    orc.set_targets(wl.target_mel, target_sem)
+    orc.set_cp(wl.cp0)
+    orc.step(1)
+    g_model = _n(orc.last_grad) - mo.smoothness_loss_grad(_n(wl.cp0))[3]
+    eng = HipPlanner(wl.pred_sd, emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    eng.set_targets(wl.target_mel, target_sem)
+    eng.set_cp(wl.cp0)
+    eng.step(1, return_loss=False)
+    eng.synchronize()
+    got = _n(eng.debug_read("dX")).reshape(T, 16, 32)[:, :B, :30].transpose(1, 0, 2)
+    err = np.linalg.norm(got - g_model) / np.linalg.norm(g_model)
+    assert err <= 2e-2, err
+
+
 def _soma_engine(HipPlanner, g, objective, dtype="f32", **extra):
     eng = HipPlanner(state_dict_from(g, "pred"), state_dict_from(g, "emb"), batch=int(g["B"]), n_frames=int(g["T"]), objective=objective,
                      dtype=dtype, tube_models=(state_dict_from(g, "cp_tube"), state_dict_from(g, "tube_mel"), state_dict_from(g, "tube_emb")),
