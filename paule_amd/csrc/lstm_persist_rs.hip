@@ -34,7 +34,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
-    const bool direct = (a.stash_via_lds & 8) != 0;   // partial tiles leave straight from the accumulators (see the tile loop)
     const int gs = a.group_rows;
     const int n_groups = (Bp + gs - 1) / gs;
     const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);   // Whh^T packed [Hp][4*Hp]
@@ -99,11 +98,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)
                 const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
                 const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
-                // tile layout: row-major [32 rows][32 columns] (a wave instruction = 8 rows x 64 B = 512 contiguous bytes), or with
-                // direct tiles [quad >> 2][quad & 1][row (32)][(quad >> 1) & 1][4 columns]: 1 KB contiguous per store instruction of the
-                // producer (see the tile loop), four whole 128-byte lines per wave instruction here
-                const unsigned o0 = direct ? (unsigned)((jq >> 2) * 1024 + (jq & 1) * 512 + erow * 16 + ((jq >> 1) & 1) * 8)
-                                           : (unsigned)((erow * 32 + 4 * jq) * 2);
+                const unsigned o0 = (unsigned)((erow * 32 + 4 * jq) * 2);
                 u32x2 pv[P];
 #pragma unroll
                 for (int s = 0; s < P; ++s)
@@ -168,25 +163,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 for (int ks = 0; ks < 8; ++ks)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i][ks]),
                                                                   __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
-                // acc[r] = partial[n = 32 nt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31]
-                if (direct) {
-                    // straight from the accumulators: a lane's registers 4 rg .. 4 rg + 3 are column quad q = 2 rg + (lane >> 5) of batch
-                    // row lane & 31.  Quads 4 pr + half and 4 pr + 2 + half (rg = 2 pr, 2 pr + 1) share a 16-byte piece of the tile
-                    // layout, and one store instruction fills 1 KB contiguous bytes: two 16-byte stores per lane and tile as with the
-                    // LDS image, without the trip through LDS
-                    const int bb = lane & 31;
-                    const unsigned tb = (unsigned)((size_t)nt * P * TILE * 2) + (unsigned)((lane >> 5) * 512 + bb * 16);
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const uint2 v0 = pack_bf16x4(acc[8 * pr], acc[8 * pr + 1], acc[8 * pr + 2], acc[8 * pr + 3]);
-                        const uint2 v1 = pack_bf16x4(acc[8 * pr + 4], acc[8 * pr + 5], acc[8 * pr + 6], acc[8 * pr + 7]);
-                        u32x4 d;
-                        d[0] = v0.x; d[1] = v0.y; d[2] = v1.x; d[3] = v1.y;
-                        if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, tb + (unsigned)(pr * 1024), 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(d, ro, tb + (unsigned)(pr * 1024), 0, kAuxSc1);
-                    }
-                    continue;
-                }
+                // acc[r] = partial[n = 32 nt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31] -> bf16 image [batch][n]
                 unsigned char* orow = out_img + (lane & 31) * ORS + (32 * nt + 4 * (lane >> 5)) * 2;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
@@ -207,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 }
             }
             PL_ST(4);   // MFMA + partial image
-            if (!own_store && !direct) {   // hand-off after a barrier: this workgroup's partial tile rows, whole 16-byte chunks, write-through
+            if (!own_store) {   // hand-off after a barrier: this workgroup's partial tile rows, whole 16-byte chunks, write-through
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < NST; ++i) {

@@ -205,7 +205,6 @@ struct pl_handle {
     bool stash_lds = true;      // PAULE_HIP_STASH_LDS: forward stash stores staged through LDS (whole 64-byte row pieces)
     bool xcd_fast16 = true;     // PAULE_HIP_XCD_FAST16: forward same-XCD hand-off for the 16-row kernels
     bool own_store = true;      // PAULE_HIP_OWN_STORE: backward 32-row kernel: every wave hands its own partial tiles over behind their MFMAs
-    bool direct_tiles = false;  // PAULE_HIP_DIRECT_TILES: backward 32-row kernel: partial tiles stored straight from the accumulators (register-native tile layout); measured slower, off
     bool wide_ingest = true;    // PAULE_HIP_WIDE_INGEST: f32 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool wide_ingest16 = true;  // PAULE_HIP_WIDE_INGEST16: 16-row bf16 backward sweep sums the partial tiles with 16-byte loads, wave by wave
     bool pipe_spread = true;    // PAULE_HIP_PIPE_SPREAD: pipelines launch small bf16 16-row sweeps spread over the XCDs (pipe_spread16)
@@ -505,7 +504,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
             s.xchg = h->sweep_xchg;
-            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0) | (h->direct_tiles ? 8 : 0));
+            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
             launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
@@ -752,7 +751,7 @@ void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const voi
             s.dh_ext = sparse_top ? nullptr : md.dh_ext;
             s.dh_last = sparse_top ? dh_last : nullptr;
             s.xchg = ly.xchg;
-            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0) | (h->direct_tiles ? 8 : 0));
+            s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
             s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
             launch_sweep(h, sl, true, Hp, grid, s);
             // dL/dh of the layer below (in place in md.dh_ext: the rows of chunk c are read by layer l before they are written
@@ -1020,7 +1019,7 @@ void acoustic_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const Loss
     for (int l = p.L - 1; l >= 0; --l) slice_p[l] = take_sweep_slice(h, st);
     PipeCtx px(h, st, p.L + e.L);   // stage i < Le: embedder layer Le-1-i; stage Le + i: predictor layer Lp-1-i
     const int grid_p = pipe_grid(h, p, true), grid_e = pipe_grid(h, e, true);
-    const int bwd_flags = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0) | (h->direct_tiles ? 8 : 0));
+    const int bwd_flags = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
     for (int k = 0; k < nc; ++k) {
         const int c = nc - 1 - k;
         const int e0 = (int)((long long)c * Tp / nc), e1 = (int)((long long)(c + 1) * Tp / nc);
@@ -1111,7 +1110,7 @@ void bwd_layer_chunk(pl_handle* h, hipStream_t sl, Model& md, int l, const void*
     s.dh_ext = sparse_top ? nullptr : md.dh_ext;
     s.dh_last = sparse_top ? dh_last : nullptr;
     s.xchg = ly.xchg;
-    s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0) | (h->direct_tiles ? 8 : 0));
+    s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
     s.t0 = t0; s.t1 = t1; s.carry = ly.carry_b;
     launch_sweep(h, sl, true, Hp, pipe_grid(h, md, true), s);
     if (l > 0)
@@ -1925,7 +1924,6 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST16")) h->wide_ingest16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST")) h->wide_ingest = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_OWN_STORE")) h->own_store = std::atoi(z) != 0;
-        if (const char* z = std::getenv("PAULE_HIP_DIRECT_TILES")) h->direct_tiles = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST16")) h->xcd_fast16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_STASH_LDS")) h->stash_lds = std::atoi(z) != 0;
         if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
