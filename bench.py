@@ -189,6 +189,14 @@ def plumbing_only(args, cfg):
         dist.destroy_process_group()
 
 
+def _uses_sweep16(hidden, batch, n_cu=256):
+    """lstm_sweep16_wanted (paule_amd/csrc/lstm_persist16.hip) restated for the kernel name in the roofline object: groups of 16
+    rows when all of them are resident at once, up to 128 rows or, for narrow models, up to half the chip."""
+    hp, bp = -(-hidden // 32) * 32, -(-batch // 16) * 16
+    p, groups = hp // 32, bp // 16
+    return bp <= 16 or (groups * p <= n_cu and (bp <= 128 or groups * p <= n_cu // 2))
+
+
 def source_digest():
     """Digest of the kernel sources: what profiles/traffic.json was measured on (the GPU box has no .git to ask for HEAD)."""
     import hashlib
@@ -351,8 +359,8 @@ def main():
             hp = -(-int(eng.pred_hidden) // 32) * 32   # feature dimensions are padded to multiples of 32
             chained = -(-cfg["batch"] // 16) > 256 // (hp // 16) and os.environ.get("PAULE_HIP_F32_CHAINS", "-1") != "0" and hp in (96, 736)
             kname = "lstm_bwd_chain_f32_kernel" if chained else "lstm_bwd_sweep_f32_kernel"
-        elif -(-cfg["batch"] // 16) * 16 <= 128 and os.environ.get("PAULE_HIP_SWEEP16", "1") != "0" and rs:
-            kname = "lstm_bwd16_rs_sweep_kernel"   # batches of up to 128 rows: the 16-row kernels (what pl_bench_kernel launches there)
+        elif _uses_sweep16(int(eng.pred_hidden), cfg["batch"]) and os.environ.get("PAULE_HIP_SWEEP16", "1") != "0" and rs:
+            kname = "lstm_bwd16_rs_sweep_kernel"   # the 16-row kernels (what pl_bench_kernel launches for this width and batch)
         else:
             kname = "lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel"
         achieved = fl / (ms * 1e-3) / 1e12
