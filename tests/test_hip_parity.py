@@ -846,7 +846,7 @@ def test_long_sequences_bf16_sweeps(HipPlanner):
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_long_sequences_set_a_vs_oracle(HipPlanner, dtype):
     """BASELINE configs[4]'s shape on Paule's default models (set A, H = 720, T = 2000, T' = 1000) against the float64 oracle on
-    the same two utterances, two iterations: the long-form path of cfg5 (one 16-row group, pipelined sweeps of 2000 / 1000 steps)
+    the same two utterances, one iteration (losses, the model gradient through the 2000 / 1000-step recurrences, the updated CP): the long-form path of cfg5 (one 16-row group, pipelined sweeps of 2000 / 1000 steps)
     compared with the reference arithmetic, not only checked for its properties.  f32: the f32 bars; bf16: the bf16 bars."""
     B, T = 2, 2000
     wl = synthetic.make_workload(B, T, "A")
@@ -856,9 +856,9 @@ def test_long_sequences_set_a_vs_oracle(HipPlanner, dtype):
         orc.set_targets(wl.target_mel, wl.target_semvec)
         orc.set_cp(wl.cp0)
         from oracle import manual as mo
-        l1 = _n(orc.step(1))
+        l1 = _n(orc.step(1))   # ONE oracle iteration (~2.5 minutes of float64 torch on the box's cores): loss, gradient, updated CP
         g_model = _n(orc.last_grad) - mo.smoothness_loss_grad(_n(wl.cp0))[3]   # model part of dL/dCP at the first iteration
-        _ORACLE_CACHE["long_set_a"] = (np.concatenate([l1, _n(orc.step(1))]), _n(orc.get_cp()), g_model)
+        _ORACLE_CACHE["long_set_a"] = (l1, _n(orc.get_cp()), g_model)
     lo, cpo, g_model = _ORACLE_CACHE["long_set_a"]
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype=dtype)
     eng.set_targets(wl.target_mel, wl.target_semvec)
@@ -868,15 +868,14 @@ def test_long_sequences_set_a_vs_oracle(HipPlanner, dtype):
     dX = _n(eng.debug_read("dX")).reshape(T, 16, 32)[:, :B, :30].transpose(1, 0, 2)
     g_err = np.linalg.norm(dX - g_model) / np.linalg.norm(g_model)   # through 2000 + 1000 + 1000 recurrent steps each way
     assert g_err <= (1e-4 if dtype == "f32" else 2e-2), g_err
-    lh = np.concatenate([l1, _n(eng.step(1))])
-    eng.synchronize()
+    lh = l1
     dcp = np.abs(_n(eng.get_cp()) - cpo)
     if dtype == "f32":
         np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
         assert dcp.max() <= CP_ATOL_F32
     else:
         np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
-        assert dcp.max() <= 0.5 * 0.01 * 2 and dcp.mean() <= 1e-4, (dcp.max(), dcp.mean())
+        assert dcp.max() <= 0.5 * 0.01 * 2 and dcp.mean() <= 1e-4, (dcp.max(), dcp.mean())   # one Adam step of lr = 0.01
 
 
 def test_minimum_length_and_single_utterance(HipPlanner):
