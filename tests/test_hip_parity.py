@@ -386,6 +386,26 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
 
 
+def test_fused_backward_after_pipelined_forward(HipPlanner, monkeypatch):
+    """PAULE_HIP_FUSED=2: the fused backward launch behind a chunk-pipelined forward pass (small batch, 16-row forward kernels): the
+    backward launch does not care how the stashes were made; the plan stays with the per-layer path's to the bf16 exchange rounding."""
+    B, T, H = 40, 50, 96
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("PAULE_HIP_FUSED", mode)
+        monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        loss = _n(eng.step(6))
+        eng.synchronize()
+        out[mode] = (loss, _n(eng.get_cp()), _n(eng.debug_read("dX")))
+    assert _cos(out["2"][2], out["0"][2]) >= 0.99999
+    np.testing.assert_allclose(out["2"][0], out["0"][0], rtol=1e-4, atol=1e-6)
+    assert np.abs(out["2"][1] - out["0"][1]).max() <= 2e-4
+
+
 @pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720), dict(B=48, T=41, H=96)])
 def test_fused_backward_matches_per_layer_path(HipPlanner, monkeypatch, shape):
     """The fused backward launch (PAULE_HIP_FUSED=3: embedder recurrences, their dL/dh product and the backward mel head in
