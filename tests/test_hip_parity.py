@@ -386,6 +386,35 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
 
 
+@pytest.mark.parametrize("extra", [dict(objective="semvec"), dict(objective="acoustic_semvec", smiling=True)])
+def test_fused_launches_other_objectives_vs_oracle(HipPlanner, extra):
+    """The fused forward + backward launches (the default at 64 rows) under the `semvec` objective (no mel term: the backward mel
+    head starts from the embedder's gradient alone) and with the smiling projection: model gradient of the first iteration against
+    the exact float64 oracle (<= 2 %), and the plan after 6 iterations against the torch oracle at the bf16 bars."""
+    from oracle import manual as mo
+    B, T, H = 64, 40, 96
+    objective, smiling = extra["objective"], extra.get("smiling", False)
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    ex = mo.ManualPlanner(wl.pred_sd, wl.emb_sd, objective=objective, smiling=smiling)
+    ex.set_targets(wl.target_mel.numpy(), wl.target_semvec.numpy())
+    ex.set_cp(wl.cp0.numpy())
+    _, _, px = mo.loss_and_grad(ex.models, objective, ex.x, ex.target_mel, ex.target_semvec)
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective=objective, dtype="bf16", smiling=smiling)
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    l1 = _n(eng.step(1))
+    eng.synchronize()
+    dX = _n(eng.debug_read("dX")).reshape(T, B, 32)[:, :, :30].transpose(1, 0, 2)
+    err = np.linalg.norm(dX - px["grad_model"]) / np.linalg.norm(px["grad_model"])
+    assert err <= 2e-2, err
+    lh = np.concatenate([l1, _n(eng.step(5))])
+    eng.synchronize()
+    lo = ex.step(6)
+    np.testing.assert_allclose(lh[:, :, :6], lo[:, :, :6], rtol=LOSS_RTOL_BF16, atol=5e-3)
+    d = np.abs(_n(eng.get_cp()) - ex.get_cp())
+    assert d.mean() <= 0.05 * 0.01 * 6 and d.max() <= 0.5 * 0.01 * 6, (d.mean(), d.max())
+
+
 def test_fused_backward_after_pipelined_forward(HipPlanner, monkeypatch):
     """PAULE_HIP_FUSED=2: the fused backward launch behind a chunk-pipelined forward pass (small batch, 16-row forward kernels): the
     backward launch does not care how the stashes were made; the plan stays with the per-layer path's to the bf16 exchange rounding."""
