@@ -386,7 +386,8 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
 
 
-@pytest.mark.parametrize("extra", [dict(objective="semvec"), dict(objective="acoustic_semvec", smiling=True)])
+@pytest.mark.parametrize("extra", [dict(objective="semvec"), dict(objective="acoustic_semvec", smiling=True),
+                                   dict(objective="acoustic_semvec", classifier=True, past=True)])
 def test_fused_launches_other_objectives_vs_oracle(HipPlanner, extra):
     """The fused forward + backward launches (the default at 64 rows) under the `semvec` objective (no mel term: the backward mel
     head starts from the embedder's gradient alone) and with the smiling projection: model gradient of the first iteration against
@@ -398,10 +399,17 @@ def test_fused_launches_other_objectives_vs_oracle(HipPlanner, extra):
     ex = mo.ManualPlanner(wl.pred_sd, wl.emb_sd, objective=objective, smiling=smiling)
     ex.set_targets(wl.target_mel.numpy(), wl.target_semvec.numpy())
     ex.set_cp(wl.cp0.numpy())
-    _, _, px = mo.loss_and_grad(ex.models, objective, ex.x, ex.target_mel, ex.target_semvec)
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective=objective, dtype="bf16", smiling=smiling)
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
+    if extra.get("classifier"):   # the speech-classifier term (its gradient joins dL/dY in front of the backward mel head) and a fixed past
+        gen = torch.Generator().manual_seed(3)
+        clf = {"linear.weight": torch.randn(1, 60, generator=gen, dtype=torch.float64) * 0.2, "linear.bias": torch.tensor([0.1], dtype=torch.float64)}
+        past = wl.cp0[0, :6].clone()
+        for pl in (ex, eng):
+            pl.set_speech_classifier(clf)
+            pl.set_past_cp(past if pl is eng else past.numpy())
+    _, _, px = mo.loss_and_grad(ex.models, objective, ex.x, ex.target_mel, ex.target_semvec, ex.classifier)
     l1 = _n(eng.step(1))
     eng.synchronize()
     dX = _n(eng.debug_read("dX")).reshape(T, B, 32)[:, :, :30].transpose(1, 0, 2)
@@ -410,7 +418,7 @@ def test_fused_launches_other_objectives_vs_oracle(HipPlanner, extra):
     lh = np.concatenate([l1, _n(eng.step(5))])
     eng.synchronize()
     lo = ex.step(6)
-    np.testing.assert_allclose(lh[:, :, :6], lo[:, :, :6], rtol=LOSS_RTOL_BF16, atol=5e-3)
+    np.testing.assert_allclose(lh[:, :, :7], lo[:, :, :7], rtol=LOSS_RTOL_BF16, atol=5e-3)
     d = np.abs(_n(eng.get_cp()) - ex.get_cp())
     assert d.mean() <= 0.05 * 0.01 * 6 and d.max() <= 0.5 * 0.01 * 6, (d.mean(), d.max())
 
