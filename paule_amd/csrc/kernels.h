@@ -70,6 +70,7 @@ struct LstmSweepArgs {
     int n_valid;
     int stash_via_lds;     // forward, 32-row kernel: 1 = the five stash arrays leave through LDS as 64-byte row pieces
     int chains;            // lstm_chain_f32.hip: batch groups a workgroup serves in turn with one copy of its weights
+    int bwd_waves;         // lstm_persist_rs.hip: waves per workgroup, 4 or 8 (0 = 8, the default; PAULE_HIP_BWD_WAVES)
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit

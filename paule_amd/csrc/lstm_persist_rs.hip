@@ -18,19 +18,26 @@
 
 namespace pl {
 
-template <int KS>   // KS = Hp / 16
-__global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs a) {
+// NW = waves per workgroup.  4: one wave per SIMD, a wave owns N tiles w, w + 4, ...  8 (round 3, the default): waves 0 .. 3 do
+// what they did (poll, ingest, cell update: same threads, same summation order), and the tile products are dealt over EIGHT
+// waves, two per SIMD -- a tile's epilogue (accumulators -> bf16 -> LDS -> read-back by rows -> hand-off stores) is a dependent
+// chain that leaves the matrix pipe idle, and the SIMD's other wave now multiplies meanwhile.  A tile is still produced by one
+// wave with the same 8 MFMAs, so the results are bit-identical to NW = 4.
+template <int KS, int NW>   // KS = Hp / 16
+__global__ __launch_bounds__(64 * NW, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs a) {
     constexpr int Hp = 16 * KS;
     constexpr int P = Hp / 32;                   // slices = N tiles of 32 hidden units
-    constexpr int NT = (P + 3) / 4;              // N tiles per wave (wave w: tiles w, w + 4, ...)
+    constexpr int NT = (P + NW - 1) / NW;        // N tiles per wave (wave w: tiles w, w + NW, ...)
     constexpr int DRS = 128 * 2 + 16;            // dA^T image: [32 batch rows][128 local gate rows] bf16, odd chunk stride
     constexpr int ORS = Hp * 2 + 16;             // partial image: [32 batch rows][Hp] bf16
-    constexpr int NST = (P * 128 + 255) / 256;   // hand-off stores (16 B) per thread per step
+    constexpr int NTH = 64 * NW;
+    constexpr int NST = (P * 128 + NTH - 1) / NTH;   // hand-off stores (16 B) per thread per step
     __shared__ __attribute__((aligned(16))) unsigned char da_img[32 * DRS];
     __shared__ __attribute__((aligned(16))) unsigned char out_img[32 * ORS];
     __shared__ int lds_flag;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool cellw = wave < 4;                 // the waves that own cells (a scalar condition: whole waves)
     const int n_res = gridDim.x / P;
     const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
     const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
@@ -43,15 +50,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
     uint4 wreg[NT][8];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int nt = wave + 4 * i;
+        const int nt = wave + NW * i;
         const int n = 32 * (nt < P ? nt : 0) + (lane & 31);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             wreg[i][ks] = *reinterpret_cast<const uint4*>(WT + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
     }
 
-    // cell ownership: thread -> batch row (tid >> 3), hidden units 32p + 4 (tid & 7) .. +3
-    const int erow = tid >> 3, jq = tid & 7;
+    // cell ownership (threads of waves 0 .. 3): thread -> batch row (tid >> 3), hidden units 32p + 4 (tid & 7) .. +3
+    const int erow = (tid & 255) >> 3, jq = tid & 7;
     const int j = 32 * p + 4 * jq;
     PL_ST_DECL
     const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
 
     for (int g = g_first; g < n_groups; g += n_res) {
         const int b = gs * g + erow;
-        const bool ok = erow < gs && b < Bp;
+        const bool ok = erow < gs && b < Bp;   // (waves 0 .. 3)
         const int bc = ok ? b : Bp - 1;
         float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
         int* xtab = a.xcc_tab + (size_t)g * 64;
@@ -77,16 +84,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
 
         for (int t = T - 1; t >= 0; --t) {
             // stash operands of this step (written by the forward launch): plain loads, issued before the wait
-            const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
-            uint2 sg[4];
+            uint2 sg[4] = {}, sc = make_uint2(0u, 0u), scp = make_uint2(0u, 0u), sdh = make_uint2(0u, 0u);
+            if (cellw) {
+                const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
-            const uint2 sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
-            uint2 scp = make_uint2(0u, 0u);
-            if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
-            uint2 sdh = make_uint2(0u, 0u);
-            if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
-            else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
+                for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+                sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+                if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
+                if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
+                else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
+            }
 
             float dh[4];
             unpack_bf16x4(sdh, dh);
@@ -95,54 +102,56 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 if (!wait_arrivals(cnt + (size_t)(t + 1) * a.flag_stride, P, plain_handoff, a.status, &lds_flag, a.spin_ticks, a.poll_mask)) return;
                 if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
                 PL_ST(1);
-                // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)
-                const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
-                const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
-                const unsigned o0 = (unsigned)((erow * 32 + 4 * jq) * 2);
-                u32x2 pv[P];
+                if (cellw) {
+                    // sum the P partial tiles of step t+1 that belong to this thread's cells (sc1 loads: handed-off bytes)
+                    const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+                    const unsigned o0 = (unsigned)((erow * 32 + 4 * jq) * 2);
+                    u32x2 pv[P];
 #pragma unroll
-                for (int s = 0; s < P; ++s)
-                    pv[s] = plain_handoff ? __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxNt)
-                                          : __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
+                    for (int s = 0; s < P; ++s)
+                        pv[s] = plain_handoff ? __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxNt)
+                                              : __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
 #pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    float f[4];
-                    unpack_bf16x4(make_uint2(pv[s][0], pv[s][1]), f);
-                    dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+                    for (int s = 0; s < P; ++s) {
+                        float f[4];
+                        unpack_bf16x4(make_uint2(pv[s][0], pv[s][1]), f);
+                        dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+                    }
                 }
             }
             PL_ST(2);   // partial ingest
 
-            float gi[4], gf[4], gg[4], go[4], c[4], cp[4];
-            unpack_bf16x4(sg[0], gi);
-            unpack_bf16x4(sg[1], gf);
-            unpack_bf16x4(sg[2], gg);
-            unpack_bf16x4(sg[3], go);
-            unpack_bf16x4(sc, c);
-            unpack_bf16x4(scp, cp);
-            float dai[4], daf[4], dag[4], dao[4];
+            if (cellw) {
+                float gi[4], gf[4], gg[4], go[4], c[4], cp[4];
+                unpack_bf16x4(sg[0], gi);
+                unpack_bf16x4(sg[1], gf);
+                unpack_bf16x4(sg[2], gg);
+                unpack_bf16x4(sg[3], go);
+                unpack_bf16x4(sc, c);
+                unpack_bf16x4(scp, cp);
+                float dai[4], daf[4], dag[4], dao[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
-            const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
-            const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
-            if (ok) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
-                bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
-                *reinterpret_cast<uint2*>(go_) = pi;
-                *reinterpret_cast<uint2*>(go_ + Hp) = pf;
-                *reinterpret_cast<uint2*>(go_ + 2 * Hp) = pg;
-                *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
+                for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
+                const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
+                const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
+                if (ok) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                    bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                    *reinterpret_cast<uint2*>(go_) = pi;
+                    *reinterpret_cast<uint2*>(go_ + Hp) = pf;
+                    *reinterpret_cast<uint2*>(go_ + 2 * Hp) = pg;
+                    *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
+                }
+                if (t > 0) {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
+                    unsigned char* drow = da_img + erow * DRS + jq * 8;
+                    *reinterpret_cast<uint2*>(drow) = pi;
+                    *reinterpret_cast<uint2*>(drow + 64) = pf;
+                    *reinterpret_cast<uint2*>(drow + 128) = pg;
+                    *reinterpret_cast<uint2*>(drow + 192) = po;
+                }
             }
             if (t == 0) break;   // nobody consumes the partials of step 0
             if (t == T - 1 && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-            // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
-            {
-                unsigned char* drow = da_img + erow * DRS + jq * 8;
-                *reinterpret_cast<uint2*>(drow) = pi;
-                *reinterpret_cast<uint2*>(drow + 64) = pf;
-                *reinterpret_cast<uint2*>(drow + 128) = pg;
-                *reinterpret_cast<uint2*>(drow + 192) = po;
-            }
             __syncthreads();
             PL_ST(3);   // cell + stash stores + dA image
             uint4 bfr[8];
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
             const bool own_store = (a.stash_via_lds & 2) != 0;   // A/B: every wave hands its own tiles over right behind their MFMAs
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const int nt = wave + 4 * i;
+                const int nt = wave + NW * i;
                 if (nt >= P) break;
                 f32x16 acc;
 #pragma unroll
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_rs_sweep_kernel(LstmSweepArgs
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < NST; ++i) {
-                    const int e = tid + 256 * i;      // 16-byte chunk: destination e / 128, row (e % 128) / 4, quarter e % 4
+                    const int e = tid + NTH * i;      // 16-byte chunk: destination e / 128, row (e % 128) / 4, quarter e % 4
                     if (e < P * 128) {
                         const int dst = e >> 7, r = (e & 127) >> 2, c4 = e & 3;
                         const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (32 * dst + 8 * c4) * 2);
@@ -216,10 +225,13 @@ size_t lstm_rs_exchange_bytes(int Hp, int Bp) {
 }
 
 void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a) {
-#define PL_CASE(K)                                                                                   \
-    if (Hp == 16 * K) {                                                                              \
-        hipLaunchKernelGGL(lstm_bwd_rs_sweep_kernel<K>, dim3(grid), dim3(256), 0, stream, a);        \
-        return;                                                                                      \
+#define PL_CASE(K)                                                                                        \
+    if (Hp == 16 * K) {                                                                                   \
+        if (a.bwd_waves == 4)                                                                             \
+            hipLaunchKernelGGL((lstm_bwd_rs_sweep_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a);    \
+        else                                                                                              \
+            hipLaunchKernelGGL((lstm_bwd_rs_sweep_kernel<K, 8>), dim3(grid), dim3(512), 0, stream, a);    \
+        return;                                                                                           \
     }
     PL_SWEEP_KS_LIST(PL_CASE)
 #undef PL_CASE

@@ -199,6 +199,7 @@ struct pl_handle {
                                 // hand-off is half lines per workgroup and reads back slower from L2 than from the memory side (+1 %)
     int bwd_mode = 1;           // backward sweep: 1 reduce-scatter of partial dh tiles (default: 8.5 % faster iteration with the
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
+    int bwd_waves = 8;          // PAULE_HIP_BWD_WAVES: waves per workgroup of the reduce-scatter backward sweep (4: one per SIMD, round 2's form)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
     int f32_chains = -1;        // PAULE_HIP_F32_CHAINS: f32 batches of more groups than fit the chip: -1 auto, 0 off (groups take turns / launch-per-step), N forced
@@ -391,8 +392,11 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
     }
     else if (use_sweep16(h, Hp, bwd))
         launch_lstm_sweep16(st, bwd, Hp, grid, s);
-    else if (bwd && h->bwd_mode == 1 && h->sweep_xchg)
-        launch_lstm_bwd_rs_sweep(st, Hp, grid, s);
+    else if (bwd && h->bwd_mode == 1 && h->sweep_xchg) {
+        LstmSweepArgs s8 = s;
+        s8.bwd_waves = h->bwd_waves;
+        launch_lstm_bwd_rs_sweep(st, Hp, grid, s8);
+    }
     else
         launch_lstm_sweep(st, bwd, Hp, grid, s);
 }
@@ -1914,6 +1918,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->use_sweep = !(env && env[0] == '1');
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
