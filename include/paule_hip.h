@@ -57,7 +57,10 @@ enum { PL_MODEL_PRED = 0 /* ForwardModel, paule/models.py:326 */,
 
 /* columns of one loss_log row (weighted sub-losses as logged at paule/paule.py:942-945, :988-992) */
 enum { PL_LOSS_TOTAL = 0, PL_LOSS_MEL = 1, PL_LOSS_SEMVEC = 2, PL_LOSS_VEL = 3, PL_LOSS_JERK = 4,
-       PL_LOSS_LOCAL_LINEAR = 5, PL_LOSS_SPEECH_CLASSIFIER = 6 /* 0 unless pl_set_speech_classifier */, PL_LOSS_RESERVED = 7,
+       PL_LOSS_LOCAL_LINEAR = 5, PL_LOSS_SPEECH_CLASSIFIER = 6 /* 0 unless pl_set_speech_classifier */,
+       /* with somatosensory feedback (pl_config.cp_tube_layers > 0; it excludes the speech classifier, paule/paule.py:117-118):
+        * the tube path's weighted mel and semvec terms (paule/paule.py:624-644, weights :598-599) */
+       PL_LOSS_TUBE_MEL = 6, PL_LOSS_TUBE_SEMVEC = 7,
        PL_LOSS_COLS = 8 };
 
 typedef struct pl_handle pl_handle;
@@ -157,7 +160,9 @@ int pl_step(pl_handle *h, int n_iters, float *loss_log, float *grad_out);
  * (one workgroup per CU; the fused acoustic launches take up to all 256 CUs).  They finish only when all their workgroups
  * are resident at the same time.  Handles of ONE process are safe: every entry point that launches sweeps chains behind the
  * previous one on the same device, whatever stream it runs on.  A SECOND process on the same GPU can hold CUs a launch is
- * waiting for: both then run into the bounded wait (PAULE_HIP_SPIN_MS, default 2 s) and this call returns PL_ERR_HIP -- the
+ * waiting for.  The role-fused launches notice that at their top -- every workgroup signs in and waits at most
+ * PAULE_HIP_CENSUS_MS (50 ms) for the others -- and this call returns PL_ERR_STATE; the per-layer sweeps run into the
+ * bounded wait (PAULE_HIP_SPIN_MS, default 2 s) and this call returns PL_ERR_HIP.  Either way the
  * plan of that pl_step is not valid, call pl_set_cp / pl_reset_optimizer and step again once the GPU is yours.  Host code
  * must call this (or pl_get_cp, which a caller follows with it) before it trusts results: the Python layers do
  * (Paule.plan_resynth, plan_sharded). */
@@ -260,12 +265,26 @@ int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems,
 enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1,
        /* persistent sweeps: one launch = all T steps of layer 0 (+ its ~5 us counter-zeroing launch); FLOPs = 2*B*4H*H*(T-1) */
        PL_KERNEL_LSTM_FWD_SWEEP = 2, PL_KERNEL_LSTM_BWD_SWEEP = 3,
-       /* the fused acoustic forward launch (predictor + mel head + embedder layers as roles of one grid; bf16, batches of 129+
+       /* the fused acoustic forward launch (predictor + mel head + embedder layers as roles of one grid; bf16, batches of 49+
         * rows): one launch = all steps of all its layers (+ the flag-zeroing launch); FLOPs = 2 * B * sum over layers of
         * 4H (in + H) T_layer + 2 * B * H * mel_dim * T; PL_ERR_UNSUPPORTED when the handle does not use it; model_id ignored */
        PL_KERNEL_FUSED_FWD = 4 };
 int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg_ms_out /* host */,
                     double *flops_per_launch_out /* host */);
+
+/* Which launch schedule the handle planned for its shapes (host array of n >= 0 ints; entries beyond PL_PLAN_COUNT read 0).
+ * Test / measurement aid: the planner declines the role-fused launches silently on many conditions (CU budget, model
+ * widths, batch below the crossover ...), and a parity test that compares "fused" with "per layer" must be able to tell
+ * that the fused launch really ran.  No reference counterpart (the reference has one schedule: torch's). */
+enum { PL_PLAN_FUSED_FWD = 0,      /* 1: role-fused forward launch, 0: per-layer forward sweeps / pipelines */
+       PL_PLAN_FUSED_BWD = 1,      /* 1: role-fused backward launch */
+       PL_PLAN_FWD_CHAINS_PRED = 2, PL_PLAN_FWD_CHAINS_EMB = 3,   /* batch groups per workgroup of the forward roles */
+       PL_PLAN_BWD_CHAINS_PRED = 4, PL_PLAN_BWD_CHAINS_EMB = 5,
+       PL_PLAN_FWD_WORKGROUPS = 6, PL_PLAN_BWD_WORKGROUPS = 7,    /* role-bearing workgroups of the fused launches */
+       PL_PLAN_BWD_WAVES = 8,      /* waves per workgroup of the per-layer reduce-scatter backward sweep (4 or 8) */
+       PL_PLAN_N_CU = 9,
+       PL_PLAN_COUNT = 10 };
+int pl_plan_info(const pl_handle *h, int32_t *out /* host */, int n);
 
 /* Bytes of device memory held by the handle. */
 int64_t pl_device_bytes(const pl_handle *h);

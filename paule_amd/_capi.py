@@ -24,7 +24,7 @@ PL_LOSS_COLS = 8
 EXPORTED_SYMBOLS = (
     "pl_default_config", "pl_create", "pl_destroy", "pl_set_lstm_weights", "pl_set_linear",
     "pl_set_speech_classifier", "pl_set_targets", "pl_set_cp", "pl_set_past_cp", "pl_reset_optimizer", "pl_step", "pl_synchronize", "pl_get_cp",
-    "pl_get_pred", "pl_get_pred_frames", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_device_bytes", "pl_flops_per_iteration",
+    "pl_get_pred", "pl_get_pred_frames", "pl_get_tube_pred", "pl_embed_tube", "pl_embed_mel", "pl_debug_read", "pl_bench_kernel", "pl_plan_info", "pl_device_bytes", "pl_flops_per_iteration",
     "pl_train_pred_step", "pl_reset_pred_optimizer", "pl_get_lstm_weights", "pl_get_linear",
     "pl_set_inverse_conv", "pl_inverse_forward", "pl_set_embedder_output", "pl_set_embedder_conv",
     "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
@@ -117,6 +117,8 @@ def load_library(path: str | None = None):
     lib.pl_get_model_optimizer_step.restype = C.c_int64
     lib.pl_get_model_optimizer_step.argtypes = [vp, C.c_int]
     lib.pl_set_model_optimizer_step.argtypes = [vp, C.c_int, C.c_int64]
+    lib.pl_plan_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
+    lib.pl_plan_info.restype = C.c_int
     lib.pl_device_bytes.restype = C.c_int64
     lib.pl_device_bytes.argtypes = [vp]
     lib.pl_flops_per_iteration.restype = C.c_double

@@ -71,6 +71,8 @@ struct LstmSweepArgs {
     int stash_via_lds;     // forward, 32-row kernel: 1 = the five stash arrays leave through LDS as 64-byte row pieces
     int chains;            // lstm_chain_f32.hip: batch groups a workgroup serves in turn with one copy of its weights
     int bwd_waves;         // lstm_persist_rs.hip: waves per workgroup, 4 or 8 (0 = 8, the default; PAULE_HIP_BWD_WAVES)
+    int* tflags;           // lstm_persist_rs.hip, streamed form: per-tile flags [2 slots][groups][P destinations][32] (zeroed with the
+                           // counters); null = the whole-workgroup hand-off (one flag per workgroup and step)
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit

@@ -217,6 +217,245 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_bwd_rs_sweep_kernel(LstmSweep
     PL_ST_DUMP(a.stamps);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Streamed form of the reduce-scatter (round 3, the default).  In the kernel above a step is a chain of whole-workgroup phases:
+// all tiles -> drain -> barrier -> ONE flag -> (consumers) poll -> 23 tile loads -> cell -> tiles ...; the last tile's way to its
+// consumer starts only when the slowest wave of the producer has drained, and the consumer's 47 KB of tile loads start only when
+// the last producer has signalled (profiles/r03_sweep_phase_stamps.txt: 1.49 us wait + 1.13 us ingest of a 4.55-us step).  Here
+// every 32 x 32 tile travels on its own:
+//   * a tile is produced by ONE wave, so that wave alone drains its two stores (counted vmcnt, one tile behind: the wait sits under
+//     the next tile's MFMAs) and raises the tile's OWN flag -- tflags[slot][group][destination][source] = step + 1;
+//   * source p produces its tiles in the rotated order destination p + 1, p + 2, ... (mod P), eight waves at a time, so every
+//     destination receives about a third of its tiles per round instead of all of them in one round (destination 20 would get all 23
+//     in the last round and hold the whole group up);
+//   * the four cell-owning waves of a destination poll the 23 flags of their destination with one wave instruction, load whatever
+//     has newly arrived, and poll again -- two thirds of the ingest is under way by the time the last round's flags come up.
+// Same tiles, same 8 MFMAs per tile, same fixed-order sum over the sources: bit-identical to the kernel above.  One workgroup
+// barrier per step (the dA image is double-buffered); hand-off rules as before (write-through sc1 both sides, or plain / nt through
+// the shared L2 for a group that verified it sits on one XCD); every spin bounded.
+template <int KS>
+__global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int P = Hp / 32;
+    constexpr int NW = 8;
+    constexpr int NT = (P + NW - 1) / NW;
+    constexpr int DRS = 128 * 2 + 16;
+    constexpr int ORS = Hp * 2 + 16;
+    static_assert(P <= 32, "one flag word per source in a 32-int row");
+    __shared__ __attribute__((aligned(16))) unsigned char da_img[2][32 * DRS];
+    __shared__ __attribute__((aligned(16))) unsigned char out_img[32 * ORS];
+    __shared__ int lds_flag, lds_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool cellw = wave < 4;
+    const int n_res = gridDim.x / P;
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int gs = a.group_rows;
+    const int n_groups = (Bp + gs - 1) / gs;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);   // Whh^T packed [Hp][4*Hp]
+
+    // this wave's tiles: positions k = wave + 8 i of the rotated order, destination (p + 1 + k) mod P
+    uint4 wreg[NT][8];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int k = wave + NW * i;
+        const int nt = k < P ? (p + 1 + k) % P : 0;
+        const int n = 32 * nt + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            wreg[i][ks] = *reinterpret_cast<const uint4*>(WT + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
+    }
+
+    const int erow = (tid & 255) >> 3, jq = tid & 7;
+    const int j = 32 * p + 4 * jq;
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(a.G);
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(a.c);
+    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(a.dh_ext);
+    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(a.dh_last);
+    bf16_t* __restrict__ X = static_cast<bf16_t*>(a.xchg);
+    constexpr size_t TILE = 32 * 32;
+    const size_t grp_stride = (size_t)P * P * TILE;
+    const size_t slot_stride = (size_t)n_groups * grp_stride;
+    if (tid == 0) lds_abort = 0;
+    __syncthreads();
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = gs * g + erow;
+        const bool ok = erow < gs && b < Bp;
+        const int bc = ok ? b : Bp - 1;
+        float dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
+        // tile flags [2 slots][groups][P destinations][32]: the row of destination d holds one word per source
+        int* const tf = a.tflags;
+
+        for (int t = T - 1; t >= 0; --t) {
+            uint2 sg[4] = {}, sc = make_uint2(0u, 0u), scp = make_uint2(0u, 0u), sdh = make_uint2(0u, 0u);
+            if (cellw) {
+                const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+                sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+                if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
+                if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
+                else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
+            }
+            float dh[4];
+            unpack_bf16x4(sdh, dh);
+            PL_ST(0);
+            if (t + 1 < T) {
+                if (cellw) {
+                    // The P tiles of step t + 1 for this workgroup's units, loaded as their flags come up: each cell wave polls the row
+                    // of its destination with one wave instruction and issues the loads of whatever is new.  (vmcnt retires in order, so
+                    // a poll's answer is seen after the tile loads issued before it have landed -- loads that are needed anyway.
+                    // Measured and dropped: a fifth wave that only polls and hands the arrival mask round through LDS -- its polls
+                    // queue behind the cell waves' tile loads in the CU's memory pipe, 5.54 vs 5.22 ms per iteration.)
+                    const int token = t + 2;
+                    const int* frow = tf + ((size_t)((t + 1) & 1) * n_groups + g) * P * 32 + (size_t)p * 32;
+                    const __amdgpu_buffer_rsrc_t rf = make_rsrc(frow, (unsigned)(P * 4));
+                    const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+                    const unsigned o0 = (unsigned)((erow * 32 + 4 * jq) * 2);
+                    constexpr unsigned full = P == 32 ? 0xffffffffu : ((1u << P) - 1u);
+                    unsigned issued = 0;
+                    u32x2 pv[P];
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 1;; ++spin) {
+                        int v = 0;
+                        if (lane < P)
+                            v = plain_handoff ? (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxNt)
+                                              : (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
+                        const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(v == token) & full;
+                        const unsigned newly = (unsigned)__builtin_amdgcn_readfirstlane((int)(mask & ~issued));
+#pragma unroll
+                        for (int s = 0; s < P; ++s)
+                            if ((newly >> s) & 1u)
+                                pv[s] = plain_handoff ? __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxNt)
+                                                      : __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
+                        issued |= newly;
+                        if (issued == full) break;
+                        if ((spin & a.poll_mask) == 0 &&
+                            (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0 ||
+                             __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks)) {
+                            if (lane == 0) {
+                                __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                lds_abort = 1;
+                            }
+#pragma unroll
+                            for (int s = 0; s < P; ++s)
+                                if (!((issued >> s) & 1u)) pv[s] = u32x2{0u, 0u};
+                            break;
+                        }
+                    }
+                    PL_ST(1);   // polls + tile loads issued
+#pragma unroll
+                    for (int s = 0; s < P; ++s) {
+                        float f[4];
+                        unpack_bf16x4(make_uint2(pv[s][0], pv[s][1]), f);
+                        dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+                    }
+                }
+                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+            }
+            PL_ST(2);   // tiles landed + sums
+
+            unsigned char* const dimg = da_img[t & 1];
+            if (cellw) {
+                float gi[4], gf[4], gg[4], go[4], c[4], cp[4];
+                unpack_bf16x4(sg[0], gi);
+                unpack_bf16x4(sg[1], gf);
+                unpack_bf16x4(sg[2], gg);
+                unpack_bf16x4(sg[3], go);
+                unpack_bf16x4(sc, c);
+                unpack_bf16x4(scp, cp);
+                float dai[4], daf[4], dag[4], dao[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
+                const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
+                const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
+                if (ok) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                    bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                    *reinterpret_cast<uint2*>(go_) = pi;
+                    *reinterpret_cast<uint2*>(go_ + Hp) = pf;
+                    *reinterpret_cast<uint2*>(go_ + 2 * Hp) = pg;
+                    *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
+                }
+                if (t > 0) {
+                    unsigned char* drow = dimg + erow * DRS + jq * 8;
+                    *reinterpret_cast<uint2*>(drow) = pi;
+                    *reinterpret_cast<uint2*>(drow + 64) = pf;
+                    *reinterpret_cast<uint2*>(drow + 128) = pg;
+                    *reinterpret_cast<uint2*>(drow + 192) = po;
+                }
+            }
+            if (t == 0) break;   // nobody consumes the partials of step 0
+            if (t == T - 1 && tid == 0) {   // this workgroup's XCD, in place before ANY of its flags (they are raised behind the barrier below)
+                __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(lds_abort) != 0) return;
+            PL_ST(3);   // cell + stash stores + dA image + barrier
+            uint4 bfr[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                bfr[ks] = *reinterpret_cast<const uint4*>(dimg + (lane & 31) * DRS + ks * 32 + (lane >> 5) * 16);
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            int* const fcol = tf + ((size_t)(t & 1) * n_groups + g) * P * 32 + p;   // + 32 * destination
+            const __amdgpu_buffer_rsrc_t rfl = make_rsrc(fcol, (unsigned)(((P - 1) * 32 + 1) * 4));
+            auto raise = [&](int nt) {   // the wave's own stores of that tile are acknowledged: its flag
+                if (lane == 0) {
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), rfl, (unsigned)(nt * 32 * 4), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), rfl, (unsigned)(nt * 32 * 4), 0, kAuxSc1);
+                }
+            };
+            int nt_prev = -1;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int k = wave + NW * i;
+                if (k >= P) break;
+                const int nt = (p + 1 + k) % P;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+                unsigned char* orow = out_img + (lane & 31) * ORS + (32 * nt + 4 * (lane >> 5)) * 2;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<uint2*>(orow + rg * 16) = pack_bf16x4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cidx = lane + 64 * q, r = cidx >> 2, c4 = cidx & 3;
+                    const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (32 * nt + 8 * c4) * 2);
+                    u32x4 d;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    const unsigned off = (unsigned)(((size_t)nt * P * TILE + cidx * 8) * 2);
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                }
+                if (nt_prev >= 0) {   // the tile before: all but this tile's two stores have been acknowledged
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    raise(nt_prev);
+                }
+                nt_prev = nt;
+            }
+            if (nt_prev >= 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise(nt_prev);
+            }
+            PL_ST(4);   // tiles + flags
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
 #define PL_SWEEP_KS_LIST(X) X(2) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(46) X(48)
 
 size_t lstm_rs_exchange_bytes(int Hp, int Bp) {
@@ -227,7 +466,9 @@ size_t lstm_rs_exchange_bytes(int Hp, int Bp) {
 void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a) {
 #define PL_CASE(K)                                                                                        \
     if (Hp == 16 * K) {                                                                                   \
-        if (a.bwd_waves == 4)                                                                             \
+        if (a.tflags && a.bwd_waves != 4 && K <= 64)                                                      \
+            hipLaunchKernelGGL(lstm_bwd_rs_stream_kernel<(K <= 64 ? K : 2)>, dim3(grid), dim3(512), 0, stream, a); \
+        else if (a.bwd_waves == 4)                                                                        \
             hipLaunchKernelGGL((lstm_bwd_rs_sweep_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a);    \
         else                                                                                              \
             hipLaunchKernelGGL((lstm_bwd_rs_sweep_kernel<K, 8>), dim3(grid), dim3(512), 0, stream, a);    \

@@ -199,6 +199,7 @@ struct pl_handle {
                                 // hand-off is half lines per workgroup and reads back slower from L2 than from the memory side (+1 %)
     int bwd_mode = 1;           // backward sweep: 1 reduce-scatter of partial dh tiles (default: 8.5 % faster iteration with the
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
+    bool bwd_stream = true;     // PAULE_HIP_BWD_STREAM: reduce-scatter backward sweep with per-tile flags and streamed ingest (lstm_persist_rs.hip)
     int bwd_waves = 8;          // PAULE_HIP_BWD_WAVES: waves per workgroup of the reduce-scatter backward sweep (4: one per SIMD, round 2's form)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
@@ -395,6 +396,8 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
     else if (bwd && h->bwd_mode == 1 && h->sweep_xchg) {
         LstmSweepArgs s8 = s;
         s8.bwd_waves = h->bwd_waves;
+        // per-tile flags of the streamed hand-off: behind the XCD-id table of the same flag slice (zeroed with it)
+        s8.tflags = h->bwd_stream && s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T) ? s.xcc_tab + (size_t)((h->Bp + 7) / 8) * 64 : nullptr;
         launch_lstm_bwd_rs_sweep(st, Hp, grid, s8);
     }
     else
@@ -1919,6 +1922,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
+        if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
@@ -1996,7 +2000,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         for (Model* md : {&h->tube, &h->tmel, &h->temb})
             if (md->L > 0 && md->Hp / slice > pmax) pmax = md->Hp / slice;
         h->flag_stride = (pmax + 15) / 16 * 16;
-        const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64;   // arrival flags, then the XCD-id table
+        // arrival flags, then the XCD-id table, then (bf16) the per-tile flags of the streamed backward hand-off [2][groups][P][32]
+        const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64 + (h->dt == BF16 ? 2 * n_groups_max * (size_t)pmax * 32 : 0);
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
         // forward + backward sweep of every layer of an iteration, + the head / projection roles of the fused launches
         h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers) +
@@ -2775,6 +2780,25 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
 }
 
 int64_t pl_device_bytes(const pl_handle* h) { return h ? (int64_t)h->bytes : 0; }
+
+int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
+    if (!h || !out || n < 0) return fail(PL_ERR_INVALID, "pl_plan_info: null handle / output");
+    const int32_t v[PL_PLAN_COUNT] = {
+        h->fused_fwd_ok ? 1 : 0,
+        h->fused_bwd_ok ? 1 : 0,
+        h->fused_fwd_ok ? h->fused_Cp : 0,
+        h->fused_fwd_ok ? h->fused_Ce : 0,
+        h->fused_bwd_ok ? h->fused_Cp : 0,
+        h->fused_bwd_ok ? h->fused_Ce : 0,
+        h->fused_fwd_ok ? h->fused_active_fwd : 0,
+        h->fused_bwd_ok ? h->fused_active_bwd : 0,
+        h->bwd_waves,
+        h->n_cu,
+    };
+    for (int i = 0; i < n && i < PL_PLAN_COUNT; ++i) out[i] = v[i];
+    for (int i = PL_PLAN_COUNT; i < n; ++i) out[i] = 0;
+    return PL_OK;
+}
 
 double pl_flops_per_iteration(const pl_handle* h) {
     if (!h) return 0.0;

@@ -511,6 +511,16 @@ class HipPlanner:
                    _capi.PL_MODEL_PRED if model == "pred" else _capi.PL_MODEL_EMBED, int(reps), C.byref(ms), C.byref(fl))
         return ms.value, fl.value
 
+    PLAN_FIELDS = ("fused_fwd", "fused_bwd", "fwd_chains_pred", "fwd_chains_emb", "bwd_chains_pred", "bwd_chains_emb",
+                   "fwd_workgroups", "bwd_workgroups", "bwd_waves", "n_cu")
+
+    def plan_info(self):
+        """The launch schedule the library planned for this handle (include/paule_hip.h: pl_plan_info) as a dict:
+        fused_fwd / fused_bwd 0 or 1 (the role-fused launches of lstm_fused.hip), their chain counts and workgroups, ..."""
+        buf = (C.c_int32 * len(self.PLAN_FIELDS))()
+        self._call(self.lib.pl_plan_info, buf, len(self.PLAN_FIELDS))
+        return dict(zip(self.PLAN_FIELDS, (int(v) for v in buf)))
+
     @property
     def device_bytes(self):
         return int(self.lib.pl_device_bytes(self._h))
