@@ -84,7 +84,10 @@ __device__ __forceinline__ bool flags_wait(const FlagPoll& s, int* status, int* 
             }
         }
         if (lane == 0) {
-            if (!ok) flag_store(status, 1);
+            if (!ok) {   // 0 -> 1 only: an earlier cause (the census's 2) stays
+                int expected = 0;
+                __hip_atomic_compare_exchange_strong((PL_GLOBAL int*)status, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             *lds_word = ok;
         }
     }
@@ -109,11 +112,20 @@ __device__ __forceinline__ bool census_ok(const FusedArgs& a, int* lds_word) {
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
         const int lane = threadIdx.x;
         int ok = 1;
+        if (a.census_late_ticks && blockIdx.x == 0) {   // test hook: this workgroup shows up only after the others have given up
+            const unsigned long long tl = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - tl < a.census_late_ticks) __builtin_amdgcn_s_sleep(32);
+        }
         if (lane == 0) __hip_atomic_fetch_add((PL_GLOBAL int*)a.census, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spin = 1;; ++spin) {
             const int v = flag_load(a.census);
-            if (v >= a.n_active) break;
+            // the others may have given up already (status set) while the count still completes with this late sign-in: the
+            // launch is void either way, and the FIRST cause must stay in the status word
+            if (v >= a.n_active) {
+                if (flag_load(a.status) != 0) ok = 0;
+                break;
+            }
             if ((spin & 15u) == 0 && (flag_load(a.status) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > a.census_ticks)) {
                 ok = 0;
                 break;
@@ -121,7 +133,10 @@ __device__ __forceinline__ bool census_ok(const FusedArgs& a, int* lds_word) {
             __builtin_amdgcn_s_sleep(8);
         }
         if (lane == 0) {
-            if (!ok && flag_load(a.status) == 0) flag_store(a.status, 2);
+            if (!ok) {
+                int expected = 0;
+                __hip_atomic_compare_exchange_strong((PL_GLOBAL int*)a.status, &expected, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             *lds_word = ok;
         }
     }

@@ -159,6 +159,7 @@ struct FusedArgs {
     int* census;              // residency check: every role-bearing workgroup signs in here first (zeroed with the flags) ...
     int n_active;             // ... and waits, briefly, until all n_active have: a launch that is not wholly resident (another process
     unsigned long long census_ticks;   // holds CUs) sets status 2 and leaves within census_ticks instead of spinning for seconds in its waits
+    unsigned long long census_late_ticks;   // test hook (PAULE_HIP_CENSUS_LATE_MS): workgroup 0 signs in this late; 0 = off
     unsigned long long* stamps;
     const FusedRole* roles;   // [n_roles] in device memory (a table in the kernel arguments would have to be indexed dynamically,
                               // which makes the compiler copy it to scratch)
@@ -261,7 +262,7 @@ void launch_unpad_rows(hipStream_t stream, const float* src, int B, int S, int S
 // outputs are split over K to fill the chip and summed in a fixed order afterwards
 size_t train_scratch_bytes(int M, int N);
 void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
-                    int Bp, int nb, int Tk, int tA0, int tB0, float* scratch, size_t scratch_bytes, int n_cu);
+                    int Bp, int nb, int Tk, int tA0, int tB0, float* scratch, size_t scratch_bytes, int n_cu, bool tn_bf16 = true);
 // out[c] = sum over the same rows of A[.][c]; part: >= 64 * ncols doubles
 void launch_colsum(hipStream_t stream, int dt, const void* A, int lda, int ncols, int Bp, int nb, int Tk, int t0, float* out, double* part);
 // scal[0] = sqrt(mean((pred - target)^2)) over n elements (f64), scal[1] = the sum of squares; loss_out (device f32) optional

@@ -199,6 +199,12 @@ struct pl_handle {
                                 // hand-off is half lines per workgroup and reads back slower from L2 than from the memory side (+1 %)
     int bwd_mode = 1;           // backward sweep: 1 reduce-scatter of partial dh tiles (default: 8.5 % faster iteration with the
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
+    // diagnostic switches, read ONCE by pl_create (no getenv on launch paths)
+    bool tn_bf16 = true;        // PAULE_HIP_TN_BF16: training, bf16: weight-gradient products on the bf16 MFMA (0: the exact f32 MFMA form)
+    bool stop_after_fwd = false;   // PAULE_HIP_STOP_AFTER_FWD: pl_step enqueues the forward pass only (tools/fused_check.py, stash comparisons in tests)
+    bool debug_fused = false;   // PAULE_HIP_DEBUG_FUSED
+    bool census_hooks = false;  // PAULE_HIP_CENSUS_EXPECT_EXTRA / PAULE_HIP_CENSUS_LATE_MS were set when the handle was created: the test
+                                // hooks of the residency census are then re-read at every fused launch (never otherwise)
     bool bwd_stream = true;     // PAULE_HIP_BWD_STREAM: reduce-scatter backward sweep with per-tile flags and streamed ingest (lstm_persist_rs.hip)
     int bwd_waves = 8;          // PAULE_HIP_BWD_WAVES: waves per workgroup of the reduce-scatter backward sweep (4: one per SIMD, round 2's form)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
@@ -343,7 +349,16 @@ int* take_sweep_slice(pl_handle* h, hipStream_t st) {
     return h->sweep_cnt;
 }
 void zero_all_sweep_slots(pl_handle* h, hipStream_t st) {
-    const size_t ints = h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots;
+    // the per-layer slices come first, then the flag slices of the fused forward launch's roles, then the fused backward launch's:
+    // only what this handle's plan hands out is zeroed (a handle without fused launches does not pay for their slices: ADVICE r2)
+    int n_used = h->n_sweep_slots;
+    if (h->cfg.emb_layers > 0) {
+        const int n_roles = 3 + 2 * (h->cfg.emb_layers - 1), n_fused = 2 * n_roles + (h->cfg.emb_layers - 1);
+        n_used = h->n_sweep_slots - n_fused;
+        if (h->fused_bwd_ok) n_used = h->n_sweep_slots;
+        else if (h->fused_fwd_ok) n_used += n_roles;
+    }
+    const size_t ints = h->sweep_cnt_bytes / sizeof(int) * n_used;
     if (h->zero_mode == 1)
         (void)hipMemsetAsync(h->sweep_cnt, 0, ints * sizeof(int), st);
     else
@@ -534,9 +549,9 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
         if (train_nb > 0) {
             const void* lin = l == 0 ? in_act : md.layers[l - 1].h;
             launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, ly.h, Hp, ly.gWhh, Hp, 4 * Hp, Hp, Bp, train_nb, Tl - 1, 1, 0, md.train_scratch,
-                           md.train_scratch_bytes, h->n_cu);
+                           md.train_scratch_bytes, h->n_cu, h->tn_bf16);
             launch_gemm_tn(st, h->dt, ly.G, 4 * Hp, lin, ly.in_p, ly.gWih, ly.in_p, 4 * Hp, ly.in_p, Bp, train_nb, Tl, 0, 0,
-                           md.train_scratch, md.train_scratch_bytes, h->n_cu);
+                           md.train_scratch, md.train_scratch_bytes, h->n_cu, h->tn_bf16);
             launch_colsum(st, h->dt, ly.G, 4 * Hp, 4 * Hp, Bp, train_nb, Tl, 0, ly.gb, md.colsum_part);
         }
         if (l > 0)   // dL/dh of the layer below = dA * Wih
@@ -1379,9 +1394,12 @@ void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, c
     // the last word of role 0's flag slice (inside its XCD-id table, which the fused launches do not use): zeroed with the flags
     a.census = fused_slice(h, 0, bwd) + h->sweep_cnt_bytes / sizeof(int) - 1;
     a.n_active = bwd ? h->fused_active_bwd : h->fused_active_fwd;
-    if (const char* z = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA")) a.n_active += std::atoi(z);   // test hook: a workgroup that never shows up
+    if (h->census_hooks) {   // test hooks: a workgroup that never shows up / one that shows up after the others have given up
+        if (const char* z = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA")) a.n_active += std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_CENSUS_LATE_MS")) a.census_late_ticks = 100000ull * (unsigned long long)std::atoll(z);
+    }
     a.census_ticks = h->census_ticks;
-    if (std::getenv("PAULE_HIP_DEBUG_FUSED"))
+    if (h->debug_fused)
         fprintf(stderr, "[pl] fused %s launch: grid %d, %d role-bearing workgroups expected, census word at slice int %zu, bound %llu ticks, Cp %d Ce %d\n",
                 bwd ? "backward" : "forward", grid, a.n_active, (size_t)(a.census - h->sweep_cnt), a.census_ticks, h->fused_Cp, h->fused_Ce);
     a.stamps = h->sweep_stamps ? h->sweep_stamps + (bwd ? 256 * 8 : 0) : nullptr;
@@ -1573,7 +1591,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
         pred_forward(h, st);
         if (with_sem) emb_forward(h, st, nullptr, h->mel_bm);
     }
-    if (std::getenv("PAULE_HIP_STOP_AFTER_FWD")) {   // diagnostic: leave the forward stashes as they are (tools/fused_check.py)
+    if (h->stop_after_fwd) {   // diagnostic: leave the forward stashes as they are (tools/fused_check.py)
         h->sweep_slot = -1;
         return;
     }
@@ -1923,6 +1941,14 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_TN_BF16")) h->tn_bf16 = std::atoi(z) != 0;
+        h->debug_fused = std::getenv("PAULE_HIP_DEBUG_FUSED") != nullptr;
+        h->census_hooks = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA") != nullptr || std::getenv("PAULE_HIP_CENSUS_LATE_MS") != nullptr;
+        if (std::getenv("PAULE_HIP_STOP_AFTER_FWD")) {
+            h->stop_after_fwd = true;
+            fprintf(stderr, "[pl] PAULE_HIP_STOP_AFTER_FWD is set: pl_step of this handle enqueues the forward pass ONLY (diagnostic mode: no loss, "
+                            "no backward pass, no update -- loss logs and the CP do not change)\n");
+        }
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
@@ -2388,7 +2414,7 @@ int pl_train_model_step(pl_handle* h, int model_id, int n_rows, int n_frames, co
     // backward (paule/paule.py:1376): dY, post_linear gradients, then the recurrences with weight gradients
     launch_train_dy(st, h->dt, out_bm, target, h->scal, n_rows, T, To, p.out, Bp, p.out_p, dYb, pooled);
     launch_gemm_tn(st, h->dt, dYb, p.out_p, top.h, p.Hp, p.gWlin, p.Hp, p.out_p, p.Hp, Bp, nb, T, 0, 0, p.train_scratch,
-                   p.train_scratch_bytes, h->n_cu);
+                   p.train_scratch_bytes, h->n_cu, h->tn_bf16);
     launch_colsum(st, h->dt, dYb, p.out_p, p.out_p, Bp, nb, T, 0, p.gblin, p.colsum_part);
     launch_gemm_nt(st, h->dt, false, dYb, p.out_p, p.WlinT, p.out_p, nullptr, p.dh_ext, p.Hp, T * Bp, p.Hp, p.out_p);
     model_backward(h, st, p, nullptr, nullptr, nb, in_tm, T);

@@ -369,7 +369,7 @@ inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 size_t train_scratch_bytes(int M, int N) { return (size_t)8 * M * N * sizeof(float); }
 
 void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
-                    int Bp, int nb, int Tk, int tA0, int tB0, float* scratch, size_t scratch_bytes, int n_cu) {
+                    int Bp, int nb, int Tk, int tA0, int tB0, float* scratch, size_t scratch_bytes, int n_cu, bool tn_bf16) {
     if (M <= 0 || N <= 0) return;
     const bool narrow = N <= 64;
     const int gx = (N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), gy = (M + 127) / 128;
@@ -391,8 +391,7 @@ void launch_gemm_tn(hipStream_t stream, int dt, const void* A, int lda, const vo
             hipLaunchKernelGGL((gemm_tn_kernel<AT_, 128>), grid, dim3(256), 0, stream, static_cast<const AT_*>(A), lda,         \
                                static_cast<const AT_*>(B), ldb, dst, ldc, M, N, Bp, nb, Tk, tA0, tB0);                          \
     } while (0)
-    const char* tn_env = std::getenv("PAULE_HIP_TN_BF16");   // 0: the f32-MFMA form for bf16 operands too (A/B, tests)
-    const bool tn_bf16 = !(tn_env && std::atoi(tn_env) == 0);
+    // tn_bf16 false (PAULE_HIP_TN_BF16=0, read once per handle): the f32-MFMA form for bf16 operands too (A/B, tests)
     if (dt == BF16 && tn_bf16) {
         if (narrow)
             hipLaunchKernelGGL((gemm_tn_bf16_kernel<64>), grid, dim3(256), 0, stream, static_cast<const bf16_t*>(A), lda,

@@ -231,10 +231,18 @@ class Paule():
         and retire one each time).  A reused handle gets the models' CURRENT weights (continued learning changes them between calls)
         and a clean slate for everything a call sets."""
         tube = kw.get("tube_models")
+
+        def arch(m):   # what decides whether a handle fits a model: its tensors' names and shapes (NOT id(): a freed model's id can come back)
+            if m is None:
+                return None
+            sd = m.state_dict() if hasattr(m, "state_dict") else m
+            return tuple((k, tuple(v.shape)) for k, v in sd.items())
+
         key = (kw["batch"], kw["n_frames"], kw["objective"], kw["dtype"], float(kw["lr"]), bool(kw["smiling"]), str(kw["device"]),
-               id(self.pred_model), id(self.embedder), inv_sd is not None, None if tube is None else tuple(id(m) for m in tube))
+               arch(self.pred_model), arch(self.embedder), arch(inv_sd), None if tube is None else tuple(arch(m) for m in tube))
         planner = self._planners.get(key)
         if planner is not None and hasattr(planner, "set_weights"):
+            self._planners[key] = self._planners.pop(key)   # most recently used last
             planner.set_weights(pred_model=self.pred_model, embedder=self.embedder)
             if tube is not None and hasattr(planner, "set_tube_weights"):
                 planner.set_tube_weights(*tube)
@@ -246,12 +254,28 @@ class Paule():
             return planner
         planner = self._planner_factory(self.pred_model, self.embedder, **kw, **({"inv_model": inv_sd} if inv_sd is not None else {}))
         if hasattr(planner, "set_weights"):
-            if len(self._planners) >= 8:   # a few shapes stay resident (each holds its activations: 1.9 GB at B = 256 x 300); oldest out
-                old = self._planners.pop(next(iter(self._planners)))
-                if hasattr(old, "close"):
-                    old.close()
             self._planners[key] = planner
+            self._trim_planners(keep=planner)
         return planner
+
+    # a few shapes stay resident; a handle holds its activations (1.9 GB at B = 256 x 300), so the cache is bounded by bytes as well
+    PLANNER_CACHE_ENTRIES = 8
+    PLANNER_CACHE_BYTES = 24 << 30
+
+    def _trim_planners(self, keep=None):
+        """Least recently used handles out until the cache fits its bounds; never the handle just built nor the one published as
+        ``self.planner`` (user code may hold it)."""
+        def total():
+            return sum(int(getattr(pl_, "device_bytes", 0) or 0) for pl_ in self._planners.values())
+        for key in list(self._planners):
+            if len(self._planners) <= self.PLANNER_CACHE_ENTRIES and total() <= self.PLANNER_CACHE_BYTES:
+                break
+            pl_ = self._planners[key]
+            if pl_ is keep or pl_ is self.planner:
+                continue
+            del self._planners[key]
+            if hasattr(pl_, "close"):
+                pl_.close()
 
     def release_planners(self):
         """Frees the cached engine handles (device memory)."""

@@ -410,6 +410,47 @@ def test_sharded_planning_world2_gloo(tmp_path):
     np.testing.assert_allclose(cp_all.numpy(), eng.get_cp().numpy(), atol=1e-13)
 
 
+class _FailingEngine(OracleEngine):
+    """An engine whose device status check fails after stepping (what HipPlanner.check() does after a timed-out in-kernel wait)."""
+
+    def check(self):
+        raise ValueError("persistent LSTM sweep: a bounded in-kernel wait timed out (injected)")
+
+
+def _worker_one_rank_fails(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from paule_amd.distributed import ShardFailed
+    wl = synthetic.make_workload(5, 24, None, pred=dict(num_lstm_layers=1, hidden_size=12),
+                                 emb=dict(num_lstm_layers=1, hidden_size=10))
+    cls = _FailingEngine if rank == 1 else OracleEngine
+    mk = lambda batch: cls(wl.pred_sd, wl.emb_sd, batch=batch, n_frames=24, objective="acoustic_semvec")
+    try:
+        plan_sharded(mk, wl.cp0, wl.target_mel, wl.target_semvec, 2)
+        verdict = "returned"
+    except ShardFailed as e:
+        verdict = "own" if e.__cause__ is not None else "peer"
+    with open(f"{out}.{rank}", "w") as f:
+        f.write(verdict)
+    dist.barrier()   # both ranks are still able to meet: nobody is stuck in the gather
+    dist.destroy_process_group()
+
+
+def test_sharded_planning_one_rank_fails_everybody_raises(tmp_path):
+    """a rank whose planner.check() raises must not leave its peers blocked in the all_gather.  Rank 1's
+    engine fails its status check; BOTH ranks raise ShardFailed (rank 1 with its own error as the cause) and meet again at a
+    barrier afterwards -- the processes are joined with a timeout, a hang fails the test."""
+    out = str(tmp_path / "verdict")
+    port = 29500 + (os.getpid() + 7) % 2000
+    ctx = mp.spawn(_worker_one_rank_fails, args=(2, port, out), nprocs=2, join=False)
+    import time
+    deadline = time.time() + 120
+    while not ctx.join(timeout=1):
+        assert time.time() < deadline, "plan_sharded left a rank blocked in a collective"
+    assert open(out + ".0").read() == "peer" and open(out + ".1").read() == "own"
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` outside a torch.distributed launcher starts N ranks itself (child processes), they meet, take the
     max over ranks of the timed region, gather CP-shaped tensors and rank 0 prints ONE JSON line.  Here without an engine
