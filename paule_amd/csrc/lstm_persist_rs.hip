@@ -452,6 +452,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
             }
             PL_ST(4);   // tiles + flags
         }
+        __syncthreads();   // a workgroup that sweeps several groups in turn: nobody writes the next group's dA image while a wave still reads this one's
     }
     PL_ST_DUMP(a.stamps);
 }

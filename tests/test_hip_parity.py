@@ -11,6 +11,7 @@ import torch
 from conftest import state_dict_from
 from oracle import manual as om
 from oracle import planner as op
+import oracle_golden as og
 from paule_amd import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -908,19 +909,17 @@ def test_two_handles_on_two_streams_do_not_starve_each_other(HipPlanner):
 
 def test_long_sequences_f32_vs_oracle(HipPlanner):
     """T = 2000 CP frames (cfg5's length; T' = 1000 embedder steps): flag / stash indexing over long sweeps, f32 against the
-    oracle on small stacked models (2 x 64 predictor, 1 x 96 embedder: the CPU oracle has to finish in seconds), 2 iterations."""
-    wl = synthetic.make_workload(2, 2000, None, pred=dict(num_lstm_layers=2, hidden_size=64),
-                                 emb=dict(num_lstm_layers=1, hidden_size=96))
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
-                           objective="acoustic_semvec")
+    oracle on small stacked models (2 x 64 predictor, 1 x 96 embedder), 2 iterations.  Oracle side: tests/golden/oracle_long_small.npz
+    (tests/oracle_golden.py)."""
+    wl = og.workload("long_small")
+    ref = og.get("long_small")
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=2, n_frames=2000, objective="acoustic_semvec")
-    for pl in (orc, eng):
-        pl.set_targets(wl.target_mel, wl.target_semvec)
-        pl.set_cp(wl.cp0)
-    lo, lh = _n(orc.step(2)), _n(eng.step(2))
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    lh = _n(eng.step(2))
     eng.synchronize()
-    np.testing.assert_allclose(lh, lo, rtol=LOSS_RTOL_F32, atol=1e-7)
-    np.testing.assert_allclose(_n(eng.get_cp()), _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(lh, ref["loss"], rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(_n(eng.get_cp()), ref["cp_after"][1], atol=CP_ATOL_F32, rtol=0)
 
 
 def test_long_sequences_bf16_sweeps(HipPlanner):
@@ -942,20 +941,14 @@ def test_long_sequences_bf16_sweeps(HipPlanner):
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_long_sequences_set_a_vs_oracle(HipPlanner, dtype):
     """BASELINE configs[4]'s shape on Paule's default models (set A, H = 720, T = 2000, T' = 1000) against the float64 oracle on
-    the same two utterances, one iteration (losses, the model gradient through the 2000 / 1000-step recurrences, the updated CP): the long-form path of cfg5 (one 16-row group, pipelined sweeps of 2000 / 1000 steps)
-    compared with the reference arithmetic, not only checked for its properties.  f32: the f32 bars; bf16: the bf16 bars."""
+    the same two utterances, one iteration (losses, the model gradient through the 2000 / 1000-step recurrences, the updated CP): the
+    long-form path of cfg5 (one 16-row group, pipelined sweeps of 2000 / 1000 steps) compared with the reference arithmetic, not
+    only checked for its properties.  f32: the f32 bars; bf16: the bf16 bars.  The oracle's iteration (~2 minutes of float64 torch)
+    is the committed fixture tests/golden/oracle_long_set_a.npz."""
     B, T = 2, 2000
-    wl = synthetic.make_workload(B, T, "A")
-    if "long_set_a" not in _ORACLE_CACHE:   # the float64 oracle takes its seconds once for both dtypes
-        orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
-                               objective="acoustic_semvec")
-        orc.set_targets(wl.target_mel, wl.target_semvec)
-        orc.set_cp(wl.cp0)
-        from oracle import manual as mo
-        l1 = _n(orc.step(1))   # ONE oracle iteration (~2.5 minutes of float64 torch on the box's cores): loss, gradient, updated CP
-        g_model = _n(orc.last_grad) - mo.smoothness_loss_grad(_n(wl.cp0))[3]   # model part of dL/dCP at the first iteration
-        _ORACLE_CACHE["long_set_a"] = (l1, _n(orc.get_cp()), g_model)
-    lo, cpo, g_model = _ORACLE_CACHE["long_set_a"]
+    wl = og.workload("long_set_a")
+    ref = og.get("long_set_a")
+    lo, cpo, g_model = ref["loss"], ref["cp_after"][0], ref["g_model"]
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype=dtype)
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
@@ -1376,19 +1369,16 @@ def test_full_size_cfg2_f32_against_oracle_rows(HipPlanner):
     batched HIP run against a float64 oracle run on those two alone (per-utterance rule a-0: the rows of a batch are B = 1
     problems) at the f32 bar, and rows 16..31 bit-equal to a 16-utterance engine (same 16-row sweeps, no cross-row coupling)."""
     B, T = 64, 300
-    wl = synthetic.make_workload(B, T, "A")
+    wl = og.workload("cfg2_rows")
+    ref = og.get("cfg2_rows")   # the oracle on rows 0 and 1: tests/golden/oracle_cfg2_rows.npz
     eng = HipPlanner(wl.pred_sd, None, batch=B, n_frames=T, objective="acoustic")
     eng.set_targets(wl.target_mel, None)
     eng.set_cp(wl.cp0)
     loss = _n(eng.step(3))
     cp = _n(eng.get_cp())
     eng.synchronize()
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), None, objective="acoustic")
-    orc.set_targets(wl.target_mel[:2], None)
-    orc.set_cp(wl.cp0[:2])
-    lo = _n(orc.step(3))
-    np.testing.assert_allclose(loss[:, :2], lo, rtol=LOSS_RTOL_F32, atol=1e-7)
-    np.testing.assert_allclose(cp[:2], _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(loss[:, :2], ref["loss"], rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(cp[:2], ref["cp_after"][2], atol=CP_ATOL_F32, rtol=0)
     sub = HipPlanner(wl.pred_sd, None, batch=16, n_frames=T, objective="acoustic")
     sub.set_targets(wl.target_mel[16:32], None)
     sub.set_cp(wl.cp0[16:32])
@@ -1402,7 +1392,8 @@ def test_full_size_cfg3_f32_against_oracle_rows(HipPlanner):
     run on those two alone at the f32 bars, and rows 32..47 (one whole group, the third chain of its set) bit-equal to a
     16-utterance engine -- the same MFMA order per element, no coupling between the chains of a workgroup."""
     B, T, n = 256, 300, 2
-    wl = synthetic.make_workload(B, T, "A")
+    wl = og.workload("cfg3_rows")
+    ref = og.get("cfg3_rows")   # the oracle on rows 0 and 255 (three iterations; the first two are used here)
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec")
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
@@ -1410,13 +1401,8 @@ def test_full_size_cfg3_f32_against_oracle_rows(HipPlanner):
     cp = _n(eng.get_cp())
     eng.synchronize()
     rows = [0, B - 1]
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
-                           objective="acoustic_semvec")
-    orc.set_targets(wl.target_mel[rows], wl.target_semvec[rows])
-    orc.set_cp(wl.cp0[rows])
-    lo = _n(orc.step(n))
-    np.testing.assert_allclose(loss[:, rows], lo, rtol=LOSS_RTOL_F32, atol=1e-7)
-    np.testing.assert_allclose(cp[rows], _n(orc.get_cp()), atol=CP_ATOL_F32, rtol=0)
+    np.testing.assert_allclose(loss[:, rows], ref["loss"][:n], rtol=LOSS_RTOL_F32, atol=1e-7)
+    np.testing.assert_allclose(cp[rows], ref["cp_after"][n - 1], atol=CP_ATOL_F32, rtol=0)
     sub = HipPlanner(wl.pred_sd, wl.emb_sd, batch=16, n_frames=T, objective="acoustic_semvec")
     sub.set_targets(wl.target_mel[32:48], wl.target_semvec[32:48])
     sub.set_cp(wl.cp0[32:48])
@@ -1432,7 +1418,9 @@ def test_full_size_cfg3_bf16_against_oracle_rows(HipPlanner, B):
     fused forward launch and the per-layer backward sweeps, B = 100 (a ragged last group) the fused forward AND backward launches
     -- the library's defaults for those sizes."""
     T, n = 300, 3
-    wl = synthetic.make_workload(B, T, "A")
+    case = "cfg3_rows" if B == 256 else "cfg3_100_rows"
+    wl = og.workload(case)
+    ref = og.get(case)   # the float64 oracle on the two rows: tests/golden/oracle_<case>.npz
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
     plan = eng.plan_info()   # the schedule this test says it covers is the one the library planned
     assert plan["fused_fwd"] == 1 and plan["fused_bwd"] == (0 if B == 256 else 1) and plan["bwd_waves"] == 8, plan
@@ -1442,13 +1430,8 @@ def test_full_size_cfg3_bf16_against_oracle_rows(HipPlanner, B):
     cp = _n(eng.get_cp())
     eng.synchronize()
     rows = [0, B - 1]
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd), op.embedding_model_from_state_dict(wl.emb_sd),
-                           objective="acoustic_semvec")
-    orc.set_targets(wl.target_mel[rows], wl.target_semvec[rows])
-    orc.set_cp(wl.cp0[rows])
-    lo = _n(orc.step(n))
-    np.testing.assert_allclose(loss[:, rows], lo, rtol=LOSS_RTOL_BF16, atol=5e-3)
-    d = np.abs(cp[rows] - _n(orc.get_cp()))
+    np.testing.assert_allclose(loss[:, rows], ref["loss"], rtol=LOSS_RTOL_BF16, atol=5e-3)
+    d = np.abs(cp[rows] - ref["cp_after"][n - 1])
     assert d.mean() <= 0.05 * 0.01 * n and d.max() <= 0.01 * n, (d.mean(), d.max())
 
 
@@ -1633,23 +1616,75 @@ def test_full_size_cfg3_bf16_vs_rounding_emulation(HipPlanner):
     sweeps) against the rounding emulation on its first and last utterance (rows of a batch are independent problems, a-0): the
     predictor's h stash bit-equal in >= 90 % of the entries, the model gradient dL/dCP within 3e-3 relative -- i.e. at full size,
     too, the bf16 plan differs from the reference's arithmetic by the declared roundings and nothing else."""
-    from oracle import bf16_emul as be
     B, T, H, Hp, rows = 256, 300, 720, 736, [0, 255]
-    wl = synthetic.make_workload(B, T, "A")
+    wl = og.workload("cfg3_rows")
+    ref = og.get("cfg3_rows")   # oracle/bf16_emul.py on rows 0 and 255: the predictor's h stash (bf16 patterns) and dL/dCP
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     eng.step(1, return_loss=False)
     eng.synchronize()
-    em = be.EmulPlanner(wl.pred_sd, wl.emb_sd, objective="acoustic_semvec")
-    em.set_targets(wl.target_mel[rows].numpy(), wl.target_semvec[rows].numpy())
-    em.set_cp(wl.cp0[rows].numpy())
-    _, _, pe = be.loss_and_grad(em.models, "acoustic_semvec", em.x, em.target_mel, em.target_semvec)
     h0 = _n(eng.debug_read("pred.h0")).reshape(T, B, Hp)[:, rows, :H].transpose(1, 0, 2)
-    same = np.mean(h0 == pe["pred_h"][0])
+    same = np.mean(h0 == og.bf16_from_bits(ref["emul_pred_h0_bits"]))
     dX = _n(eng.debug_read("dX")).reshape(T, B, 32)[:, rows, :30].transpose(1, 0, 2)
-    err = np.linalg.norm(dX - pe["dX"]) / np.linalg.norm(pe["dX"])
+    err = np.linalg.norm(dX - ref["emul_dX"]) / np.linalg.norm(ref["emul_dX"])
     assert same >= 0.90 and err <= 3e-3, (same, err)
+
+
+def test_full_size_cfg5_128_fused_launches_vs_oracle_and_emulation(HipPlanner):
+    """BASELINE configs[4] on ONE GPU (cfg5_128: all 128 utterances x 2000 frames, bf16, Paule's models): the fused forward AND
+    backward launches at T = 2000 -- 2000 / 1000 chain-steps per role, four 32-row groups -- which round 2 only ever tested up to
+    T = 300 (VERDICT r2 missing #2a).  First and last utterance of the batched run after one iteration against the float64 oracle
+    (loss, model gradient <= 2 %, updated CP at the bf16 bars) and against the rounding emulation (gradient <= 3e-3: the long
+    recurrences differ from the reference arithmetic by the declared roundings only).  Oracle side: tests/golden/oracle_cfg5_128_rows.npz."""
+    B, T, rows = 128, 2000, [0, 127]
+    wl = og.workload("cfg5_128_rows")
+    ref = og.get("cfg5_128_rows")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    plan = eng.plan_info()
+    assert plan["fused_fwd"] == 1 and plan["fused_bwd"] == 1, plan
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    l1 = _n(eng.step(1))
+    eng.synchronize()
+    dX = _n(eng.debug_read("dX")).reshape(T, B, 32)[:, rows, :30].transpose(1, 0, 2)
+    g_err = np.linalg.norm(dX - ref["g_model"]) / np.linalg.norm(ref["g_model"])
+    e_err = np.linalg.norm(dX - ref["emul_dX"]) / np.linalg.norm(ref["emul_dX"])
+    assert g_err <= 2e-2 and e_err <= 3e-3, (g_err, e_err)
+    np.testing.assert_allclose(l1[:, rows], ref["loss"], rtol=LOSS_RTOL_BF16, atol=5e-3)
+    dcp = np.abs(_n(eng.get_cp())[rows] - ref["cp_after"][0])
+    assert dcp.max() <= 0.5 * 0.01 * 2 and dcp.mean() <= 1e-4, (dcp.max(), dcp.mean())
+
+
+def test_full_size_cfg4_one_gpu_vs_oracle_and_row_independence(HipPlanner):
+    """BASELINE configs[3]'s whole batch on ONE GPU (cfg4_1gpu: 2048 utterances x 300 frames, bf16; 64 groups of 32 rows swept 8
+    at a time by the same workgroups) -- round 2 measured it and tested the multi-pass loop only at B = 270 x 17 frames (VERDICT
+    r2 missing #2b).  First and last utterance after two iterations against the float64 oracle (bf16 bars), and one whole group in
+    the middle of the batch (rows 1024 .. 1055, swept in the fifth pass) bit-equal to the same rows planned by a 256-utterance
+    engine: the passes do not leak into each other.  Oracle side: tests/golden/oracle_cfg4_rows.npz."""
+    B, T, n, rows = 2048, 300, 2, [0, 2047]
+    wl = og.workload("cfg4_rows")
+    ref = og.get("cfg4_rows")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    loss = _n(eng.step(n))
+    cp = _n(eng.get_cp())
+    eng.synchronize()
+    np.testing.assert_allclose(loss[:, rows], ref["loss"], rtol=LOSS_RTOL_BF16, atol=5e-3)
+    d = np.abs(cp[rows] - ref["cp_after"][n - 1])
+    assert d.mean() <= 0.05 * 0.01 * n and d.max() <= 0.01 * n, (d.mean(), d.max())
+    eng.close()
+    # rows 896 .. 1151 as a batch of their own (the default plan at 256 rows: fused forward launch + per-layer backward sweeps, the
+    # same kernels the 2048-row handle runs group by group)
+    lo_, hi_ = 896, 1152
+    sub = HipPlanner(wl.pred_sd, wl.emb_sd, batch=hi_ - lo_, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    sub.set_targets(wl.target_mel[lo_:hi_], wl.target_semvec[lo_:hi_])
+    sub.set_cp(wl.cp0[lo_:hi_])
+    ls = _n(sub.step(n))
+    sub.synchronize()
+    np.testing.assert_array_equal(ls[:, 128:160], loss[:, 1024:1056])
+    np.testing.assert_array_equal(_n(sub.get_cp())[128:160], cp[1024:1056])
 
 
 def test_plan_resynth_like_the_reference_test_on_the_gpu(golden_inverse):

@@ -1,5 +1,7 @@
 """The CPU oracle against the fixtures generated from the REFERENCE's own code (tests/golden/make_golden.py).
 Bar: float64 vs float64, <= 1e-12 absolute (relative for the large loss values)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -259,3 +261,25 @@ def test_torch_and_manual_oracles_agree_on_random_shapes():
         _close(np.asarray(M.get_cp()), P.get_cp().numpy(), tol=1e-9)
 
     check()
+
+
+# ---- committed outputs of the oracle on the full-size configurations (tests/oracle_golden.py) ------------------------------------
+def test_oracle_golden_fixtures_match_their_workloads():
+    """Every tests/golden/oracle_<case>.npz carries the digest of the inputs it was computed for; it must be the digest of the
+    workload the GPU tests will build today (generator, seeds, weights) -- a stale fixture fails here, on the CPU."""
+    import oracle_golden as og
+    for name in og.CASES:
+        assert os.path.exists(og.path(name)), f"{og.path(name)} is missing: python tests/golden/make_oracle_golden.py {name}"
+        assert og.check_digest(name), name
+
+
+@pytest.mark.parametrize("name", ["cfg2_rows", "cfg4_rows"])
+def test_oracle_golden_is_what_the_oracle_computes(name):
+    """The fixtures are outputs of oracle/ (the repo's CPU restatement, pinned to the reference above), nothing else: two of them
+    are recomputed here and compared with the committed files (loss log to 1e-12; CP trajectories are stored in float32)."""
+    import oracle_golden as og
+    want = dict(np.load(og.path(name)))
+    got = og.compute(name)
+    assert str(got["digest"]) == str(want["digest"])
+    np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got["cp_after"], want["cp_after"], rtol=0, atol=2e-7)
