@@ -66,26 +66,44 @@ def cpu_baseline(wl_args, objective, seconds_budget=25.0, full=False):
     torch.set_num_threads(nthreads)
     f64 = bool(wl_args.get("cpu_f64"))
     cdt = torch.float64 if f64 else torch.float32
-    sample_b = wl_args["batch"] if full else min(16, wl_args["batch"])
-    wl = synthetic.make_workload(sample_b, wl_args["frames"], wl_args["model_set"])
-    orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, cdt),
-                           op.embedding_model_from_state_dict(wl.emb_sd, cdt), objective=objective,
-                           dtype=cdt)
-    orc.set_targets(wl.target_mel, wl.target_semvec)
-    orc.set_cp(wl.cp0)
+    def run(n_utt, min_iters, budget, max_iters):
+        wl = synthetic.make_workload(n_utt, wl_args["frames"], wl_args["model_set"])
+        orc = op.OraclePlanner(op.forward_model_from_state_dict(wl.pred_sd, cdt),
+                               op.embedding_model_from_state_dict(wl.emb_sd, cdt), objective=objective,
+                               dtype=cdt)
+        orc.set_targets(wl.target_mel, wl.target_semvec)
+        orc.set_cp(wl.cp0)
+        orc.step(1)   # warm-up
+        iters, t0 = 0, time.perf_counter()
+        while iters < min_iters or (time.perf_counter() - t0 < budget and iters < max_iters):
+            orc.step(1)
+            iters += 1
+        return iters, time.perf_counter() - t0
+
+    B = wl_args["batch"]
+    sample_b = min(16, B)
     progress(f"cpu baseline: {nthreads} threads, sample of {sample_b} utterances")
-    orc.step(1)   # warm-up
-    iters, t0 = 0, time.perf_counter()
-    while iters < (3 if full else 2) or (not full and time.perf_counter() - t0 < seconds_budget and iters < 50):
-        orc.step(1)
-        iters += 1
-    dt = time.perf_counter() - t0
-    utt_it_s = sample_b * iters / dt
-    return dict(value=utt_it_s / wl_args["batch"],
-                unit=f"planning iters/sec at batch={wl_args['batch']}" + ("" if full else " (extrapolated from the sample)"),
-                utt_iters_per_s=utt_it_s, cores=torch.get_num_threads(), kind="port",
-                sample=f"{sample_b} utterances x {iters} iterations, T={wl_args['frames']}, {objective}, model set "
-                       f"{wl_args['model_set']}, {'float64' if f64 else 'float32'}, torch CPU oracle ({dt:.1f} s)")
+    # a short sample first: it is the baseline itself when the full batch would cost minutes, and the estimate that decides otherwise
+    s_iters, s_dt = run(sample_b, 2, 4.0 if not full and B > sample_b else seconds_budget, 50)
+    sample_it_s = sample_b * s_iters / s_dt / B          # planning iterations/s at the full batch, extrapolated from the sample
+    # SURVEY 8d asks for 1 warm-up + 3 timed iterations AT the configuration's batch.  The oracle is ~2.4 x slower per utterance at
+    # B = 256 than on 16 utterances (r2: 0.115 vs 0.272 it/s), so the sample flatters the CPU; the full batch is timed whenever its
+    # estimated cost (4 iterations) stays under a minute
+    est_full = 4 * (B / sample_b) * (s_dt / s_iters) * 2.4
+    desc = f"T={wl_args['frames']}, {objective}, model set {wl_args['model_set']}, {'float64' if f64 else 'float32'}, torch CPU oracle"
+    if B > sample_b and (full or est_full < 60.0):
+        progress(f"cpu baseline: full batch of {B} utterances (estimated {est_full:.0f} s)")
+        f_iters, f_dt = run(B, 3, 0.0, 3)
+        return dict(value=f_iters / f_dt, unit=f"planning iters/sec at batch={B}", utt_iters_per_s=B * f_iters / f_dt,
+                    cores=torch.get_num_threads(), kind="port",
+                    sample=f"{B} utterances x {f_iters} iterations after 1 warm-up, {desc} ({f_dt:.1f} s)",
+                    sample16_value=sample_it_s,
+                    sample16=f"{sample_b} utterances x {s_iters} iterations ({s_dt:.1f} s): {sample_it_s:.3f} it/s extrapolated -- the small sample flatters the CPU")
+    return dict(value=sample_it_s,
+                unit=f"planning iters/sec at batch={B}" + ("" if B == sample_b else " (extrapolated from the sample)"),
+                utt_iters_per_s=sample_b * s_iters / s_dt, cores=torch.get_num_threads(), kind="port",
+                sample=f"{sample_b} utterances x {s_iters} iterations, {desc} ({s_dt:.1f} s)"
+                       + ("" if B == sample_b else f"; the full batch was estimated at {est_full:.0f} s and not timed (--cpu-full forces it)"))
 
 
 def cpu_baseline_train(cfg, seconds_budget=20.0):
@@ -352,6 +370,11 @@ def main():
         except ValueError:
             fused = None
         rs = os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1"   # reduce-scatter form is the library default
+        plan = eng.plan_info()
+        fused_b = None   # the fused backward launch, when the handle's plan runs it (49 ... 128 rows by default): THE backward kernel of the timed iteration
+        if plan["fused_bwd"]:
+            fused_b = eng.bench_kernel("fused_bwd", "pred", reps=5)
+            eng.synchronize()
         if not swept:
             kname = "lstm_bwd_step_kernel"
         elif cfg["dtype"] == "f32":
@@ -362,7 +385,13 @@ def main():
         elif _uses_sweep16(int(eng.pred_hidden), cfg["batch"]) and os.environ.get("PAULE_HIP_SWEEP16", "1") != "0" and rs:
             kname = "lstm_bwd16_rs_sweep_kernel"   # the 16-row kernels (what pl_bench_kernel launches for this width and batch)
         else:
-            kname = "lstm_bwd_rs_sweep_kernel" if rs else "lstm_bwd_sweep_kernel"
+            streamed = rs and os.environ.get("PAULE_HIP_BWD_STREAM", "1") != "0" and os.environ.get("PAULE_HIP_BWD_WAVES", "8") != "4"
+            kname = ("lstm_bwd_rs_stream_kernel" if streamed else "lstm_bwd_rs_sweep_kernel") if rs else "lstm_bwd_sweep_kernel"
+        per_layer = None
+        if fused_b is not None:   # name and rate the kernel the timed iteration runs; keep the per-layer kernel's figures beside it
+            per_layer = {"kernel": kname, "avg_launch_us": ms * 1e3, "flops_per_launch": fl, "achieved": fl / (ms * 1e-3) / 1e12,
+                         "note": "per-layer backward sweep of the predictive model, timed on its own (the A/B reference, PAULE_HIP_FUSED=1)"}
+            kname, (ms, fl) = "fused_bwd_kernel", fused_b
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc, profiles/README.md): a measurement of ANOTHER run of
@@ -411,10 +440,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": ms * 1e3, "flops_per_launch": fl,
                          "us_per_time_step": ms * 1e3 / (T - 1) if swept else ms * 1e3,
-                         # batches of 49 .. 128 rows run BOTH passes as fused launches by default: the per-layer kernel timed above is
-                         # then the A/B reference (PAULE_HIP_FUSED=0), not a kernel of the timed iteration
-                         "note": ("the timed iteration runs the backward pass as fused_bwd_kernel; the per-layer kernel named here was timed on its own"
-                                  if fused is not None and -(-cfg["batch"] // 16) * 16 <= 128 and os.environ.get("PAULE_HIP_FUSED") in (None, "3") else None),
+                         "plan": plan, "per_layer_bwd_kernel": per_layer,
                          "fwd_kernel_avg_launch_us": ms_f * 1e3,
                          "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12,
                          "fused_fwd_kernel": None if fused is None else {

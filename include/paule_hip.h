@@ -268,7 +268,11 @@ enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1,
        /* the fused acoustic forward launch (predictor + mel head + embedder layers as roles of one grid; bf16, batches of 49+
         * rows): one launch = all steps of all its layers (+ the flag-zeroing launch); FLOPs = 2 * B * sum over layers of
         * 4H (in + H) T_layer + 2 * B * H * mel_dim * T; PL_ERR_UNSUPPORTED when the handle does not use it; model_id ignored */
-       PL_KERNEL_FUSED_FWD = 4 };
+       PL_KERNEL_FUSED_FWD = 4,
+       /* the fused acoustic backward launch (embedder recurrences top-down, their dL/dh products, backward mel head, predictor
+        * recurrence; bf16, batches of 49 ... 128 rows by default): FLOPs = 2 * B * (sum over layers of 4H * H * (T_layer - 1)
+        * + the products between the roles); PL_ERR_UNSUPPORTED when the handle does not use it; model_id ignored */
+       PL_KERNEL_FUSED_BWD = 5 };
 int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg_ms_out /* host */,
                     double *flops_per_launch_out /* host */);
 

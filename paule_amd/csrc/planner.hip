@@ -2675,7 +2675,38 @@ int pl_inverse_forward(pl_handle* h, const float* mel, int n_mel_frames, float* 
 
 int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg_ms_out, double* flops_per_launch_out) {
     if (!h || !avg_ms_out || reps < 1) return fail(PL_ERR_INVALID, "pl_bench_kernel: bad argument");
-    if (kernel < PL_KERNEL_LSTM_FWD_STEP || kernel > PL_KERNEL_FUSED_FWD) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
+    if (kernel < PL_KERNEL_LSTM_FWD_STEP || kernel > PL_KERNEL_FUSED_BWD) return fail(PL_ERR_INVALID, "pl_bench_kernel: unknown kernel");
+    if (kernel == PL_KERNEL_FUSED_BWD) {
+        if (!h->fused_bwd_ok || !h->pred.ready() || !h->emb.ready())
+            return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: this handle does not run the fused backward launch");
+        DeviceGuard guard(h->cfg.device);
+        SweepChain chain(h->cfg.device, h->stream);
+        hipEvent_t e0, e1;
+        PL_HIP(hipEventCreate(&e0));
+        PL_HIP(hipEventCreate(&e1));
+        PL_HIP(hipEventRecord(e0, h->stream));
+        for (int i = 0; i < reps; ++i) {   // the launch alone (+ the flag zeroing), on whatever the last iteration left in the stashes: its
+            zero_all_sweep_slots(h, h->stream);   // time does not depend on the data, and every pl_step rebuilds what it overwrites
+            FusedArgs a{};
+            fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
+            launch_fused_bwd(h->stream, h->pred.Hp, a);
+            h->sweep_slot = -1;
+        }
+        PL_HIP(hipEventRecord(e1, h->stream));
+        PL_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms_out = ms / reps;
+        if (flops_per_launch_out) {   // backward-data recurrences of all layers, the dL/dh products between the embedder's layers, the
+            const double Hh = h->pred.H, He = h->emb.H;   // embedder's input gradient (-> mel) and the backward mel head
+            double f = 2.0 * 4 * Hh * Hh * (h->T - 1) + 2.0 * Hh * h->M * h->Tp;
+            f += h->emb.L * 2.0 * 4 * He * He * (h->Tp - 1) + (h->emb.L - 1) * 2.0 * 4 * He * He * h->Tp + 2.0 * 4 * He * h->M * h->Tp;
+            *flops_per_launch_out = (double)h->B * f;
+        }
+        return check_launch();
+    }
     if (kernel == PL_KERNEL_FUSED_FWD) {
         if (!h->fused_fwd_ok || !h->pred.ready() || !h->emb.ready())
             return fail(PL_ERR_UNSUPPORTED, "pl_bench_kernel: this handle does not run the fused forward launch");

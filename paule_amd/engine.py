@@ -503,10 +503,10 @@ class HipPlanner:
 
     def bench_kernel(self, kernel="bwd", model="pred", reps=300):
         """(avg ms per launch, algorithmic FLOPs per launch) of one LSTM kernel -- "fwd" / "bwd" = launch-per-step
-        kernels, "fwd_sweep" / "bwd_sweep" = persistent sweeps, "fused_fwd" = the fused acoustic forward launch -- timed with hipEvents
+        kernels, "fwd_sweep" / "bwd_sweep" = persistent sweeps, "fused_fwd" / "fused_bwd" = the fused acoustic launches -- timed with hipEvents
         on the engine's stream."""
         ms, fl = C.c_float(0), C.c_double(0)
-        kid = {"fwd": 0, "bwd": 1, "fwd_sweep": 2, "bwd_sweep": 3, "fused_fwd": 4}[kernel]
+        kid = {"fwd": 0, "bwd": 1, "fwd_sweep": 2, "bwd_sweep": 3, "fused_fwd": 4, "fused_bwd": 5}[kernel]
         self._call(self.lib.pl_bench_kernel, kid,
                    _capi.PL_MODEL_PRED if model == "pred" else _capi.PL_MODEL_EMBED, int(reps), C.byref(ms), C.byref(fl))
         return ms.value, fl.value

@@ -29,6 +29,7 @@ def main():
     for kname, key in (("fused_fwd_kernel", "fused_fwd_kernel"), ("fused_bwd_kernel", "fused_bwd_kernel"),
                        ("lstm_bwd16_rs_sweep_kernel", "lstm_bwd16_rs_sweep_kernel"), ("lstm_fwd16_sweep_kernel", "lstm_fwd16_sweep_kernel"),
                        ("lstm_bwd_sweep_f32_kernel", "lstm_bwd_sweep_f32_kernel"), ("lstm_fwd_sweep_f32_kernel", "lstm_fwd_sweep_f32_kernel"),
+                       ("lstm_bwd_rs_stream_kernel", "lstm_bwd_rs_stream_kernel"),
                        ("lstm_bwd_rs_sweep_kernel", "lstm_bwd_rs_sweep_kernel"), ("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"),
                        ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
                        ("lstm_bwd_step_kernel", "lstm_bwd_step_kernel"), ("lstm_fwd_step_kernel", "lstm_fwd_step_kernel"),
@@ -40,8 +41,8 @@ def main():
         # the predictive model's sweep (T = 300) is the longest launch of its kind: take the upper half by value
         fv.sort()
         wv.sort()
-        fbig = fv[len(fv) * 2 // 3:] if "sweep" in kname else fv
-        wbig = wv[len(wv) * 2 // 3:] if "sweep" in kname else wv
+        fbig = fv[len(fv) * 2 // 3:] if ("sweep" in kname or "stream" in kname) else fv
+        wbig = wv[len(wv) * 2 // 3:] if ("sweep" in kname or "stream" in kname) else wv
         fb = 2.0 * 1024.0 * (sum(fbig) / max(1, len(fbig)))
         wb = 1024.0 * (sum(wbig) / max(1, len(wbig)))
         res[key + "_bytes_per_launch"] = fb + wb
