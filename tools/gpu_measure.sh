@@ -33,7 +33,9 @@ for part in $parts; do
     pmc) pmc_pair cfg3 "" PAULE_HIP_XCD_FAST=2 ;;
     pmc_xcd) pmc_pair cfg3 _xcdfast0 PAULE_HIP_XCD_FAST=0
              pmc_pair cfg3 _unfused PAULE_HIP_FUSED=0 ;;
-    pmc_others) pmc_pair cfg2 "" PAULE_HIP_XCD_FAST=2
+    pmc_others) pmc_pair cfg3_setB "" PAULE_HIP_XCD_FAST=2
+                pmc_pair cfg5_128 "" PAULE_HIP_XCD_FAST=2
+                pmc_pair cfg2 "" PAULE_HIP_XCD_FAST=2
                 pmc_pair cfg5 "" PAULE_HIP_XCD_FAST=2 ;;
     others) for c in cfg1 cfg2 cfg2_setB cfg3_setB cfg3_setC cfg3_f32 cfg5 cfg5_setB cfg5_128 cfg4_1gpu cfg3_soma train8; do   # train8 etc. print one JSON line each
               run bench_$c 400 python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline
