@@ -468,3 +468,33 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["plumbing_only"] and out["n_gpus"] == 2 and out["gathered_rows"] == 16 and out["gathered_ranks_ok"]
     assert out["ms_per_step"] >= 0.02 * 1e3 / 2   # the slowest rank's time, not rank 0's
+
+
+def test_planner_cache_is_keyed_by_architecture_and_lru(small):
+    """the handle cache of Paule._get_planner -- keyed by the models' architecture (not by id(): a freed model's id can
+    come back), least recently used out, bounded by bytes, and the handle published as `paule.planner` is never closed under the
+    caller."""
+    closed = []
+
+    class Eng(OracleEngine):
+        device_bytes = 1 << 30
+
+        def close(self):
+            closed.append(self)
+
+    model = pp.Paule(pred_model=small.pred_sd, embedder=small.emb_sd, planner_factory=lambda p, e, **kw: Eng(p, e, **kw),
+                     device=torch.device("cpu"))
+    kw = dict(objective="acoustic", dtype="f32", lr=0.01, smiling=False, device="cpu")
+    a = model._get_planner(batch=1, n_frames=24, **kw)
+    assert model._get_planner(batch=1, n_frames=24, **kw) is a                    # same shape, same architecture: reused
+    model.pred_model = {k: v.clone() for k, v in model.pred_model.items()} if isinstance(model.pred_model, dict) else model.pred_model
+    assert model._get_planner(batch=1, n_frames=24, **kw) is a                    # another OBJECT of the same architecture: still reused
+    model.planner = a                                                             # published to the caller
+    model.PLANNER_CACHE_ENTRIES = 3
+    others = [model._get_planner(batch=1, n_frames=24 + 2 * i, **kw) for i in range(1, 5)]
+    assert a not in closed                                                        # never the published one
+    assert closed == others[:2]                                                   # the least recently used of the rest went first
+    assert len(model._planners) == 3
+    model.PLANNER_CACHE_BYTES = 2 << 30                                           # a byte bound below what is cached: trims further
+    b = model._get_planner(batch=2, n_frames=24, **kw)
+    assert b not in closed and a not in closed and len(model._planners) == 2
