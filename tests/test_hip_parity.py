@@ -348,6 +348,36 @@ def test_full_size_properties_bf16(HipPlanner, monkeypatch):
     eng.synchronize()
 
 
+@pytest.mark.parametrize("shape", [dict(B=144, T=61, set="A"), dict(B=270, T=17, set="A"), dict(B=256, T=24, set="B")])
+def test_backward_sweep_forms_are_bit_identical(HipPlanner, monkeypatch, shape):
+    """Round 3's two changes of the 32-row reduce-scatter backward sweep change no bit: tile products on four waves (round 2's kernel),
+    on eight waves with one hand-off per step, and on eight waves with per-tile flags, rotated tile order and streamed ingest (the
+    default) produce the same dA of every layer, the same dL/dCP, losses and plan.  Ragged last group (B = 144), more groups than
+    the chip holds at once (B = 270: a workgroup sweeps a second group), the stacked predictor's set (B: only the 720-wide embedder
+    runs this kernel)."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, shape["set"])
+    monkeypatch.setenv("PAULE_HIP_FUSED", "1")   # fused forward launch + per-layer backward sweeps, as cfg3 runs
+    out = {}
+    for form, env in (("w4", dict(PAULE_HIP_BWD_WAVES="4")), ("w8", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="0")),
+                      ("stream", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1"))):
+        for k in ("PAULE_HIP_BWD_WAVES", "PAULE_HIP_BWD_STREAM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        assert eng.plan_info()["bwd_waves"] == (4 if form == "w4" else 8)
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        loss = _n(eng.step(3))
+        eng.synchronize()
+        out[form] = dict(loss=loss, cp=_n(eng.get_cp()), dX=_n(eng.debug_read("dX")), G=_n(eng.debug_read("emb.G0")))
+        eng.close()
+    for form in ("w8", "stream"):
+        for k in ("loss", "cp", "dX", "G"):
+            np.testing.assert_array_equal(out[form][k], out["w4"][k], err_msg=f"{form}: {k}")
+
+
 def test_fused_launch_census_late_sign_in_keeps_the_first_cause(HipPlanner, monkeypatch):
     """the failure the census exists for is a workgroup that gets its CU LATE (a second process held it).  The resident
     workgroups give up after the census bound (status 2) and leave; the late one then signs in, completes the count -- and must
