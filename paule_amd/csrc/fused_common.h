@@ -159,7 +159,7 @@ __device__ __forceinline__ FusedWait uni(const FusedWait& w) {
 }
 __device__ __forceinline__ FusedRole uniform_role(const FusedRole& g) {
     FusedRole r;
-    r.type = uni(g.type); r.ksx = uni(g.ksx); r.C = uni(g.C); r.T = uni(g.T); r.flags = uni(g.flags); r.flags2 = uni(g.flags2);
+    r.type = uni(g.type); r.ksx = uni(g.ksx); r.wide = uni(g.wide); r.C = uni(g.C); r.T = uni(g.T); r.flags = uni(g.flags); r.flags2 = uni(g.flags2);
     r.wait[0] = uni(g.wait[0]); r.wait[1] = uni(g.wait[1]); r.wait[2] = uni(g.wait[2]);
     r.src_sc1 = uni(g.src_sc1);
     r.G = uni(g.G); r.W = uni(g.W); r.h = uni(g.h); r.c = uni(g.c); r.x_in = uni(g.x_in); r.Wih = uni(g.Wih); r.bias = uni(g.bias);

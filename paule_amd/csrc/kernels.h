@@ -116,6 +116,7 @@ struct FusedWait {
 struct FusedRole {
     int type;              // FR_*
     int ksx;               // FR_LSTM_FWD: k-steps (of 16) of the fused narrow input projection (2 / 4), 0 = G holds the projection
+    int wide;              // forward launch with two hidden sizes: 0 the role works at the predictor's width, 1 at the embedder's
     int C;                 // chains (batch groups of 32 rows) per workgroup; set s serves groups s * C .. s * C + C - 1
     int T;                 // time steps of the role
     int* flags;            // the role's own arrival flags [groups][T][flag_stride] (zeroed before the launch)
@@ -166,7 +167,10 @@ struct FusedArgs {
 };
 // hidden sizes (padded) the fused kernels are instantiated for
 bool fused_supported(int Hp);
-void launch_fused_fwd(hipStream_t stream, int Hp, const FusedArgs& a);
+// forward launch: the predictor's roles (recurrences of all its layers, the projections between them, the mel head) and the
+// embedder's may have different hidden sizes (model set B: 4 x 180 in front of 720)
+bool fused_fwd_supported(int Hp_pred, int Hp_emb);
+void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a);
 // zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
 void launch_zero_counters(hipStream_t stream, int* p, int n);

@@ -1184,21 +1184,10 @@ constexpr int fused_fwd_lds_bytes() {
     return (m + 15) / 16 * 16;
 }
 
+// The roles of one forward launch may have TWO hidden sizes (round 3): the predictor's (KSP: its recurrences, the projections between
+// its layers, the mel head) and the embedder's (KSE); a role's descriptor says which (`wide`).  Equal sizes instantiate one set.
 template <int KS>
-__global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[fused_fwd_lds_bytes<KS>()];
-    if ((int)blockIdx.x >= a.grid) return;
-    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
-    // readfirstlane: the table is read with vector loads, and a role index the compiler takes for divergent turns every access
-    // to the role's descriptor into a vector load with an s_waitcnt vmcnt(0) -- which also waits for the prefetched tiles
-    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
-              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
-    if (role < 0 || role >= a.n_roles) return;
-    // the role's descriptor stays in (constant) device memory: uniform address -> scalar loads; the role functions copy what
-    // their loops use into locals (the whole struct held in SGPRs crowds them out, read through LDS it costs a round trip per use)
-    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
-    __syncthreads();
-    const FusedRole R = uniform_role(a.roles[role]);
+__device__ __forceinline__ void fused_fwd_role(const FusedArgs& a, const FusedRole& R, int set, int p, unsigned char* lds) {
     switch (R.type) {
         case FR_LSTM_FWD:
             if (R.ksx == 2) fused_lstm_fwd<KS, 2>(a, R, set, p, lds);
@@ -1211,9 +1200,36 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
     }
 }
 
+template <int KSP, int KSE>
+__global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
+    constexpr int kLds = fused_fwd_lds_bytes<KSP>() > fused_fwd_lds_bytes<KSE>() ? fused_fwd_lds_bytes<KSP>() : fused_fwd_lds_bytes<KSE>();
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    // readfirstlane: the table is read with vector loads, and a role index the compiler takes for divergent turns every access
+    // to the role's descriptor into a vector load with an s_waitcnt vmcnt(0) -- which also waits for the prefetched tiles
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    // the role's descriptor stays in (constant) device memory: uniform address -> scalar loads; the role functions copy what
+    // their loops use into locals (the whole struct held in SGPRs crowds them out, read through LDS it costs a round trip per use)
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    const FusedRole R = uniform_role(a.roles[role]);
+    if constexpr (KSP == KSE) {
+        fused_fwd_role<KSE>(a, R, set, p, lds);
+    } else {
+        if (R.wide) fused_fwd_role<KSE>(a, R, set, p, lds);
+        else fused_fwd_role<KSP>(a, R, set, p, lds);
+    }
+}
+
 }  // namespace
 
 #define PL_FUSED_KS_LIST(X) X(6) X(46)
+// (predictor, embedder) hidden sizes / 16 of the forward launch: equal widths, and the class-default stacked predictor (4 x 180) in
+// front of a 720-wide embedder (model set B)
+#define PL_FUSED_FWD_PAIRS(X) X(6, 6) X(46, 46) X(12, 46)
 
 bool fused_supported(int Hp) {
 #define PL_CASE(K) if (Hp == 16 * K) return true;
@@ -1222,13 +1238,20 @@ bool fused_supported(int Hp) {
     return false;
 }
 
-void launch_fused_fwd(hipStream_t stream, int Hp, const FusedArgs& a) {
-#define PL_CASE(K)                                                                              \
-    if (Hp == 16 * K) {                                                                         \
-        hipLaunchKernelGGL(fused_fwd_kernel<K>, dim3(a.grid), dim3(256), 0, stream, a);         \
-        return;                                                                                 \
+bool fused_fwd_supported(int Hp_pred, int Hp_emb) {
+#define PL_CASE(KP, KE) if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) return true;
+    PL_FUSED_FWD_PAIRS(PL_CASE)
+#undef PL_CASE
+    return false;
+}
+
+void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a) {
+#define PL_CASE(KP, KE)                                                                               \
+    if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) {                                                    \
+        hipLaunchKernelGGL((fused_fwd_kernel<KP, KE>), dim3(a.grid), dim3(256), 0, stream, a);        \
+        return;                                                                                       \
     }
-    PL_FUSED_KS_LIST(PL_CASE)
+    PL_FUSED_FWD_PAIRS(PL_CASE)
 #undef PL_CASE
 }
 

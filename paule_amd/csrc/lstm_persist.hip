@@ -479,7 +479,17 @@ int lstm_sweep_grid(int Hp, int Bp, int n_cu, bool spread_small) {
     // workgroups (blockIdx % 8 == group) still land on one XCD and can use the verified same-XCD hand-off
     if (spread_small && groups < 8 && res >= 8) return 8 * P;
     if (res > groups) res = groups;
-    if (res >= 8) res = res / 8 * 8;   // a multiple of the XCD count keeps a group's workgroups on one XCD (speed only)
+    // Resident groups: as few as sweep all groups in the fewest passes (a workgroup takes its groups in turn), and a multiple of the
+    // XCD count where that costs no pass -- it keeps a group's workgroups on one XCD (speed only: the verified same-XCD hand-off).
+    // Round 2 rounded DOWN to a multiple of 8 unconditionally: 12 groups of the 4 x 180 predictor then took two passes on 8 slots
+    // where 12 fit at once (set B at B = 192: 14.2 ms per iteration against 6.7 ms at B = 256), 64 groups of cfg4_1gpu 8 passes
+    // instead of 6.
+    if (res >= 1) {
+        const int cap = res, passes = (groups + cap - 1) / cap;
+        res = (groups + passes - 1) / passes;
+        const int r8 = (res + 7) / 8 * 8;
+        if (r8 <= cap) res = r8;
+    }   // a multiple of the XCD count keeps a group's workgroups on one XCD (speed only)
     return res < 1 ? 0 : res * P;
 }
 

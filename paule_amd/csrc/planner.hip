@@ -353,7 +353,7 @@ void zero_all_sweep_slots(pl_handle* h, hipStream_t st) {
     // only what this handle's plan hands out is zeroed (a handle without fused launches does not pay for their slices: ADVICE r2)
     int n_used = h->n_sweep_slots;
     if (h->cfg.emb_layers > 0) {
-        const int n_roles = 3 + 2 * (h->cfg.emb_layers - 1), n_fused = 2 * n_roles + (h->cfg.emb_layers - 1);
+        const int n_roles = (2 * h->cfg.pred_layers - 1) + 1 + (2 * h->cfg.emb_layers - 1), n_fused = 2 * n_roles + (h->cfg.emb_layers - 1);
         n_used = h->n_sweep_slots - n_fused;
         if (h->fused_bwd_ok) n_used = h->n_sweep_slots;
         else if (h->fused_fwd_ok) n_used += n_roles;
@@ -1256,6 +1256,16 @@ void tube_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs
 // Placement (speed only): the grid has one block per CU, block b sits on XCD b % 8 (observed dealing); a recurrence set's
 // P workgroups take consecutive depths of ONE XCD slot while one has room, everything else fills what is left.
 struct FusedSet { int role, set, P; bool together; };
+// Role indices of the fused launches.  Forward: the predictor's layers first -- recurrence of layer l at 2 l, the projection that
+// feeds it (l >= 1) at 2 l - 1 -- then the mel head, then the embedder: its first layer, and per further layer its projection and its
+// recurrence.  With a one-layer predictor (the only shape the backward launch takes) that is 0 predictor, 1 head, 2 embedder layer 1,
+// 3 + 2 (l - 1) / 4 + 2 (l - 1) projection / recurrence of embedder layer l: the numbering the backward roles use.
+inline int fused_roles_count(int pred_layers, int emb_layers) { return (2 * pred_layers - 1) + 1 + (2 * emb_layers - 1); }
+inline int fr_pred(int l) { return 2 * l; }
+inline int fr_pred_proj(int l) { return 2 * l - 1; }
+inline int fr_head(int pL) { return 2 * pL - 1; }
+inline int fr_emb(int pL, int l) { return 2 * pL + 2 * l; }
+inline int fr_emb_proj(int pL, int l) { return 2 * pL + 2 * l - 1; }
 
 std::vector<short> fused_block_table(int n_cu, const std::vector<FusedSet>& sets, int* grid_out) {
     const int slots = 8, depth = n_cu / slots;
@@ -1304,11 +1314,18 @@ int plan_fused(pl_handle* h) {
     if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
     const Model &p = h->pred, &e = h->emb;
     if (!(mode & 3) || h->dt != BF16 || !h->use_sweep || !h->fuse_input || h->Bp < min_rows) return PL_OK;
-    if (p.L != 1 || e.L < 1 || e.L > 4 || p.Hp != e.Hp || !fused_supported(p.Hp) || p.Hp / 32 > 31) return PL_OK;
+    // the forward launch takes a stacked predictor (all its layers one width) in front of an embedder of another width (round 3: the
+    // class-default 4 x 180 predictor of model set B); the backward launch one predictor layer and equal widths, as before
+    const bool fwd_shape = p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_fwd_supported(p.Hp, e.Hp) && p.Hp / 32 <= 31 && e.Hp / 32 <= 31;
+    const bool bwd_shape = p.L == 1 && p.Hp == e.Hp && fused_supported(p.Hp);
+    if (!fwd_shape && !bwd_shape) return PL_OK;
+    if (!fwd_shape) mode &= ~1;
+    if (!bwd_shape) mode &= ~2;
+    if (!(mode & 3)) return PL_OK;
     if (p.layers[0].in_p != 32 || e.layers[0].in_p != 64 || h->Mp != 64 || h->emb_post > 0 || h->emb_blocks > 0) return PL_OK;
     if (!h->need_emb_in_step() || h->n_cu % 8 != 0) return PL_OK;
-    const int P = p.Hp / 32, ng = (h->Bp + 31) / 32, n_emb_roles = 2 * e.L - 1;
-    if (3 + 2 * (e.L - 1) > kFusedMaxRoles) return PL_OK;
+    const int Pp = p.Hp / 32, Pe = e.Hp / 32, P = Pe, ng = (h->Bp + 31) / 32, n_emb_roles = 2 * e.L - 1, n_pred_roles = 2 * p.L - 1;
+    if (fused_roles_count(p.L, e.L) > kFusedMaxRoles) return PL_OK;
     int forced_p = 0, forced_e = 0;
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CP")) forced_p = std::atoi(z);
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CE")) forced_e = std::atoi(z);
@@ -1319,7 +1336,10 @@ int plan_fused(pl_handle* h) {
         for (int ce = 1; ce <= cmax; ++ce) {
             if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
             const int sp = (ng + cp - 1) / cp, se = (ng + ce - 1) / ce;
-            if (sp * (P + 1) + se * P * n_emb_roles > h->n_cu || sp * P + se * (1 + P * n_emb_roles) > h->n_cu) continue;
+            // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward (equal widths):
+            // one head workgroup per embedder set
+            if (sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > h->n_cu) continue;
+            if ((mode & 2) && sp * Pp + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
             const double tp = std::max(cp * 2.1, 4.2), te = std::max(ce * 2.1, 4.2) / 2.0;
             const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
             if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
@@ -1327,17 +1347,20 @@ int plan_fused(pl_handle* h) {
     if (!best_cp) return PL_OK;
     const int sp = (ng + best_cp - 1) / best_cp, se = (ng + best_ce - 1) / best_ce;
     h->fused_Cp = best_cp; h->fused_Ce = best_ce;
-    h->fused_n_roles = 3 + 2 * (e.L - 1);
+    h->fused_n_roles = fused_roles_count(p.L, e.L);
     int rc;
     if (mode & 1) {
         std::vector<FusedSet> sets;
-        for (int s = 0; s < sp; ++s) sets.push_back({0, s, P, true});
-        for (int s = 0; s < se; ++s) sets.push_back({2, s, P, true});
+        for (int l = 0; l < p.L; ++l)
+            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred(l), s, Pp, true});
+        for (int s = 0; s < se; ++s) sets.push_back({fr_emb(p.L, 0), s, Pe, true});
         for (int l = 1; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({4 + 2 * (l - 1), s, P, true});
+            for (int s = 0; s < se; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
+        for (int l = 1; l < p.L; ++l)
+            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
         for (int l = 1; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({3 + 2 * (l - 1), s, P, false});
-        for (int s = 0; s < sp; ++s) sets.push_back({1, s, 1, false});
+            for (int s = 0; s < se; ++s) sets.push_back({fr_emb_proj(p.L, l), s, Pe, false});
+        for (int s = 0; s < sp; ++s) sets.push_back({fr_head(p.L), s, 1, false});
         int grid = 0;
         std::vector<short> tab = fused_block_table(h->n_cu, sets, &grid);
         if (grid > 0 && grid <= h->n_cu) {
@@ -1421,38 +1444,49 @@ int build_fused_roles(pl_handle* h) {
         std::vector<FusedRole> roles(n_roles);
         int* fl[kFusedMaxRoles];
         for (int r = 0; r < n_roles; ++r) fl[r] = fused_slice(h, r, false);
-        {   // 0: predictor recurrence, CP input fused
-            FusedRole& R = roles[0];
-            LstmLayer& ly = p.layers[0];
-            R.type = FR_LSTM_FWD; R.ksx = ly.in_p / 16; R.C = h->fused_Cp; R.T = T; R.flags = fl[0];
-            R.wait[0] = FusedWait{fl[0], T, P, 0, 0, -1};
-            R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c; R.x_in = h->X0; R.Wih = ly.Wih; R.bias = ly.bias;
+        const int Pp = p.Hp / 32, Pe = e.Hp / 32, pL = p.L;
+        for (int l = 0; l < pL; ++l) {   // the predictor's layers: CP input fused into the first, a projection role in front of every further one
+            LstmLayer& ly = p.layers[l];
+            FusedRole& R = roles[fr_pred(l)];
+            R.type = FR_LSTM_FWD; R.wide = 0; R.C = h->fused_Cp; R.T = T; R.flags = fl[fr_pred(l)];
+            R.wait[0] = FusedWait{fl[fr_pred(l)], T, Pp, 0, 0, -1};
+            R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c;
+            if (l == 0) {
+                R.ksx = ly.in_p / 16; R.x_in = h->X0; R.Wih = ly.Wih; R.bias = ly.bias;
+            } else {
+                R.ksx = 0; R.src_sc1 = 1;
+                R.wait[2] = FusedWait{fl[fr_pred_proj(l)], T, 1, 1, 0, 0};
+                FusedRole& Rp = roles[fr_pred_proj(l)];
+                Rp.type = FR_PROJ_FWD; Rp.wide = 0; Rp.C = h->fused_Cp; Rp.T = T; Rp.flags = fl[fr_pred_proj(l)];
+                Rp.wait[0] = FusedWait{fl[fr_pred(l - 1)], T, Pp, 0, 0, 0};
+                Rp.src_h = p.layers[l - 1].h; Rp.Wg = ly.Wih; Rp.bias = ly.bias; Rp.out = ly.G;
+            }
         }
-        {   // 1: mel head on every predictor step, pooled pairs out
-            FusedRole& R = roles[1];
-            R.type = FR_HEAD_FWD; R.C = h->fused_Cp; R.T = 2 * Tp; R.flags = fl[1];
-            R.wait[0] = FusedWait{fl[0], T, P, 0, 0, 0};
-            R.src_h = p.layers[0].h; R.Wg = p.Wlin; R.bias = p.blin; R.out = h->mel_tm; R.out_bm = h->mel_bm; R.out_dim = h->M; R.out_p = h->Mp;
+        {   // mel head on every step of the predictor's top layer, pooled pairs out
+            FusedRole& R = roles[fr_head(pL)];
+            R.type = FR_HEAD_FWD; R.wide = 0; R.C = h->fused_Cp; R.T = 2 * Tp; R.flags = fl[fr_head(pL)];
+            R.wait[0] = FusedWait{fl[fr_pred(pL - 1)], T, Pp, 0, 0, 0};
+            R.src_h = p.layers[pL - 1].h; R.Wg = p.Wlin; R.bias = p.blin; R.out = h->mel_tm; R.out_bm = h->mel_bm; R.out_dim = h->M; R.out_p = h->Mp;
         }
-        {   // 2: embedder layer 1, pooled mel input fused
-            FusedRole& R = roles[2];
+        {   // embedder layer 1, pooled mel input fused
+            FusedRole& R = roles[fr_emb(pL, 0)];
             LstmLayer& ly = e.layers[0];
-            R.type = FR_LSTM_FWD; R.ksx = ly.in_p / 16; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[2];
-            R.wait[0] = FusedWait{fl[2], Tp, P, 0, 0, -1};
-            R.wait[1] = FusedWait{fl[1], Tp, 1, 0, 0, 0};
+            R.type = FR_LSTM_FWD; R.wide = 1; R.ksx = ly.in_p / 16; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[fr_emb(pL, 0)];
+            R.wait[0] = FusedWait{fl[fr_emb(pL, 0)], Tp, Pe, 0, 0, -1};
+            R.wait[1] = FusedWait{fl[fr_head(pL)], Tp, 1, 0, 0, 0};
             R.src_sc1 = 1;
             R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c; R.x_in = h->mel_tm; R.Wih = ly.Wih; R.bias = ly.bias;
         }
         for (int l = 1; l < e.L; ++l) {
             LstmLayer& ly = e.layers[l];
-            const int rp = 3 + 2 * (l - 1), rl = rp + 1, rsrc = l == 1 ? 2 : rl - 2;
+            const int rp = fr_emb_proj(pL, l), rl = fr_emb(pL, l), rsrc = fr_emb(pL, l - 1);
             FusedRole& Rp = roles[rp];
-            Rp.type = FR_PROJ_FWD; Rp.C = h->fused_Ce; Rp.T = Tp; Rp.flags = fl[rp];
-            Rp.wait[0] = FusedWait{fl[rsrc], Tp, P, 0, 0, 0};
+            Rp.type = FR_PROJ_FWD; Rp.wide = 1; Rp.C = h->fused_Ce; Rp.T = Tp; Rp.flags = fl[rp];
+            Rp.wait[0] = FusedWait{fl[rsrc], Tp, Pe, 0, 0, 0};
             Rp.src_h = e.layers[l - 1].h; Rp.Wg = ly.Wih; Rp.bias = ly.bias; Rp.out = ly.G;
             FusedRole& Rl = roles[rl];
-            Rl.type = FR_LSTM_FWD; Rl.ksx = 0; Rl.C = h->fused_Ce; Rl.T = Tp; Rl.flags = fl[rl];
-            Rl.wait[0] = FusedWait{fl[rl], Tp, P, 0, 0, -1};
+            Rl.type = FR_LSTM_FWD; Rl.wide = 1; Rl.ksx = 0; Rl.C = h->fused_Ce; Rl.T = Tp; Rl.flags = fl[rl];
+            Rl.wait[0] = FusedWait{fl[rl], Tp, Pe, 0, 0, -1};
             Rl.wait[2] = FusedWait{fl[rp], Tp, 1, 1, 0, 0};
             Rl.src_sc1 = 1;
             Rl.G = ly.G; Rl.W = ly.Whh; Rl.h = ly.h; Rl.c = ly.c;
@@ -1524,7 +1558,7 @@ bool fused_acoustic_forward(pl_handle* h, hipStream_t st) {
     launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_fwd, h->fused_tab_fwd, h->fused_roles_fwd, false);
-    launch_fused_fwd(st, h->pred.Hp, a);
+    launch_fused_fwd(st, h->pred.Hp, h->emb.Hp, a);
     return true;
 }
 
@@ -2031,7 +2065,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
         // forward + backward sweep of every layer of an iteration, + the head / projection roles of the fused launches
         h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers) +
-                           (cfg->emb_layers > 0 ? 2 * (3 + 2 * (cfg->emb_layers - 1)) + (cfg->emb_layers - 1) : 0);
+                           (cfg->emb_layers > 0 ? 2 * fused_roles_count(cfg->pred_layers, cfg->emb_layers) + (cfg->emb_layers - 1) : 0);
         if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
 #ifdef PL_STAMPS

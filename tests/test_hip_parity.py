@@ -452,6 +452,26 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
 
 
+@pytest.mark.parametrize("shape", [dict(B=256, T=60, graph=True), dict(B=70, T=31, graph=False)])
+def test_fused_forward_stacked_predictor_is_bit_identical(HipPlanner, monkeypatch, shape):
+    """Round 3: the fused forward launch takes the class-default STACKED predictor (4 x 180, paule/models.py:335-339) in front of
+    a 720-wide embedder (model set B) -- its four recurrences and the three projections between them as further roles at the
+    predictor's width, the mel head on the top layer, the embedder's roles at its own width.  Every forward stash of every layer,
+    the pooled mel, the losses and the plan equal the per-layer path's (32-row kernels) bit for bit; full groups with a graph, a
+    ragged batch eagerly."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "B")
+    bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
+    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False)
+    for name in bufs:
+        np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
+    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, shape["graph"])
+    np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
+    np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
+
+
 @pytest.mark.parametrize("extra", [dict(objective="semvec"), dict(objective="acoustic_semvec", smiling=True),
                                    dict(objective="acoustic_semvec", classifier=True, past=True)])
 def test_fused_launches_other_objectives_vs_oracle(HipPlanner, extra):
