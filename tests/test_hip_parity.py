@@ -1100,6 +1100,7 @@ def test_layer_wavefront_is_bit_identical(HipPlanner, shape, monkeypatch):
     bit-identical to the layer-after-layer schedule, for any number of chunks (uneven chunk lengths included), with and
     without graph capture."""
     wl = synthetic.make_workload(shape["B"], shape["T"], shape["set"])
+    monkeypatch.setenv("PAULE_HIP_FUSED", "0")   # (from 49 rows the stacked predictor's forward pass is a fused launch by default: round 3)
     outs = []
     for chunks in ("0", "4", "7"):
         monkeypatch.setenv("PAULE_HIP_WAVEFRONT", chunks)
@@ -1515,8 +1516,10 @@ _GRAD_FAMILIES = [
     ("fused launches, three embedder layers", dict(B=128, T=20, pred=(1, 720), emb=(3, 720)), {}),
     ("fused forward launch, 32-row backward sweeps", dict(B=160, T=20, pred=(1, 720), emb=(2, 720)), {}),
     ("per-layer 32-row sweeps", dict(B=160, T=20, pred=(1, 720), emb=(2, 720)), {"PAULE_HIP_FUSED": "0"}),
-    ("stacked predictor (set B), 16-row sweeps + wavefront", dict(B=100, T=24, pred=(4, 180), emb=(1, 720)), {}),
-    ("stacked predictor (set B), B = 256", dict(B=256, T=20, pred=(4, 180), emb=(1, 720)), {}),
+    ("stacked predictor (set B), 16-row sweeps + wavefront", dict(B=100, T=24, pred=(4, 180), emb=(1, 720)), {"PAULE_HIP_FUSED": "0"}),
+    ("stacked predictor (set B), fused forward launch of two widths, ragged", dict(B=100, T=24, pred=(4, 180), emb=(1, 720), fused_fwd=1), {}),
+    ("stacked predictor (set B), B = 256, fused forward launch", dict(B=256, T=20, pred=(4, 180), emb=(1, 720), fused_fwd=1), {}),
+    ("stacked predictor (set B), B = 256, per-layer path", dict(B=256, T=20, pred=(4, 180), emb=(1, 720)), {"PAULE_HIP_FUSED": "0"}),
     ("2 x 360 / 2 x 360", dict(B=40, T=30, pred=(2, 360), emb=(2, 360)), {}),
     ("tiny ragged model, odd T", dict(B=5, T=31, pred=(1, 48), emb=(1, 40)), {}),
     ("launch-per-step kernels", dict(B=20, T=30, pred=(1, 96), emb=(2, 96)), {"PAULE_HIP_NO_SWEEP": "1"}),
@@ -1540,6 +1543,8 @@ def test_bf16_model_gradient_across_kernel_families(HipPlanner, case, monkeypatc
     ex.set_cp(wl.cp0.numpy())
     _, _, px = mo.loss_and_grad(ex.models, "acoustic_semvec", ex.x, ex.target_mel, ex.target_semvec)
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    if "fused_fwd" in c:   # the family this case names is the one the library planned
+        assert eng.plan_info()["fused_fwd"] == c["fused_fwd"], eng.plan_info()
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     eng.step(1, return_loss=False)
