@@ -287,7 +287,9 @@ enum { PL_PLAN_FUSED_FWD = 0,      /* 1: role-fused forward launch, 0: per-layer
        PL_PLAN_FWD_WORKGROUPS = 6, PL_PLAN_BWD_WORKGROUPS = 7,    /* role-bearing workgroups of the fused launches */
        PL_PLAN_BWD_WAVES = 8,      /* waves per workgroup of the per-layer reduce-scatter backward sweep (4 or 8) */
        PL_PLAN_N_CU = 9,
-       PL_PLAN_COUNT = 10 };
+       PL_PLAN_RETAINED_EXECS = 10, /* process-wide: graph execs with parallel branches that retired handles left allocated (host
+                                    * memory; the HIP runtime crashes at a later branched launch once such execs are destroyed) */
+       PL_PLAN_COUNT = 11 };
 int pl_plan_info(const pl_handle *h, int32_t *out /* host */, int n);
 
 /* Bytes of device memory held by the handle. */

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/paule_hip.h"
@@ -1679,6 +1680,9 @@ int check_launch() {
 }
 
 static const bool g_dbg_graph = std::getenv("PAULE_HIP_DEBUG_GRAPH") != nullptr;
+// graph execs with parallel branches that retired handles left allocated (see drop_graph): counted, so that a host can see the leak
+// the containment of the runtime crash costs (pl_plan_info: PL_PLAN_RETAINED_EXECS, process-wide)
+static std::atomic<int> g_retained_branched_execs{0};
 #define DBG_G(msg) do { if (g_dbg_graph) { fprintf(stderr, "[pl] %s\n", msg); fflush(stderr); } } while (0)
 void drop_graph(pl_handle* h) {
     if (!h->graph_exec && !h->graph) return;
@@ -1694,6 +1698,7 @@ void drop_graph(pl_handle* h) {
     // tools/microbench/capture_stress.py reproduces it with PAULE_HIP_DESTROY_BRANCHED=1, 720 handles pass without).  The exec
     // of a retired handle stays allocated for the life of the process (kernel arguments only; device buffers are freed).
     if (h->graph_exec && (h->wf_regions.empty() || std::getenv("PAULE_HIP_DESTROY_BRANCHED"))) (void)hipGraphExecDestroy(h->graph_exec);
+    else if (h->graph_exec) g_retained_branched_execs.fetch_add(1, std::memory_order_relaxed);
     DBG_G("drop: graph destroy");
     if (h->graph) (void)hipGraphDestroy(h->graph);
     DBG_G("drop: done");
@@ -2885,6 +2890,7 @@ int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
         h->fused_bwd_ok ? h->fused_active_bwd : 0,
         h->bwd_waves,
         h->n_cu,
+        g_retained_branched_execs.load(std::memory_order_relaxed),
     };
     for (int i = 0; i < n && i < PL_PLAN_COUNT; ++i) out[i] = v[i];
     for (int i = PL_PLAN_COUNT; i < n; ++i) out[i] = 0;

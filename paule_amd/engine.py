@@ -512,7 +512,7 @@ class HipPlanner:
         return ms.value, fl.value
 
     PLAN_FIELDS = ("fused_fwd", "fused_bwd", "fwd_chains_pred", "fwd_chains_emb", "bwd_chains_pred", "bwd_chains_emb",
-                   "fwd_workgroups", "bwd_workgroups", "bwd_waves", "n_cu")
+                   "fwd_workgroups", "bwd_workgroups", "bwd_waves", "n_cu", "retained_execs")
 
     def plan_info(self):
         """The launch schedule the library planned for this handle (include/paule_hip.h: pl_plan_info) as a dict:
