@@ -1,6 +1,5 @@
-// Device helpers shared by the role-fused launches (lstm_fused.hip: round 2's one-wave-per-SIMD roles and the backward launch;
-// lstm_fused8.hip: round 3's forward launch with two waves per SIMD): global-address-space accessors, flag polls, bounded waits,
-// the residency census and the uniform copy of a role descriptor.
+// Device helpers of the role-fused launches (lstm_fused.hip; also included by the experiments under tools/experiments/):
+// global-address-space accessors, flag polls, bounded waits, the residency census and the uniform copy of a role descriptor.
 #pragma once
 #include "sweep_common.h"
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time of the fused forward launch alone (pl_bench_kernel: hipEvents around `reps` launches) for engine variants.
-usage: fwd_probe.py "B:VAR=a,VAR2=b" ...     e.g.  fwd_probe.py 256:PAULE_HIP_FUSED_W8=0 256:PAULE_HIP_FUSED_W8=1,PAULE_HIP_FUSED_CP=2
+usage: fwd_probe.py "B:VAR=a,VAR2=b" ...     e.g.  fwd_probe.py 256: 256:PAULE_HIP_FUSED_CP=4,PAULE_HIP_FUSED_CE=4 128:
+(written for the forward-pipeline experiment of round 3, tools/experiments/lstm_fused8.hip, whose PAULE_HIP_FUSED_W8 switch no longer exists)
 env: FP_FRAMES (300), FP_REPS (20)"""
 import os
 import sys
