@@ -165,6 +165,7 @@ __device__ __forceinline__ FusedRole uniform_role(const FusedRole& g) {
     r.src_h = uni(g.src_h); r.Wg = uni(g.Wg); r.out = uni(g.out); r.out_bm = uni(g.out_bm); r.out_dim = uni(g.out_dim); r.out_p = uni(g.out_p);
     r.dh_ext = uni(g.dh_ext); r.dh_ext_half = uni(g.dh_ext_half); r.dh_ext_rows = uni(g.dh_ext_rows); r.dh_last = uni(g.dh_last);
     r.dA_sc1 = uni(g.dA_sc1); r.xchg = uni(g.xchg); r.xchg_ext = uni(g.xchg_ext); r.xchg_mel = uni(g.xchg_mel);
+    r.fast_flags = uni(g.fast_flags); r.xtab = uni(g.xtab); r.hx = uni(g.hx);
     return r;
 }
 

@@ -150,6 +150,10 @@ struct FusedRole {
                            // FR_DX_BWD: where it writes them
     void* xchg_mel;        // LSTM: partial tiles of this layer's input gradient, out_p / 32 tiles per source [ring][groups][out_p / 32][P][32][32]
                            // (null: none); backward head: where it reads them
+    // 16-row LSTM roles (launch_fused_fwd16 / _bwd16: batches of up to 16 rows): the verified same-XCD form of the role's OWN exchange
+    int* fast_flags;       // second flag set [T][flag_stride], stored plain / polled nt once the role found itself on one XCD
+    int* xtab;             // [P] XCD ids (+ 1) of the role's workgroups, written with their first hand-off
+    void* hx;              // forward: private copy of the h hand-off [2 slots][16][Hp] (plain stores, nt loads); `h` stays write-through
 };
 struct FusedArgs {
     int Bp, B, n_groups, flag_stride, n_roles, grid;
@@ -172,6 +176,9 @@ bool fused_supported(int Hp);
 bool fused_fwd_supported(int Hp_pred, int Hp_emb);
 void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a);
+// the same role tables with the LSTM roles on 16 batch rows (v_mfma_f32_16x16x32_bf16, one chain): batches of up to 16 rows
+void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
+void launch_fused_bwd16(hipStream_t stream, int Hp, const FusedArgs& a);
 // zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
 void launch_zero_counters(hipStream_t stream, int* p, int n);
 

@@ -24,6 +24,7 @@
 // Arithmetic is that of the per-layer path, instruction for instruction (same MFMA shapes and k order per output element):
 // the forward results are bit-identical to it (tests/test_hip_parity.py::test_fused_forward_is_bit_identical).
 #include "fused_common.h"
+#include "lstm_fused16.h"
 
 #ifndef FUSED_BWD_ANSWER_AT
 #define FUSED_BWD_ANSWER_AT 1   // backward recurrence: next chain-step's flag answer + prefetch issue 0 before / 1 half way through / 2 after the tiles
@@ -1224,6 +1225,73 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
     }
 }
 
+// ---- the same tables with the LSTM roles on 16 batch rows (lstm_fused16.h): batches of up to 16 rows --------------------------------
+template <int KS>
+constexpr int fused_fwd16_lds_bytes() {
+    int m = LstmFwd16Lds<KS, 0>::BYTES;
+    m = m > LstmFwd16Lds<KS, 1>::BYTES ? m : LstmFwd16Lds<KS, 1>::BYTES;
+    m = m > LstmFwd16Lds<KS, 2>::BYTES ? m : LstmFwd16Lds<KS, 2>::BYTES;
+    m = m > GemmFwdLds<KS>::BYTES ? m : GemmFwdLds<KS>::BYTES;
+    return (m + 15) / 16 * 16;
+}
+
+template <int KS>
+__device__ __forceinline__ void fused_fwd16_role(const FusedArgs& a, const FusedRole& R, int set, int p, unsigned char* lds) {
+    switch (R.type) {
+        case FR_LSTM_FWD:   // the descriptor counts the fused input projection in k-steps of 16 (in_p = 32 -> 2, 64 -> 4)
+            if (R.ksx == 2) fused_lstm_fwd16<KS, 1>(a, R, set, p, lds);
+            else if (R.ksx == 4) fused_lstm_fwd16<KS, 2>(a, R, set, p, lds);
+            else fused_lstm_fwd16<KS, 0>(a, R, set, p, lds);
+            break;
+        case FR_PROJ_FWD: fused_gemm_fwd<KS, false>(a, R, set, p, lds); break;
+        case FR_HEAD_FWD: fused_gemm_fwd<KS, true>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
+template <int KSP, int KSE>
+__global__ __launch_bounds__(256, 1) void fused_fwd16_kernel(FusedArgs a) {
+    constexpr int kLds = fused_fwd16_lds_bytes<KSP>() > fused_fwd16_lds_bytes<KSE>() ? fused_fwd16_lds_bytes<KSP>() : fused_fwd16_lds_bytes<KSE>();
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    const FusedRole R = uniform_role(a.roles[role]);
+    if constexpr (KSP == KSE) {
+        fused_fwd16_role<KSE>(a, R, set, p, lds);
+    } else {
+        if (R.wide) fused_fwd16_role<KSE>(a, R, set, p, lds);
+        else fused_fwd16_role<KSP>(a, R, set, p, lds);
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void fused_bwd16_kernel(FusedArgs a) {
+    constexpr int kLds = LstmBwdLds<KS>::BYTES > LstmBwd16Lds<KS>::BYTES ? LstmBwdLds<KS>::BYTES : LstmBwd16Lds<KS>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(kLds + 15) / 16 * 16];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    const FusedRole R = uniform_role(a.roles[role]);
+    switch (R.type) {
+        case FR_LSTM_BWD:
+            if (R.xchg_mel) fused_lstm_bwd16<KS, true>(a, R, set, p, lds);
+            else fused_lstm_bwd16<KS, false>(a, R, set, p, lds);
+            break;
+        case FR_DX_BWD: fused_dx_bwd<KS>(a, R, set, p, lds); break;
+        case FR_HEAD_BWD: fused_head_bwd<KS>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
 }  // namespace
 
 #define PL_FUSED_KS_LIST(X) X(6) X(46)
@@ -1252,6 +1320,26 @@ void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedAr
         return;                                                                                       \
     }
     PL_FUSED_FWD_PAIRS(PL_CASE)
+#undef PL_CASE
+}
+
+void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a) {
+#define PL_CASE(KP, KE)                                                                               \
+    if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) {                                                    \
+        hipLaunchKernelGGL((fused_fwd16_kernel<KP, KE>), dim3(a.grid), dim3(256), 0, stream, a);      \
+        return;                                                                                       \
+    }
+    PL_FUSED_FWD_PAIRS(PL_CASE)
+#undef PL_CASE
+}
+
+void launch_fused_bwd16(hipStream_t stream, int Hp, const FusedArgs& a) {
+#define PL_CASE(K)                                                                              \
+    if (Hp == 16 * K) {                                                                         \
+        hipLaunchKernelGGL(fused_bwd16_kernel<K>, dim3(a.grid), dim3(256), 0, stream, a);       \
+        return;                                                                                 \
+    }
+    PL_FUSED_KS_LIST(PL_CASE)
 #undef PL_CASE
 }
 

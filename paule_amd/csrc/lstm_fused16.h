@@ -1,0 +1,599 @@
+// LSTM roles of the fused launches for batches of UP TO 16 ROWS (the reference plans one utterance, paule/paule.py:585-588;
+// continued learning uses mini-batches of 8, :404; BASELINE configs[4] leaves 16 utterances per GPU).
+//
+// Why.  A recurrence of one 16-row group is pure latency: 2 x 23 MFMAs of 16 x 16 x 32 and a 23-KB operand per step.  The 32-row
+// roles (lstm_fused.hip) spend a 32 x 32 x 16 chain and a 46-KB tile on it (3.8 us per forward step at B = 16 against 2.8 us of
+// the 16-row per-layer kernel, lstm_persist16.hip), which is why batches of up to 48 rows stayed on the chunk pipelines over
+// hardware queues (planner.hip, 4.1f) -- and those pay a pipeline fill of one chunk per stage (cfg5: 3.8 of 18.8 ms) that more
+// chunks do not shrink: the runtime folds the branches of a captured graph onto four queues and the pipeline drains in the
+// middle (profiles/r03_timeline_cfg5_pipelines8.txt).  Inside ONE launch a dependency costs a flag, not a queue:
+//
+//  * the arithmetic of lstm_persist16.hip (A tiles ordered [unit][gate], two 16-row tiles per wave forward; 46 N tiles of 16
+//    hidden units backward, wide ingest, every wave hands its own tiles over), as roles of the fused launches' tables: same
+//    flags, same stashes, same product roles (mel head, projections, dL/dh products, backward mel head: those keep their
+//    32-row tiles and guard the rows that do not exist);
+//  * the role's OWN exchange takes the verified same-XCD form of the per-layer kernels (sweep_common.h): the host table puts a
+//    recurrence's 23 workgroups on one XCD slot, every workgroup publishes the XCD it runs on with its first hand-off, and a
+//    role that finds itself on one XCD switches its own hand-off to plain stores / nt loads (served by that XCD's L2) and
+//    its own flags to a second, plain flag set.  What OTHER roles read stays write-through: the forward role stores h twice
+//    (a private 2-slot copy for itself, the stash for everybody else), and the write-through flag of a step is raised one step
+//    late, at a barrier every wave reaches with its stores drained anyway -- off the recurrence's critical path;
+//  * what a step needs from another role (`FusedWait` 1 and 2) is looked at ONE STEP AHEAD by a wave that does not poll
+//    (wave 3): in steady state the producers are ahead, the blocking wait then polls the role's own flags only (an L2 round
+//    trip) and the write-through rows are fetched before it.
+//
+// One group, one chain: the host plans these roles for Bp = 16 only (planner.hip: plan_fused).
+#pragma once
+#include "fused_common.h"
+
+namespace pl {
+namespace {
+
+__device__ __forceinline__ unsigned short bf16_bits16(float v) { return __builtin_bit_cast(unsigned short, (bf16_t)v); }
+__device__ __forceinline__ float bf16_val16(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// blocking, bounded wait of a 16-row role: its own P flags (lanes 0 .. P-1; nt loads once the role runs on one XCD) and, unless the
+// look-ahead has seen them already, the flags of other roles (write-through).  Wave 0 polls; ends with a barrier.
+__device__ __forceinline__ bool wait16(const int* own, int n_own, bool own_fast, const FlagPoll& ext, bool with_ext, int* status,
+                                       int* lds_word, unsigned long long spin_ticks, unsigned poll_mask) {
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        const int lane = threadIdx.x;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(own ? own : status, (unsigned)((own ? n_own : 1) * 4));
+        const int n = own ? n_own : 0;
+        int ok = 1;
+        for (unsigned spin = 1;; ++spin) {
+            int v = 1;
+            if (lane < n) {
+                v = own_fast ? (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxNt)
+                             : (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
+            } else if (with_ext) {
+                if (lane >= 32 && lane - 32 < ext.nb) v = flag_load(ext.fb + (lane - 32));
+                else if (lane == 63 && ext.fc) v = flag_load(ext.fc);
+            }
+            if (__all(v != 0)) break;
+            if ((spin & poll_mask) == 0 && (flag_load(status) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > spin_ticks)) {
+                ok = 0;
+                break;
+            }
+        }
+        if (lane == 0) {
+            if (!ok) {
+                int expected = 0;
+                __hip_atomic_compare_exchange_strong((PL_GLOBAL int*)status, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *lds_word = ok;
+        }
+    }
+    __syncthreads();
+    return *lds_word != 0;
+}
+
+// what a step waits for from OTHER roles (FusedWait 1 -> lanes 32.., FusedWait 2 -> lane 63)
+__device__ __forceinline__ FlagPoll ext_flags(const FusedArgs& a, const FusedRole& R, int t, int p) {
+    FlagPoll s{nullptr, 0, nullptr, 0, nullptr};
+    int n2 = 0;
+    s.fb = wait_addr(a, R.wait[1], 0, t, p, s.nb);
+    s.fc = wait_addr(a, R.wait[2], 0, t, p, n2);
+    return s;
+}
+__device__ __forceinline__ bool ext_empty(const FlagPoll& s) { return s.nb == 0 && !s.fc; }
+__device__ __forceinline__ int ext_poll(const FlagPoll& s, int lane) {
+    int v = 1;
+    if (lane >= 32 && lane - 32 < s.nb) v = flag_load(s.fb + (lane - 32));
+    else if (lane == 63 && s.fc) v = flag_load(s.fc);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward recurrence (arithmetic of lstm_fwd16_sweep_kernel)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int KSX>   // KSX = in_p / 32 (0: G holds the input projection, written by a projection role of this launch)
+struct LstmFwd16Lds {
+    static constexpr int Hp = 16 * KS;
+    static constexpr int RS = Hp * 2 + 16;        // h image row stride: odd number of 16-byte chunks
+    static constexpr int ORS = 64 + 16;           // staged outputs [6 arrays][16 rows][32 units] bf16
+    static constexpr int XRS = KSX * 64 + 16;
+    static constexpr int O_HIMG = 0;
+    static constexpr int O_OST = O_HIMG + 16 * RS;
+    static constexpr int O_XIMG = O_OST + 6 * 16 * ORS;
+    static constexpr int O_FLAG = O_XIMG + (KSX ? 16 * XRS : 16);
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+template <int KS, int KSX>
+__device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmFwd16Lds<KS, KSX>;
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp, KS32 = KS / 2, P = Hp / 32;
+    constexpr int ROWB = Hp * 2, RS = L::RS, ORS = L::ORS, XRS = L::XRS;
+    constexpr int CPR = Hp / 8;                   // 16-byte chunks per h row
+    constexpr int NLD = (16 * CPR + 255) / 256;
+    constexpr int PF = 4;                         // B-fragment read-ahead (k-steps of 32)
+    constexpr int INP = KSX ? 32 * KSX : 32, XC = INP / 8;
+    static_assert(KS % 2 == 0, "Hp is a multiple of 32");
+    unsigned char* himg = lds + L::O_HIMG;
+    unsigned char* ost = lds + L::O_OST;
+    unsigned char* ximg = lds + L::O_XIMG;
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int Bp = a.Bp, T = R.T;
+    if (set != 0 || Bp != 16 || a.n_groups != 1) return;   // one group of 16 (padded) rows: the host plans nothing else for these roles
+    const bf16_t* __restrict__ W = static_cast<const bf16_t*>(R.W);
+
+    // weights -> registers: A row lr of tile j = unit 8 wave + 4 j + (lr >> 2), gate lr & 3; k = 32 ks + 8 kq .. + 7
+    uint4 wreg[2][KS32];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const bf16_t* wrow = W + (size_t)((lr & 3) * Hp + 32 * p + 8 * wave + 4 * jt + (lr >> 2)) * Hp + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) { wreg[jt][ks] = gld<uint4>(wrow + 32 * ks); pin(wreg[jt][ks]); }
+    }
+    uint4 wx[2][KSX ? KSX : 1];
+    float bias_r[2][4];
+    if constexpr (KSX > 0) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const bf16_t* xrow = static_cast<const bf16_t*>(R.Wih) + (size_t)((lr & 3) * Hp + 32 * p + 8 * wave + 4 * jt + (lr >> 2)) * INP + 8 * kq;
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) { wx[jt][ks] = gld<uint4>(xrow + 32 * ks); pin(wx[jt][ks]); }
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate) bias_r[jt][gate] = gld<float>(R.bias + gate * Hp + 32 * p + 8 * wave + 4 * jt + kq);
+        }
+    }
+    // cell ownership (C layout): batch row lr, units 8 wave + kq (tile 0) and 8 wave + 4 + kq (tile 1); accumulator register = gate
+    const int ul[2] = {8 * wave + kq, 8 * wave + 4 + kq};
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
+    bf16_t* __restrict__ Hs = static_cast<bf16_t*>(R.h);
+    bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c);
+    bf16_t* __restrict__ HX = static_cast<bf16_t*>(R.hx);        // [2][16][Hp], this role's own copy of the hand-off
+    const bf16_t* const x_in = static_cast<const bf16_t*>(R.x_in);
+    const bool src_sc1 = R.src_sc1 != 0;
+    int* const Fpub = R.flags;
+    int* const Ffast = R.fast_flags;
+    int* const xtab = R.xtab;
+    const int fs = a.flag_stride;
+
+    float c_state[2] = {0.f, 0.f};
+    bool fast = false;          // the role's workgroups share one XCD (verified at step 1): own hand-off through its L2
+    bool pub_pending = false;   // the write-through flag of step t - 1 is still to be raised
+    bool ext_known = false;     // the look-ahead saw everything step t needs from other roles
+    int la_pv = 0;              // wave 3: the look-ahead's answer (flags of step t + 1), asked at the top of step t
+
+    for (int t = 0; t < T; ++t) {
+        const FlagPoll ext = ext_flags(a, R, t, p);
+        const bool has_ext = !ext_empty(ext);
+        // look-ahead at what step t + 1 needs from other roles: asked by a wave that does not poll, answered under this step
+        FlagPoll ext_n{nullptr, 0, nullptr, 0, nullptr};
+        if (t + 1 < T) ext_n = ext_flags(a, R, t + 1, p);
+        const bool la_here = !ext_empty(ext_n);
+        if (wave == 3 && la_here) la_pv = ext_poll(ext_n, lane);
+        // input rows nobody in this launch writes: in flight during the wait
+        uint4 xv = make_uint4(0, 0, 0, 0);
+        if constexpr (KSX > 0) {
+            if (!src_sc1 && wave < KSX) xv = gld<uint4>(x_in + ((size_t)t * Bp + tid / XC) * INP + (tid % XC) * 8);
+        }
+        if (t > 0 || (has_ext && !ext_known)) {
+            const bool of = fast && t >= 2;   // step t - 1 was handed over in the same-XCD form
+            const int* own = t > 0 ? (of ? Ffast : Fpub) + (size_t)(t - 1) * fs : nullptr;
+            if (!wait16(own, P, of, ext, has_ext && !ext_known, a.status, lflag, a.spin_ticks, a.poll_mask)) return;
+        }
+        if (t == 1 && Ffast && HX) fast = group_on_one_xcd(xtab, P, lflag + 2);
+        if constexpr (KSX > 0) {
+            if (src_sc1 && wave < KSX) {
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(x_in + (size_t)t * Bp * INP, (unsigned)((size_t)Bp * INP * 2));
+                xv = ld16_sc1(rx, (unsigned)(((tid / XC) * INP + (tid % XC) * 8) * 2));
+            }
+        }
+        f32x4 acc[2];
+        if (t > 0) {
+            const bool from_hx = fast && t >= 2;
+            const bf16_t* hsrc = from_hx ? HX + (size_t)((t - 1) & 1) * 16 * Hp : Hs + (size_t)(t - 1) * slabH;
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(hsrc, (unsigned)(16 * ROWB));
+            uint4 v[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int q = tid + 256 * i, row = q / CPR, c = q % CPR;
+                v[i] = q < 16 * CPR ? ld16_handoff(rh, (unsigned)(row * ROWB + c * 16), from_hx) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int q = tid + 256 * i;
+                if (q < 16 * CPR) *reinterpret_cast<uint4*>(himg + (q / CPR) * RS + (q % CPR) * 16) = v[i];
+            }
+        }
+        if constexpr (KSX > 0) {
+            if (wave < KSX) *reinterpret_cast<uint4*>(ximg + (tid / XC) * XRS + (tid % XC) * 16) = xv;
+        }
+        // every wave's write-through stores of step t - 1 have drained by now (its loads of this step are younger and back)
+        if (pub_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (pub_pending && tid == 0) flag_store(Fpub + (size_t)(t - 1) * fs + p, 1);
+        pub_pending = false;
+        // the projection rows of this step (written by a projection role: the blocking wait or the look-ahead has seen its flag)
+        float gx[2][4];
+        if constexpr (KSX == 0) {
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) {
+                    const unsigned off = (unsigned)(((size_t)lr * G4 + gate * Hp + 32 * p + ul[jt]) * 2);
+                    const unsigned short u = src_sc1 ? (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rg, off, 0, kAuxSc1)
+                                                     : (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rg, off, 0, 0);
+                    gx[jt][gate] = bf16_val16(u);
+                }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                acc[jt] = f32x4{bias_r[jt][0], bias_r[jt][1], bias_r[jt][2], bias_r[jt][3]};
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) gx[jt][gate] = 0.f;
+            }
+        }
+        if (t > 0) {
+            const unsigned char* bsrc = himg + lr * RS + kq * 16;
+            uint4 bq[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < KS32) bq[i] = *reinterpret_cast<const uint4*>(bsrc + i * 64);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[ks % PF]);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[0][ks]), bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[1][ks]), bf, acc[1], 0, 0, 0);
+                if (ks + PF < KS32) bq[ks % PF] = *reinterpret_cast<const uint4*>(bsrc + (ks + PF) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (KSX > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ximg + lr * XRS + ks * 64 + kq * 16));
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[0][ks]), xb, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[1][ks]), xb, acc[1], 0, 0, 0);
+            }
+        }
+        if (t == 0 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());
+        // cell update (2 cells per lane) -> all six outputs into the staging image [array][row][unit]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const float vi = sigmoid_fast(acc[jt][0] + gx[jt][0]), vf = sigmoid_fast(acc[jt][1] + gx[jt][1]);
+            const float vg = tanh_fast(acc[jt][2] + gx[jt][2]), vo = sigmoid_fast(acc[jt][3] + gx[jt][3]);
+            c_state[jt] = cell_c(vf, c_state[jt], vi, vg);
+            const float vh = vo * tanh_fast(c_state[jt]);
+            unsigned char* o = ost + lr * ORS + ul[jt] * 2;
+            *reinterpret_cast<unsigned short*>(o) = bf16_bits16(vh);
+            *reinterpret_cast<unsigned short*>(o + 1 * 16 * ORS) = bf16_bits16(vi);
+            *reinterpret_cast<unsigned short*>(o + 2 * 16 * ORS) = bf16_bits16(vf);
+            *reinterpret_cast<unsigned short*>(o + 3 * 16 * ORS) = bf16_bits16(vg);
+            *reinterpret_cast<unsigned short*>(o + 4 * 16 * ORS) = bf16_bits16(vo);
+            *reinterpret_cast<unsigned short*>(o + 5 * 16 * ORS) = bf16_bits16(c_state[jt]);
+        }
+        // the look-ahead's answer, for everybody after the next barrier
+        if (wave == 3 && lane == 0) lflag[3] = 0;
+        if (wave == 3 && la_here) {
+            const bool seen = __all(la_pv != 0);
+            if (lane == 0) lflag[3] = seen ? 1 : 0;
+        }
+        __syncthreads();
+        ext_known = lflag[3] != 0;
+        // hand-off first (wave 0: 16 rows x four 16-byte pieces), then the five stash arrays (320 pieces)
+        if (wave == 0) {
+            const int row = tid >> 2, qt = tid & 3;
+            const uint4 hv = *reinterpret_cast<const uint4*>(ost + row * ORS + qt * 16);
+            u32x4 d;
+            d[0] = hv.x; d[1] = hv.y; d[2] = hv.z; d[3] = hv.w;
+            if (fast) {   // the role's own copy: plain, stays in this XCD's L2
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(HX + (size_t)(t & 1) * 16 * Hp, (unsigned)(16 * ROWB));
+                __builtin_amdgcn_raw_buffer_store_b128(d, rx, (unsigned)((row * Hp + 32 * p + 8 * qt) * 2), 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+            __builtin_amdgcn_raw_buffer_store_b128(d, ro, (unsigned)((row * Hp + 32 * p + 8 * qt) * 2), 0, kAuxSc1);
+        }
+        asm volatile("" ::: "memory");   // keep the stash stores behind the hand-off
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 0 || wave == 0) {   // 320 pieces: array e / 64 (gates i f g o, c), row (e % 64) / 4, quarter e % 4
+                const int e = tid + 256 * i;
+                const int arr = e >> 6, row = (e & 63) >> 2, qt = e & 3;
+                const uint4 sv = *reinterpret_cast<const uint4*>(ost + (arr + 1) * 16 * ORS + row * ORS + qt * 16);
+                bf16_t* dst = arr < 4 ? G + (size_t)t * slabG + (size_t)row * G4 + arr * Hp + 32 * p + 8 * qt
+                                      : Cs + (size_t)t * slabH + (size_t)row * Hp + 32 * p + 8 * qt;
+                gst<uint4>(dst, sv);
+            }
+        }
+        if (fast) {
+            // wave 0's own-copy store is older than its write-through store and its two stash stores
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const __amdgpu_buffer_rsrc_t rf = make_rsrc(Ffast + (size_t)t * fs + p, 4u);
+                __builtin_amdgcn_raw_buffer_store_b32(1u, rf, 0u, 0, 0);
+            }
+            pub_pending = true;
+        } else {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // write-through store older than the two stash stores
+            __syncthreads();
+            if (tid == 0) flag_store(Fpub + (size_t)t * fs + p, 1);
+        }
+    }
+    if (pub_pending) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) flag_store(Fpub + (size_t)(T - 1) * fs + p, 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward recurrence, reduce-scatter of bf16 partial tiles (arithmetic of lstm_bwd16_rs_sweep_kernel: wide ingest, every wave
+// hands its own tiles over).  MEL: the embedder's first layer also multiplies its dA with its rows of W_ih^T (four 16-column
+// tiles, one per wave) and hands the partial tiles to the backward mel head in the head's [32][32] layout (rows 0 .. 15).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+struct LstmBwd16Lds {
+    static constexpr int Hp = 16 * KS;
+    static constexpr int DRS = 128 * 2 + 16;      // dA image [16 batch rows][128 local gate rows] bf16
+    static constexpr int ORS = Hp * 2 + 16;       // partial image [16 batch rows][Hp] bf16
+    static constexpr int MRS = 64 * 2 + 16;       // input-gradient image [16 batch rows][64 mel columns] bf16
+    static constexpr int RED_BYTES = 4 * 16 * 36 * 4;   // the four waves' f32 sums of the wide ingest
+    static constexpr int O_DA = 0;
+    static constexpr int O_OUT = O_DA + 16 * DRS;
+    static constexpr int O_RED = O_OUT + 16 * ORS;
+    static constexpr int O_MEL = O_RED + RED_BYTES;
+    static constexpr int O_FLAG = O_MEL + 16 * MRS;
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+template <int KS, bool MEL>
+__device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmBwd16Lds<KS>;
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32;
+    constexpr int NTT = Hp / 16;                  // N tiles of 16 hidden units
+    constexpr int NT = (NTT + 3) / 4;             // per wave (wave w: tiles w, w + 4, ...)
+    constexpr int TPG = (P + 3) / 4;              // sources a wave sums in the ingest
+    constexpr int DRS = L::DRS, ORS = L::ORS, MRS = L::MRS;
+    constexpr size_t TILE = 16 * 32;              // own exchange: [16 rows][32 columns] bf16
+    constexpr size_t TILE32 = 32 * 32;            // the product roles' tiles
+    unsigned char* da_img = lds + L::O_DA;
+    unsigned char* out_img = lds + L::O_OUT;
+    float* red = reinterpret_cast<float*>(lds + L::O_RED);
+    unsigned char* mel_img = lds + L::O_MEL;
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int Bp = a.Bp, T = R.T;
+    if (set != 0 || Bp != 16 || a.n_groups != 1) return;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(R.W);   // Whh^T packed [Hp][4 Hp]
+    // tile nt = wave + 4 i: A row lr = hidden column 16 nt + lr; k chunk kc (= gate kc): gate row kc * Hp + 32 p + 8 kq + jj
+    uint4 wreg[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nt = wave + 4 * i;
+        const int n = 16 * (nt < NTT ? nt : 0) + lr;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) { wreg[i][kc] = gld<uint4>(WT + (size_t)n * G4 + kc * Hp + 32 * p + 8 * kq); pin(wreg[i][kc]); }
+    }
+    uint4 wmel[4] = {};
+    if constexpr (MEL) {   // wave w: mel columns 16 w .. 16 w + 15 (out_p = 64: the host checks)
+        const bf16_t* WM = static_cast<const bf16_t*>(R.Wg);   // Wih^T packed [out_p][4 Hp]
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) { wmel[kc] = gld<uint4>(WM + (size_t)(16 * wave + lr) * G4 + kc * Hp + 32 * p + 8 * kq); pin(wmel[kc]); }
+    }
+    // cell ownership: thread -> batch row tid >> 4, hidden units 32 p + 2 (tid & 15), + 1
+    const int erow = tid >> 4, jq = tid & 15;
+    const int j = 32 * p + 2 * jq;
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(R.c);
+    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(R.dh_ext);
+    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(R.dh_last);
+    bf16_t* __restrict__ X = static_cast<bf16_t*>(R.xchg);        // [2 slots][P destinations][P sources][16][32]
+    bf16_t* __restrict__ XM = static_cast<bf16_t*>(R.xchg_mel);   // [ring][2 tiles of 32 columns][P sources][32][32]
+    const size_t slot_stride = (size_t)P * P * TILE;
+    const size_t mslot_stride = (size_t)2 * P * TILE32;
+    const bool src_sc1 = R.src_sc1 != 0, dA_sc1 = R.dA_sc1 != 0;
+    const int dh_ext_half = R.dh_ext_half, dh_ext_rows = R.dh_ext_rows;
+    int* const Fpub = R.flags;
+    int* const Ffast = R.fast_flags;
+    int* const xtab = R.xtab;
+    const int fs = a.flag_stride;
+    auto ld2 = [](const bf16_t* q, float (&f)[2]) {
+        const unsigned u = *(const PL_GLOBAL unsigned*)(q);
+        f[0] = bf16_val16((unsigned short)(u & 0xffffu));
+        f[1] = bf16_val16((unsigned short)(u >> 16));
+    };
+    auto pk2 = [](float x, float y) -> unsigned { return (unsigned)bf16_bits16(x) | ((unsigned)bf16_bits16(y) << 16); };
+
+    float dc_next[2] = {0.f, 0.f};
+    bool fast = false, pub_pending = false, ext_known = false;
+    int la_pv = 0;
+
+    for (int t = T - 1; t >= 0; --t) {
+        const FlagPoll ext = ext_flags(a, R, t, p);
+        const bool has_ext = !ext_empty(ext);
+        FlagPoll ext_n{nullptr, 0, nullptr, 0, nullptr};
+        if (t > 0) ext_n = ext_flags(a, R, t - 1, p);
+        const bool la_here = !ext_empty(ext_n);
+        if (wave == 3 && la_here) la_pv = ext_poll(ext_n, lane);
+        // the stash rows of the forward launch, in flight during the wait
+        const bf16_t* g_row = G + (size_t)t * slabG + (size_t)erow * G4 + j;
+        float gi[2], gf[2], gg[2], go[2], c[2], cp[2] = {0.f, 0.f}, dh[2] = {0.f, 0.f};
+        ld2(g_row, gi);
+        ld2(g_row + Hp, gf);
+        ld2(g_row + 2 * Hp, gg);
+        ld2(g_row + 3 * Hp, go);
+        ld2(Cs + (size_t)t * slabH + (size_t)erow * Hp + j, c);
+        if (t > 0) ld2(Cs + (size_t)(t - 1) * slabH + (size_t)erow * Hp + j, cp);
+        const int dh_row = dh_ext_half ? (t >> 1) : t;
+        const bool dh_here = dhe && dh_row < dh_ext_rows;
+        unsigned dh_bits = 0u;
+        auto load_dh = [&]() {
+            if (src_sc1) {
+                const __amdgpu_buffer_rsrc_t rd = make_rsrc(dhe + (size_t)dh_row * slabH, (unsigned)(slabH * 2));
+                dh_bits = __builtin_amdgcn_raw_buffer_load_b32(rd, (unsigned)(((size_t)erow * Hp + j) * 2), 0, kAuxSc1);
+            } else {
+                dh_bits = *(const PL_GLOBAL unsigned*)(dhe + (size_t)dh_row * slabH + (size_t)erow * Hp + j);
+            }
+        };
+        const bool dh_early = dh_here && (!has_ext || ext_known);   // its producer's flag is known to be up: fetch it under the wait
+        if (dh_early) load_dh();
+        else if (!dhe && dhl && t == T - 1) dh_bits = *(const PL_GLOBAL unsigned*)(dhl + (size_t)erow * Hp + j);
+        if (t + 1 < T || (has_ext && !ext_known)) {
+            const bool of = fast && t + 1 <= T - 2;   // step t + 1 was handed over in the same-XCD form
+            const int* own = t + 1 < T ? (of ? Ffast : Fpub) + (size_t)(t + 1) * fs : nullptr;
+            if (!wait16(own, P, of, ext, has_ext && !ext_known, a.status, lflag, a.spin_ticks, a.poll_mask)) return;
+        }
+        if (t == T - 2 && Ffast) fast = group_on_one_xcd(xtab, P, lflag + 2);
+        if (dh_here && !dh_early) load_dh();
+        if (t + 1 < T) {
+            // wide ingest: wave w sums the tiles of sources w * TPG .. (one wave instruction = one whole 1-KB tile), the four waves'
+            // f32 sums meet in LDS; fixed order
+            const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)p * P * TILE;
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+            uint4 pw[TPG];
+#pragma unroll
+            for (int i = 0; i < TPG; ++i) {
+                const int src = wave * TPG + i;
+                pw[i] = src < P ? ld16_handoff(rx, (unsigned)(src * TILE * 2 + lane * 16), fast) : make_uint4(0, 0, 0, 0);
+            }
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TPG; ++i) {
+                float f[4];
+                unpack_bf16x4(make_uint2(pw[i].x, pw[i].y), f);
+                acc8[0] += f[0]; acc8[1] += f[1]; acc8[2] += f[2]; acc8[3] += f[3];
+                unpack_bf16x4(make_uint2(pw[i].z, pw[i].w), f);
+                acc8[4] += f[0]; acc8[5] += f[1]; acc8[6] += f[2]; acc8[7] += f[3];
+            }
+            float* redw = red + wave * (16 * 36);   // [wave][16 rows][32 + 4 pad] f32
+            const int row = lane >> 2, c8 = lane & 3;
+            *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8) = make_float4(acc8[0], acc8[1], acc8[2], acc8[3]);
+            *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8 + 4) = make_float4(acc8[4], acc8[5], acc8[6], acc8[7]);
+            // every wave's write-through stores of step t + 1 (dA, input-gradient tiles) have drained by now
+            if (pub_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (pub_pending && tid == 0) flag_store(Fpub + (size_t)(t + 1) * fs + p, 1);
+            pub_pending = false;
+        }
+        {
+            const unsigned db = dh_bits;
+            dh[0] = bf16_val16((unsigned short)(db & 0xffffu));
+            dh[1] = bf16_val16((unsigned short)(db >> 16));
+        }
+        if (t + 1 < T) {
+            const float* rd = red + erow * 36 + 2 * jq;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                dh[0] += rd[w * (16 * 36)];
+                dh[1] += rd[w * (16 * 36) + 1];
+            }
+        }
+        float dai[2], daf[2], dag[2], dao[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
+        const unsigned pi = pk2(dai[0], dai[1]), pf = pk2(daf[0], daf[1]), pg = pk2(dag[0], dag[1]), po = pk2(dao[0], dao[1]);
+        if (t == T - 1 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());
+        {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
+            unsigned char* drow = da_img + erow * DRS + jq * 4;
+            *reinterpret_cast<unsigned*>(drow) = pi;
+            *reinterpret_cast<unsigned*>(drow + 64) = pf;
+            *reinterpret_cast<unsigned*>(drow + 128) = pg;
+            *reinterpret_cast<unsigned*>(drow + 192) = po;
+        }
+        // the look-ahead's answer, for everybody after the next barrier
+        if (wave == 3 && lane == 0) lflag[3] = 0;
+        if (wave == 3 && la_here) {
+            const bool seen = __all(la_pv != 0);
+            if (lane == 0) lflag[3] = seen ? 1 : 0;
+        }
+        __syncthreads();
+        ext_known = lflag[3] != 0;
+        uint4 bfr[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) bfr[kc] = *reinterpret_cast<const uint4*>(da_img + lr * DRS + kc * 64 + kq * 16);
+        const bool hand_fast = fast;   // this step's own hand-off form
+        if (t > 0) {   // nobody consumes the recurrence's partials of step 0
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int nt = wave + 4 * i;
+                if (nt < NTT) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[i][kc]), __builtin_bit_cast(bf16x8, bfr[kc]), acc, 0, 0, 0);
+                    // acc[r] = partial[n = 16 nt + 4 kq + r][batch lr] -> bf16 image [batch][n]; the 16 x 16 tile is this wave's alone:
+                    // read back by rows (a wave's LDS operations are ordered), 32 chunks of 16 bytes = the (nt & 1) half of
+                    // destination nt >> 1's [16][32] tile
+                    *reinterpret_cast<uint2*>(out_img + lr * ORS + (16 * nt + 4 * kq) * 2) = pack_bf16x4(acc[0], acc[1], acc[2], acc[3]);
+                    if (lane < 32) {
+                        const int r = lane >> 1, hc = lane & 1;
+                        const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (16 * nt + 8 * hc) * 2);
+                        u32x4 d;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + r * 32 + (nt & 1) * 16 + hc * 8) * 2);
+                        if (hand_fast) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                    }
+                }
+            }
+        }
+        // behind the hand-off: what other roles (or the dL/dCP product after the launch) read.  dA_t overwrites the gate stash in place
+        {
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+            const unsigned o = (unsigned)(((size_t)erow * G4 + j) * 2);
+            if (dA_sc1) {
+                __builtin_amdgcn_raw_buffer_store_b32(pi, rg, o, 0, kAuxSc1);
+                __builtin_amdgcn_raw_buffer_store_b32(pf, rg, o + Hp * 2, 0, kAuxSc1);
+                __builtin_amdgcn_raw_buffer_store_b32(pg, rg, o + 2 * Hp * 2, 0, kAuxSc1);
+                __builtin_amdgcn_raw_buffer_store_b32(po, rg, o + 3 * Hp * 2, 0, kAuxSc1);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(pi, rg, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(pf, rg, o + Hp * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(pg, rg, o + 2 * Hp * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(po, rg, o + 3 * Hp * 2, 0, 0);
+            }
+        }
+        if constexpr (MEL) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wmel[kc]), __builtin_bit_cast(bf16x8, bfr[kc]), acc, 0, 0, 0);
+            // acc[r] = dmel partial[column 16 wave + 4 kq + r][batch lr]
+            *reinterpret_cast<uint2*>(mel_img + lr * MRS + (16 * wave + 4 * kq) * 2) = pack_bf16x4(acc[0], acc[1], acc[2], acc[3]);
+            bf16_t* xd = XM + (size_t)(t % kFusedRing) * mslot_stride + (size_t)p * TILE32;   // [tile of 32 columns][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)P + 1) * TILE32 * 2));
+            if (lane < 32) {
+                const int r = lane >> 1, hc = lane & 1;
+                const uint4 v = *reinterpret_cast<const uint4*>(mel_img + r * MRS + (16 * wave + 8 * hc) * 2);
+                st16_sc1(ro, (unsigned)(((size_t)(wave >> 1) * P * TILE32 + r * 32 + (wave & 1) * 16 + hc * 8) * 2), v);
+            }
+        }
+        if (hand_fast && t > 0) {
+            // the wave's partial tiles are older than its dA stores (4) and its input-gradient store (1)
+            if constexpr (MEL) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const __amdgpu_buffer_rsrc_t rf = make_rsrc(Ffast + (size_t)t * fs + p, 4u);
+                __builtin_amdgcn_raw_buffer_store_b32(1u, rf, 0u, 0, 0);
+            }
+            pub_pending = true;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) flag_store(Fpub + (size_t)t * fs + p, 1);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace pl

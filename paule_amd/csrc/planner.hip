@@ -244,6 +244,8 @@ struct pl_handle {
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
     int fused_grid_fwd = 0;
     bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
+    bool fused_rows16 = false;  // batches of up to 16 rows: the LSTM roles of both launches run on 16-row tiles (lstm_fused16.h)
+    void* fused_hx[kFusedMaxRoles] = {};        // rows16: the forward LSTM roles' own copies of their h hand-off [2][16][Hp]
     short* fused_tab_bwd = nullptr;
     int fused_grid_bwd = 0;
     void* fused_xchg[kFusedMaxRoles] = {};      // recurrence exchange of every backward LSTM role (they run side by side)
@@ -1311,15 +1313,21 @@ int plan_fused(pl_handle* h) {
     // CU's memory pipe and the per-layer backward sweeps are faster (B = 256: 5.82 vs 7.19 ms) -- forward launch only.
     int mode = h->Bp >= 129 ? 1 : 3;
     if (const char* z = std::getenv("PAULE_HIP_FUSED")) mode = std::atoi(z);
-    int min_rows = 49;   // up to 48 rows the 16-row kernels' chunk pipelines (4.1f) are as fast or faster (T = 2000, B = 32: 19.2 vs 20.8 ms)
+    int min_rows = 49;   // 17 .. 48 rows: the 16-row kernels' chunk pipelines (4.1f) are as fast or faster (T = 2000, B = 32: 19.2 vs 20.8 ms)
     if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
+    // up to 16 rows (ONE 16-row group: the reference's own B = 1, continued learning's 8, cfg5's 16 per GPU): both launches with the
+    // LSTM roles on 16-row tiles and the same-XCD form of each role's own exchange (lstm_fused16.h) -- both or neither
+    bool rows16 = h->Bp == 16 && h->Bp < min_rows;
+    if (const char* z = std::getenv("PAULE_HIP_FUSED16")) rows16 = rows16 && std::atoi(z) != 0;
+    if (rows16 && ((mode & 3) != 3 || !h->sweep16)) rows16 = false;   // PAULE_HIP_SWEEP16=0: no 16-row kernels of either kind
     const Model &p = h->pred, &e = h->emb;
-    if (!(mode & 3) || h->dt != BF16 || !h->use_sweep || !h->fuse_input || h->Bp < min_rows) return PL_OK;
+    if (!(mode & 3) || h->dt != BF16 || !h->use_sweep || !h->fuse_input || (h->Bp < min_rows && !rows16)) return PL_OK;
     // the forward launch takes a stacked predictor (all its layers one width) in front of an embedder of another width (round 3: the
     // class-default 4 x 180 predictor of model set B); the backward launch one predictor layer and equal widths, as before
     const bool fwd_shape = p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_fwd_supported(p.Hp, e.Hp) && p.Hp / 32 <= 31 && e.Hp / 32 <= 31;
     const bool bwd_shape = p.L == 1 && p.Hp == e.Hp && fused_supported(p.Hp);
     if (!fwd_shape && !bwd_shape) return PL_OK;
+    if (rows16 && (!fwd_shape || !bwd_shape || h->bwd_mode != 1)) return PL_OK;   // the chunk pipelines keep the shape
     if (!fwd_shape) mode &= ~1;
     if (!bwd_shape) mode &= ~2;
     if (!(mode & 3)) return PL_OK;
@@ -1405,6 +1413,17 @@ int plan_fused(pl_handle* h) {
             h->fused_bwd_ok = true;
         }
     }
+    if (rows16) {
+        if (h->fused_fwd_ok && h->fused_bwd_ok) {
+            h->fused_rows16 = true;
+            for (int l = 0; l < p.L; ++l)
+                if ((rc = raw_alloc(h, &h->fused_hx[fr_pred(l)], (size_t)2 * 16 * p.Hp * 2))) return rc;
+            for (int l = 0; l < e.L; ++l)
+                if ((rc = raw_alloc(h, &h->fused_hx[fr_emb(p.L, l)], (size_t)2 * 16 * e.Hp * 2))) return rc;
+        } else {
+            h->fused_fwd_ok = h->fused_bwd_ok = false;
+        }
+    }
     return PL_OK;
 }
 
@@ -1436,6 +1455,16 @@ int* fused_slice(pl_handle* h, int r, bool bwd) {   // backward: r >= n_roles ar
     return h->sweep_cnt + (size_t)(h->n_sweep_slots - n_fused + (bwd ? h->fused_n_roles : 0) + r) * ints;
 }
 
+// 16-row LSTM roles (fused_rows16): the second, plain flag set and the XCD-id table of the role sit in its own flag slice -- a slice
+// has room for (Bp + 7) / 8 = 2 groups of arrival flags and these launches have one: the second group's area holds the plain set,
+// the XCD ids follow where they do for the per-layer sweeps
+void fused16_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
+    if (!h->fused_rows16) return;
+    R.fast_flags = slice + (size_t)h->T * h->flag_stride;
+    R.xtab = slice + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
+    R.hx = hx;
+}
+
 // the role tables (called once, at the end of pl_create: every buffer exists)
 int build_fused_roles(pl_handle* h) {
     Model &p = h->pred, &e = h->emb;
@@ -1452,6 +1481,7 @@ int build_fused_roles(pl_handle* h) {
             R.type = FR_LSTM_FWD; R.wide = 0; R.C = h->fused_Cp; R.T = T; R.flags = fl[fr_pred(l)];
             R.wait[0] = FusedWait{fl[fr_pred(l)], T, Pp, 0, 0, -1};
             R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c;
+            fused16_fields(h, R, fl[fr_pred(l)], h->fused_hx[fr_pred(l)]);
             if (l == 0) {
                 R.ksx = ly.in_p / 16; R.x_in = h->X0; R.Wih = ly.Wih; R.bias = ly.bias;
             } else {
@@ -1477,6 +1507,7 @@ int build_fused_roles(pl_handle* h) {
             R.wait[1] = FusedWait{fl[fr_head(pL)], Tp, 1, 0, 0, 0};
             R.src_sc1 = 1;
             R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c; R.x_in = h->mel_tm; R.Wih = ly.Wih; R.bias = ly.bias;
+            fused16_fields(h, R, fl[fr_emb(pL, 0)], h->fused_hx[fr_emb(pL, 0)]);
         }
         for (int l = 1; l < e.L; ++l) {
             LstmLayer& ly = e.layers[l];
@@ -1491,6 +1522,7 @@ int build_fused_roles(pl_handle* h) {
             Rl.wait[2] = FusedWait{fl[rp], Tp, 1, 1, 0, 0};
             Rl.src_sc1 = 1;
             Rl.G = ly.G; Rl.W = ly.Whh; Rl.h = ly.h; Rl.c = ly.c;
+            fused16_fields(h, Rl, fl[rl], h->fused_hx[rl]);
         }
         if ((rc = dev_alloc(h, &h->fused_roles_fwd, (size_t)n_roles))) return rc;
         PL_HIP(hipMemcpyAsync(h->fused_roles_fwd, roles.data(), sizeof(FusedRole) * n_roles, hipMemcpyHostToDevice, h->stream));
@@ -1508,6 +1540,7 @@ int build_fused_roles(pl_handle* h) {
             R.wait[2] = FusedWait{fl[1], Tp, 1, 0, 1, 0};
             R.src_sc1 = 1;
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.dh_ext = p.dh_ext; R.dh_ext_half = 1; R.dh_ext_rows = Tp; R.xchg = h->fused_xchg[0];
+            fused16_fields(h, R, fl[0], nullptr);
         }
         {   // 1: backward mel head
             FusedRole& R = roles[1];
@@ -1523,6 +1556,7 @@ int build_fused_roles(pl_handle* h) {
             R.type = FR_LSTM_BWD; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[rl];
             R.wait[0] = FusedWait{fl[rl], Tp, P, 0, 0, 1};
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
+            fused16_fields(h, R, fl[rl], nullptr);
             if (top) R.dh_last = h->dv;
             else {   // dL/dh rows from the layer above's product role (reduced there): this slice's columns come from its slice-p workgroup
                 const int rdx = 3 + 2 * l;
@@ -1559,7 +1593,8 @@ bool fused_acoustic_forward(pl_handle* h, hipStream_t st) {
     launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_fwd, h->fused_tab_fwd, h->fused_roles_fwd, false);
-    launch_fused_fwd(st, h->pred.Hp, h->emb.Hp, a);
+    if (h->fused_rows16) launch_fused_fwd16(st, h->pred.Hp, h->emb.Hp, a);
+    else launch_fused_fwd(st, h->pred.Hp, h->emb.Hp, a);
     return true;
 }
 
@@ -1574,7 +1609,8 @@ bool fused_acoustic_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
     launch_dy(st, F32, la, nullptr, h->Y);
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
-    launch_fused_bwd(st, p.Hp, a);
+    if (h->fused_rows16) launch_fused_bwd16(st, p.Hp, a);
+    else launch_fused_bwd(st, p.Hp, a);
     LstmLayer& l0 = p.layers[0];
     launch_gemm_nt(st, h->dt, true, l0.G, 4 * p.Hp, l0.WihT, 4 * p.Hp, nullptr, h->dX, l0.in_p, h->T * h->Bp, l0.in_p, 4 * p.Hp);
     return true;
@@ -2728,7 +2764,8 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
             zero_all_sweep_slots(h, h->stream);   // time does not depend on the data, and every pl_step rebuilds what it overwrites
             FusedArgs a{};
             fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
-            launch_fused_bwd(h->stream, h->pred.Hp, a);
+            if (h->fused_rows16) launch_fused_bwd16(h->stream, h->pred.Hp, a);
+            else launch_fused_bwd(h->stream, h->pred.Hp, a);
             h->sweep_slot = -1;
         }
         PL_HIP(hipEventRecord(e1, h->stream));
@@ -2891,6 +2928,7 @@ int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
         h->bwd_waves,
         h->n_cu,
         g_retained_branched_execs.load(std::memory_order_relaxed),
+        h->fused_rows16 ? 16 : ((h->fused_fwd_ok || h->fused_bwd_ok) ? 32 : 0),
     };
     for (int i = 0; i < n && i < PL_PLAN_COUNT; ++i) out[i] = v[i];
     for (int i = PL_PLAN_COUNT; i < n; ++i) out[i] = 0;

@@ -550,6 +550,103 @@ def test_fused_backward_matches_per_layer_path(HipPlanner, monkeypatch, shape):
     assert np.abs(_n(e["3"].get_cp()) - _n(e["0"].get_cp())).max() <= 2e-4   # lr = 0.01: 2 % of one step
 
 
+# ---- fused launches on 16-row tiles (lstm_fused16.h): batches of up to 16 rows -- the reference's own B = 1 ---------------------
+def _pair16(HipPlanner, monkeypatch, wl, B, T, iters, use_graph, other, stop_after_fwd=False):
+    """The same plan with the 16-row fused launches (the default for up to 16 rows) and on `other`: "pipelines" (PAULE_HIP_FUSED16=0:
+    the chunk pipelines of the 16-row per-layer kernels, lstm_persist16.hip) or "fused32" (the 32-row roles of lstm_fused.hip,
+    forced down to this batch with PAULE_HIP_FUSED_MIN_B=1); the plan the library made is asserted."""
+    out = {}
+    for which in ("fused16", other):
+        for k in ("PAULE_HIP_FUSED16", "PAULE_HIP_FUSED_MIN_B", "PAULE_HIP_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        if which == "pipelines":
+            monkeypatch.setenv("PAULE_HIP_FUSED16", "0")
+        elif which == "fused32":
+            monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
+            monkeypatch.setenv("PAULE_HIP_FUSED", "3")
+        if stop_after_fwd:
+            monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=use_graph)
+        plan = eng.plan_info()
+        want = {"fused16": (16, 1, 1), "fused32": (32, 1, 1), "pipelines": (0, 0, 0)}[which]
+        assert (plan["fused_rows"], plan["fused_fwd"], plan["fused_bwd"]) == want, (which, plan)
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        eng.losses = _n(eng.step(iters))
+        eng.synchronize()
+        out[which] = eng
+    for k in ("PAULE_HIP_FUSED16", "PAULE_HIP_FUSED_MIN_B", "PAULE_HIP_FUSED", "PAULE_HIP_STOP_AFTER_FWD"):
+        monkeypatch.delenv(k, raising=False)
+    return out
+
+
+@pytest.mark.parametrize("shape", [dict(B=16, T=61, H=720, graph=True), dict(B=1, T=300, H=720, graph=True), dict(B=5, T=41, H=96, graph=False),
+                                   dict(B=9, T=14, H=720, graph=False)])
+def test_fused16_launches_equal_pipelines_forward_and_fused32_throughout(HipPlanner, monkeypatch, shape):
+    """Batches of up to 16 rows (ONE 16-row group: the reference's B = 1, cfg5's 16 per GPU) run both fused launches with the LSTM
+    roles on 16-row tiles, each role's own exchange in the verified same-XCD form (plain stores / nt loads, a second flag set; the
+    write-through flags other roles wait for are raised a step late).
+      * Forward: the arithmetic of the 16-row per-layer kernels, instruction for instruction -- every stash, the pooled mel and the
+        first losses carry the same bits as the chunk pipelines'; the first model gradient agrees with theirs to bf16 noise
+        (cosine >= 0.99999: below the embedder's top layer dL/dh crosses the product roles' bf16 exchanges).
+      * Whole plan: bit-identical to the 32-row fused launches over six iterations (losses, dL/dCP, CP).  The recurrences hand over
+        the same bf16 partial tiles and sum them in f32 in another order (wave-wise instead of source by source) -- sums of 23 bf16
+        values are exact in f32, so the order does not show.
+    Odd T, the shortest plannable T, B = 1 at the reference's length, graph and eager."""
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    e = _pair16(HipPlanner, monkeypatch, wl, B, T, 1, False, "pipelines", stop_after_fwd=True)
+    for name in FWD_BUFFERS:
+        np.testing.assert_array_equal(_n(e["fused16"].debug_read(name)), _n(e["pipelines"].debug_read(name)), err_msg=name)
+    e = _pair16(HipPlanner, monkeypatch, wl, B, T, 1, False, "pipelines")
+    np.testing.assert_array_equal(e["fused16"].losses, e["pipelines"].losses)
+    assert _cos(e["fused16"].debug_read("emb.G1"), e["pipelines"].debug_read("emb.G1")) >= 0.999999
+    assert _cos(e["fused16"].debug_read("emb.G0"), e["pipelines"].debug_read("emb.G0")) >= 0.9999
+    assert _cos(e["fused16"].debug_read("dX"), e["pipelines"].debug_read("dX")) >= 0.99999
+    e = _pair16(HipPlanner, monkeypatch, wl, B, T, 6, shape["graph"], "fused32")
+    np.testing.assert_array_equal(e["fused16"].losses, e["fused32"].losses)
+    np.testing.assert_array_equal(_n(e["fused16"].debug_read("dX")), _n(e["fused32"].debug_read("dX")))
+    np.testing.assert_array_equal(_n(e["fused16"].get_cp()), _n(e["fused32"].get_cp()))
+    assert (e["fused16"].losses[-1, :, 0] < e["fused16"].losses[0, :, 0]).all()
+
+
+@pytest.mark.parametrize("shape", [dict(B=3, T=24, H=720), dict(B=16, T=40, H=96), dict(B=1, T=64, H=720)])
+def test_fused16_vs_oracle_and_rounding_emulation(HipPlanner, shape):
+    """The 16-row fused launches against the float64 oracle (model gradient <= 2 %) and against the rounding emulation
+    (oracle/bf16_emul.py: <= 3e-3 -- the path differs from the reference arithmetic by the declared roundings only), then five
+    iterations of the plan against both (the bars of test_bf16_path_equals_rounding_emulation)."""
+    from oracle import bf16_emul as be
+    from oracle import manual as mo
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    em = be.EmulPlanner(wl.pred_sd, wl.emb_sd, objective="acoustic_semvec")
+    ex = mo.ManualPlanner(wl.pred_sd, wl.emb_sd, objective="acoustic_semvec")
+    for o in (em, ex):
+        o.set_targets(wl.target_mel.numpy(), wl.target_semvec.numpy())
+        o.set_cp(wl.cp0.numpy())
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
+    assert eng.plan_info()["fused_rows"] == 16, eng.plan_info()
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    eng.step(1, return_loss=False)
+    eng.synchronize()
+    dX = _tm(eng.debug_read("dX"), T, 16, 32, B, 30)
+    _, _, pe = be.loss_and_grad(em.models, "acoustic_semvec", em.x, em.target_mel, em.target_semvec)
+    _, _, px = mo.loss_and_grad(ex.models, "acoustic_semvec", ex.x, ex.target_mel, ex.target_semvec)
+    nrm = np.linalg.norm(px["grad_model"])
+    err_emul, err_exact = np.linalg.norm(dX - pe["dX"]) / nrm, np.linalg.norm(dX - px["grad_model"]) / nrm
+    print(f"[fused16] dL/dCP relative error vs emulation {err_emul:.2e}, vs exact oracle {err_exact:.2e}")
+    assert err_emul <= 3e-3 and err_exact <= 2e-2, (err_emul, err_exact)
+    eng.step(4, return_loss=False)
+    eng.synchronize()
+    em.step(5)
+    ex.step(5)
+    cp = _n(eng.get_cp())
+    d_emul, d_exact = np.abs(cp - em.get_cp()), np.abs(cp - ex.get_cp())
+    print(f"[fused16] CP after 5 iterations: mean |diff| vs emulation {d_emul.mean():.2e} (max {d_emul.max():.2e}), vs exact oracle {d_exact.mean():.2e}")
+    assert d_emul.mean() <= 1e-5 and d_emul.max() <= 1e-3 and d_exact.max() <= 0.5 * 0.01 * 5, (d_emul.mean(), d_emul.max(), d_exact.max())
+
+
 # ---- continued learning of the predictive model (SURVEY 8f rank 2; paule/paule.py:1353-1379) --------------------------
 def _unpad_grad(flat, nblk, R, C, Rp, Cp):
     a = _n(flat).reshape(nblk, Rp, Cp)[:, :R, :C]
@@ -992,14 +1089,16 @@ def test_long_sequences_bf16_sweeps(HipPlanner):
 def test_long_sequences_set_a_vs_oracle(HipPlanner, dtype):
     """BASELINE configs[4]'s shape on Paule's default models (set A, H = 720, T = 2000, T' = 1000) against the float64 oracle on
     the same two utterances, one iteration (losses, the model gradient through the 2000 / 1000-step recurrences, the updated CP): the
-    long-form path of cfg5 (one 16-row group, pipelined sweeps of 2000 / 1000 steps) compared with the reference arithmetic, not
-    only checked for its properties.  f32: the f32 bars; bf16: the bf16 bars.  The oracle's iteration (~2 minutes of float64 torch)
+    long-form path of cfg5 (one 16-row group; bf16: the 16-row fused launches, f32: pipelined sweeps) compared with the reference
+    arithmetic, not only checked for its properties.  f32: the f32 bars; bf16: the bf16 bars.  The oracle's iteration (~2 minutes of float64 torch)
     is the committed fixture tests/golden/oracle_long_set_a.npz."""
     B, T = 2, 2000
     wl = og.workload("long_set_a")
     ref = og.get("long_set_a")
     lo, cpo, g_model = ref["loss"], ref["cp_after"][0], ref["g_model"]
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype=dtype)
+    if dtype == "bf16":   # round 3: one group of 16 rows runs the role-fused launches on 16-row tiles (lstm_fused16.h), 2000 / 1000 steps per role
+        assert eng.plan_info()["fused_rows"] == 16, eng.plan_info()
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     l1 = _n(eng.step(1))
@@ -1350,6 +1449,7 @@ def test_acoustic_pipeline_is_bit_identical(HipPlanner, golden_small, golden_emb
     B, T = shape["B"], shape["T"]
     wl = synthetic.make_workload(B, T, shape.get("set", "A"))   # set B: a stacked predictor (4 x 180) in front of the embedder
     emb_sd = state_dict_from(golden_embvar, "upsampling/emb") if shape.get("variant") else wl.emb_sd
+    monkeypatch.setenv("PAULE_HIP_FUSED16", "0")   # bf16 batches of up to 16 rows would take the 16-row fused launches: the pipelines are the subject here
     outs = []
     for pipe in ("1", "0"):
         monkeypatch.setenv("PAULE_HIP_WF_PIPELINE", pipe)
