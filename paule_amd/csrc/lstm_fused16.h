@@ -16,15 +16,35 @@
 //    recurrence's 23 workgroups on one XCD slot, every workgroup publishes the XCD it runs on with its first hand-off, and a
 //    role that finds itself on one XCD switches its own hand-off to plain stores / nt loads (served by that XCD's L2) and
 //    its own flags to a second, plain flag set.  What OTHER roles read stays write-through: the forward role stores h twice
-//    (a private 2-slot copy for itself, the stash for everybody else), and the write-through flag of a step is raised one step
-//    late, at a barrier every wave reaches with its stores drained anyway -- off the recurrence's critical path;
-//  * what a step needs from another role (`FusedWait` 1 and 2) is looked at ONE STEP AHEAD by a wave that does not poll
-//    (wave 3): in steady state the producers are ahead, the blocking wait then polls the role's own flags only (an L2 round
-//    trip) and the write-through rows are fetched before it.
+//    (a private 2-slot copy for itself, the stash for everybody else), and the write-through flag of a step is raised ONE STEP
+//    LATE, together with the next step's plain flag: a wave's stores complete in order, so the drain the plain flag needs
+//    anyway covers the write-through stores of the step before -- nothing is added to the recurrence's critical path;
+//  * what a step needs from another role (`FusedWait` 1 and 2) is looked at AHEAD (one step forward, two steps backward) by a
+//    wave that does not poll (wave 3): in steady state the producers are ahead, the blocking wait then polls the role's own
+//    flags only (an L2 round trip), and the backward role fetches the write-through dL/dh row a step before it is used;
+//  * operands nobody in the launch writes (CP frames forward, stash rows backward) are fetched one step ahead, BEHIND the
+//    hand-off loads of the step before: a wave's loads return in order, a memory-latency load in front of the flag poll or of
+//    the tile loads would hold them back by its whole latency.
+//
+// Measured (profiles/r03_ab_fused16.txt, r03_bench_cfg5.json): B = 1 .. 16 x 300 frames 3.08 -> 2.13 ms per iteration, cfg5
+// (16 x 2000) 18.8 -> 14.4 ms.  Phase stamps of the critical roles (tools/fused_stamps.py 16): forward 2.6 us per step (wait 0.7,
+// h tile -> LDS 0.6, MFMA chain 0.8, cell + stores + flag 0.5), backward 4.0 (wait 1.0, ingest 1.0, cell 0.45, tiles 1.2, drain +
+// flag 0.3).  Dropped after measurement: run-time tile-validity tests inside the MFMA chains (+ 0.5 ms per iteration), a deeper
+// B-fragment read-ahead (PF 6 / 8 / 12: 2.13 / 2.15 / 2.28 against 2.12 ms), software-pipelined tile groups (no gain over TG = 6).
 //
 // One group, one chain: the host plans these roles for Bp = 16 only (planner.hip: plan_fused).
 #pragma once
 #include "fused_common.h"
+
+#ifndef F16_TG
+#define F16_TG 6     // backward: partial tiles whose MFMAs interleave (independent accumulators)
+#endif
+#ifndef F16_PF
+#define F16_PF 4     // forward: B-fragment read-ahead of the MFMA chain (k-steps of 32)
+#endif
+#ifndef F16_PIPE
+#define F16_PIPE 0   // backward: 1 = the next group's MFMAs are issued before this group's epilogue
+#endif
 
 namespace pl {
 namespace {
@@ -108,7 +128,7 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
     constexpr int ROWB = Hp * 2, RS = L::RS, ORS = L::ORS, XRS = L::XRS;
     constexpr int CPR = Hp / 8;                   // 16-byte chunks per h row
     constexpr int NLD = (16 * CPR + 255) / 256;
-    constexpr int PF = 4;                         // B-fragment read-ahead (k-steps of 32)
+    constexpr int PF = F16_PF;                    // B-fragment read-ahead (k-steps of 32)
     constexpr int INP = KSX ? 32 * KSX : 32, XC = INP / 8;
     static_assert(KS % 2 == 0, "Hp is a multiple of 32");
     unsigned char* himg = lds + L::O_HIMG;
@@ -161,6 +181,16 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
     bool pub_pending = false;   // the write-through flag of step t - 1 is still to be raised
     bool ext_known = false;     // the look-ahead saw everything step t needs from other roles
     int la_pv = 0;              // wave 3: the look-ahead's answer (flags of step t + 1), asked at the top of step t
+    // input rows nobody in this launch writes (the predictor's CP frames) are fetched ONE STEP AHEAD, behind the h tile loads: a
+    // wave's loads return in order, and a memory-latency load in front of wave 0's flag poll delays the poll by its whole latency
+    uint4 xv_n = make_uint4(0, 0, 0, 0);
+    auto fetch_x = [&](int t2) {
+        if constexpr (KSX > 0) {
+            if (!src_sc1 && wave < KSX) xv_n = gld<uint4>(x_in + ((size_t)t2 * Bp + tid / XC) * INP + (tid % XC) * 8);
+        }
+    };
+    PL_ST_DECL
+    fetch_x(0);
 
     for (int t = 0; t < T; ++t) {
         const FlagPoll ext = ext_flags(a, R, t, p);
@@ -170,17 +200,14 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
         if (t + 1 < T) ext_n = ext_flags(a, R, t + 1, p);
         const bool la_here = !ext_empty(ext_n);
         if (wave == 3 && la_here) la_pv = ext_poll(ext_n, lane);
-        // input rows nobody in this launch writes: in flight during the wait
-        uint4 xv = make_uint4(0, 0, 0, 0);
-        if constexpr (KSX > 0) {
-            if (!src_sc1 && wave < KSX) xv = gld<uint4>(x_in + ((size_t)t * Bp + tid / XC) * INP + (tid % XC) * 8);
-        }
+        uint4 xv = xv_n;   // fetched a step ago
         if (t > 0 || (has_ext && !ext_known)) {
             const bool of = fast && t >= 2;   // step t - 1 was handed over in the same-XCD form
             const int* own = t > 0 ? (of ? Ffast : Fpub) + (size_t)(t - 1) * fs : nullptr;
             if (!wait16(own, P, of, ext, has_ext && !ext_known, a.status, lflag, a.spin_ticks, a.poll_mask)) return;
         }
         if (t == 1 && Ffast && HX) fast = group_on_one_xcd(xtab, P, lflag + 2);
+        PL_ST(0);   // wait
         if constexpr (KSX > 0) {
             if (src_sc1 && wave < KSX) {
                 const __amdgpu_buffer_rsrc_t rx = make_rsrc(x_in + (size_t)t * Bp * INP, (unsigned)((size_t)Bp * INP * 2));
@@ -198,20 +225,20 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
                 const int q = tid + 256 * i, row = q / CPR, c = q % CPR;
                 v[i] = q < 16 * CPR ? ld16_handoff(rh, (unsigned)(row * ROWB + c * 16), from_hx) : make_uint4(0, 0, 0, 0);
             }
+            asm volatile("" ::: "memory");
+            if (t + 1 < T) fetch_x(t + 1);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int q = tid + 256 * i;
                 if (q < 16 * CPR) *reinterpret_cast<uint4*>(himg + (q / CPR) * RS + (q % CPR) * 16) = v[i];
             }
         }
+        else if (t + 1 < T) fetch_x(t + 1);
         if constexpr (KSX > 0) {
             if (wave < KSX) *reinterpret_cast<uint4*>(ximg + (tid / XC) * XRS + (tid % XC) * 16) = xv;
         }
-        // every wave's write-through stores of step t - 1 have drained by now (its loads of this step are younger and back)
-        if (pub_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (pub_pending && tid == 0) flag_store(Fpub + (size_t)(t - 1) * fs + p, 1);
-        pub_pending = false;
+        PL_ST(1);   // operands -> LDS
         // the projection rows of this step (written by a projection role: the blocking wait or the look-ahead has seen its flag)
         float gx[2][4];
         if constexpr (KSX == 0) {
@@ -260,6 +287,7 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
             }
         }
         if (t == 0 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());
+        PL_ST(2);   // MFMA
         // cell update (2 cells per lane) -> all six outputs into the staging image [array][row][unit]
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
@@ -283,6 +311,7 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
         }
         __syncthreads();
         ext_known = lflag[3] != 0;
+        PL_ST(3);   // cell update
         // hand-off first (wave 0: 16 rows x four 16-byte pieces), then the five stash arrays (320 pieces)
         if (wave == 0) {
             const int row = tid >> 2, qt = tid & 3;
@@ -308,13 +337,16 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
                 gst<uint4>(dst, sv);
             }
         }
+        PL_ST(4);   // store issue
         if (fast) {
-            // wave 0's own-copy store is older than its write-through store and its two stash stores
+            // wave 0's own-copy store is older than its write-through store and its two stash stores -- and younger than the
+            // write-through store of step t - 1 (a wave's stores complete in order): that step's write-through flag goes up here too
             if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
                 const __amdgpu_buffer_rsrc_t rf = make_rsrc(Ffast + (size_t)t * fs + p, 4u);
                 __builtin_amdgcn_raw_buffer_store_b32(1u, rf, 0u, 0, 0);
+                if (pub_pending) flag_store(Fpub + (size_t)(t - 1) * fs + p, 1);
             }
             pub_pending = true;
         } else {
@@ -322,12 +354,14 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
             __syncthreads();
             if (tid == 0) flag_store(Fpub + (size_t)t * fs + p, 1);
         }
+        PL_ST(5);   // drain + barrier + flag
     }
     if (pub_pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) flag_store(Fpub + (size_t)(T - 1) * fs + p, 1);
     }
+    PL_ST_DUMP(a.stamps);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -404,54 +438,67 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     int* const Ffast = R.fast_flags;
     int* const xtab = R.xtab;
     const int fs = a.flag_stride;
-    auto ld2 = [](const bf16_t* q, float (&f)[2]) {
-        const unsigned u = *(const PL_GLOBAL unsigned*)(q);
-        f[0] = bf16_val16((unsigned short)(u & 0xffffu));
-        f[1] = bf16_val16((unsigned short)(u >> 16));
-    };
     auto pk2 = [](float x, float y) -> unsigned { return (unsigned)bf16_bits16(x) | ((unsigned)bf16_bits16(y) << 16); };
 
     float dc_next[2] = {0.f, 0.f};
-    bool fast = false, pub_pending = false, ext_known = false;
+    bool fast = false;
+    bool pub_pending = false;   // the write-through flag of step t + 1 is still to be raised
+    // What a step needs from other roles is looked at TWO steps ahead (wave 3, at the top of a step; answered by its end): known_cur
+    // says the flags of step t are known to be up, known_nxt those of step t - 1 -- early enough to fetch step t - 1's write-through
+    // dL/dh row one step ahead, right behind this step's tile loads.
+    bool known_cur = false, known_nxt = false;
     int la_pv = 0;
+    // Stash rows (and dL/dh from above) of the NEXT step are fetched one step ahead, BEHIND this step's tile loads: a wave's loads
+    // return in order, so a memory-latency load issued in front of the flag poll (wave 0) or of the tile loads delays them by its
+    // whole latency -- 0.7 us per step when the stash rows were fetched at the top of their own step.
+    unsigned n_g[4] = {0u, 0u, 0u, 0u}, n_c = 0u, n_cp = 0u, n_dh = 0u;
+    bool n_dh_valid = false;
+    auto dh_row_of = [&](int t2) { return dh_ext_half ? (t2 >> 1) : t2; };
+    auto fetch_stash = [&](int t2) {
+        const bf16_t* g_row = G + (size_t)t2 * slabG + (size_t)erow * G4 + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) n_g[q] = *(const PL_GLOBAL unsigned*)(g_row + q * Hp);
+        n_c = *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j);
+        n_cp = t2 > 0 ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)(t2 - 1) * slabH + (size_t)erow * Hp + j) : 0u;
+    };
+    auto fetch_dh = [&](int t2) -> unsigned {
+        const int row = dh_row_of(t2);
+        if (!dhe || row >= dh_ext_rows) return 0u;
+        if (src_sc1) {
+            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dhe + (size_t)row * slabH, (unsigned)(slabH * 2));
+            return __builtin_amdgcn_raw_buffer_load_b32(rd, (unsigned)(((size_t)erow * Hp + j) * 2), 0, kAuxSc1);
+        }
+        return *(const PL_GLOBAL unsigned*)(dhe + (size_t)row * slabH + (size_t)erow * Hp + j);
+    };
+    auto unpack2 = [](unsigned u, float (&f)[2]) {
+        f[0] = bf16_val16((unsigned short)(u & 0xffffu));
+        f[1] = bf16_val16((unsigned short)(u >> 16));
+    };
+    PL_ST_DECL
+    fetch_stash(T - 1);
+    if (!dhe && dhl) { n_dh = *(const PL_GLOBAL unsigned*)(dhl + (size_t)erow * Hp + j); n_dh_valid = true; }
+    else if (!dhe) n_dh_valid = true;
 
     for (int t = T - 1; t >= 0; --t) {
         const FlagPoll ext = ext_flags(a, R, t, p);
         const bool has_ext = !ext_empty(ext);
-        FlagPoll ext_n{nullptr, 0, nullptr, 0, nullptr};
-        if (t > 0) ext_n = ext_flags(a, R, t - 1, p);
-        const bool la_here = !ext_empty(ext_n);
-        if (wave == 3 && la_here) la_pv = ext_poll(ext_n, lane);
-        // the stash rows of the forward launch, in flight during the wait
-        const bf16_t* g_row = G + (size_t)t * slabG + (size_t)erow * G4 + j;
-        float gi[2], gf[2], gg[2], go[2], c[2], cp[2] = {0.f, 0.f}, dh[2] = {0.f, 0.f};
-        ld2(g_row, gi);
-        ld2(g_row + Hp, gf);
-        ld2(g_row + 2 * Hp, gg);
-        ld2(g_row + 3 * Hp, go);
-        ld2(Cs + (size_t)t * slabH + (size_t)erow * Hp + j, c);
-        if (t > 0) ld2(Cs + (size_t)(t - 1) * slabH + (size_t)erow * Hp + j, cp);
-        const int dh_row = dh_ext_half ? (t >> 1) : t;
-        const bool dh_here = dhe && dh_row < dh_ext_rows;
-        unsigned dh_bits = 0u;
-        auto load_dh = [&]() {
-            if (src_sc1) {
-                const __amdgpu_buffer_rsrc_t rd = make_rsrc(dhe + (size_t)dh_row * slabH, (unsigned)(slabH * 2));
-                dh_bits = __builtin_amdgcn_raw_buffer_load_b32(rd, (unsigned)(((size_t)erow * Hp + j) * 2), 0, kAuxSc1);
-            } else {
-                dh_bits = *(const PL_GLOBAL unsigned*)(dhe + (size_t)dh_row * slabH + (size_t)erow * Hp + j);
-            }
-        };
-        const bool dh_early = dh_here && (!has_ext || ext_known);   // its producer's flag is known to be up: fetch it under the wait
-        if (dh_early) load_dh();
-        else if (!dhe && dhl && t == T - 1) dh_bits = *(const PL_GLOBAL unsigned*)(dhl + (size_t)erow * Hp + j);
-        if (t + 1 < T || (has_ext && !ext_known)) {
+        FlagPoll ext_2{nullptr, 0, nullptr, 0, nullptr};
+        if (t > 1) ext_2 = ext_flags(a, R, t - 2, p);
+        const bool la_here = !ext_empty(ext_2);
+        if (wave == 3 && la_here) la_pv = ext_poll(ext_2, lane);
+        // this step's operands: fetched one step ago
+        const unsigned u_g0 = n_g[0], u_g1 = n_g[1], u_g2 = n_g[2], u_g3 = n_g[3], u_c = n_c, u_cp = n_cp;
+        unsigned dh_bits = n_dh;
+        const bool dh_have = n_dh_valid;
+        const bool wait_ext = has_ext && !known_cur;
+        if (t + 1 < T || wait_ext) {
             const bool of = fast && t + 1 <= T - 2;   // step t + 1 was handed over in the same-XCD form
             const int* own = t + 1 < T ? (of ? Ffast : Fpub) + (size_t)(t + 1) * fs : nullptr;
-            if (!wait16(own, P, of, ext, has_ext && !ext_known, a.status, lflag, a.spin_ticks, a.poll_mask)) return;
+            if (!wait16(own, P, of, ext, wait_ext, a.status, lflag, a.spin_ticks, a.poll_mask)) return;
         }
         if (t == T - 2 && Ffast) fast = group_on_one_xcd(xtab, P, lflag + 2);
-        if (dh_here && !dh_early) load_dh();
+        PL_ST(0);   // wait
+        if (!dh_have) dh_bits = fetch_dh(t);   // its producer's flag was not known a step ago: the blocking wait has seen it now
         if (t + 1 < T) {
             // wide ingest: wave w sums the tiles of sources w * TPG .. (one wave instruction = one whole 1-KB tile), the four waves'
             // f32 sums meet in LDS; fixed order
@@ -462,6 +509,13 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             for (int i = 0; i < TPG; ++i) {
                 const int src = wave * TPG + i;
                 pw[i] = src < P ? ld16_handoff(rx, (unsigned)(src * TILE * 2 + lane * 16), fast) : make_uint4(0, 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");   // the next step's operands behind the tile loads
+            if (t > 0) {
+                fetch_stash(t - 1);
+                const bool ext1 = !ext_empty(ext_flags(a, R, t - 1, p));
+                n_dh_valid = !dhe || !ext1 || known_nxt;
+                n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
             }
             float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -476,17 +530,22 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             const int row = lane >> 2, c8 = lane & 3;
             *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8) = make_float4(acc8[0], acc8[1], acc8[2], acc8[3]);
             *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8 + 4) = make_float4(acc8[4], acc8[5], acc8[6], acc8[7]);
-            // every wave's write-through stores of step t + 1 (dA, input-gradient tiles) have drained by now
-            if (pub_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (pub_pending && tid == 0) flag_store(Fpub + (size_t)(t + 1) * fs + p, 1);
-            pub_pending = false;
+        } else if (t > 0) {
+            fetch_stash(t - 1);
+            const bool ext1 = !ext_empty(ext_flags(a, R, t - 1, p));
+            n_dh_valid = !dhe || !ext1 || known_nxt;
+            n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
         }
-        {
-            const unsigned db = dh_bits;
-            dh[0] = bf16_val16((unsigned short)(db & 0xffffu));
-            dh[1] = bf16_val16((unsigned short)(db >> 16));
-        }
+        PL_ST(1);   // ingest: tile loads, wave sums, barrier
+        float gi[2], gf[2], gg[2], go[2], c[2], cp[2], dh[2];
+        unpack2(u_g0, gi);
+        unpack2(u_g1, gf);
+        unpack2(u_g2, gg);
+        unpack2(u_g3, go);
+        unpack2(u_c, c);
+        unpack2(u_cp, cp);
+        unpack2(dh_bits, dh);
         if (t + 1 < T) {
             const float* rd = red + erow * 36 + 2 * jq;
 #pragma unroll
@@ -500,54 +559,8 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         for (int u = 0; u < 2; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
         const unsigned pi = pk2(dai[0], dai[1]), pf = pk2(daf[0], daf[1]), pg = pk2(dag[0], dag[1]), po = pk2(dao[0], dao[1]);
         if (t == T - 1 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());
-        {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
-            unsigned char* drow = da_img + erow * DRS + jq * 4;
-            *reinterpret_cast<unsigned*>(drow) = pi;
-            *reinterpret_cast<unsigned*>(drow + 64) = pf;
-            *reinterpret_cast<unsigned*>(drow + 128) = pg;
-            *reinterpret_cast<unsigned*>(drow + 192) = po;
-        }
-        // the look-ahead's answer, for everybody after the next barrier
-        if (wave == 3 && lane == 0) lflag[3] = 0;
-        if (wave == 3 && la_here) {
-            const bool seen = __all(la_pv != 0);
-            if (lane == 0) lflag[3] = seen ? 1 : 0;
-        }
-        __syncthreads();
-        ext_known = lflag[3] != 0;
-        uint4 bfr[4];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) bfr[kc] = *reinterpret_cast<const uint4*>(da_img + lr * DRS + kc * 64 + kq * 16);
-        const bool hand_fast = fast;   // this step's own hand-off form
-        if (t > 0) {   // nobody consumes the recurrence's partials of step 0
-            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)p * TILE;   // [dest][this source]
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int nt = wave + 4 * i;
-                if (nt < NTT) {
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[i][kc]), __builtin_bit_cast(bf16x8, bfr[kc]), acc, 0, 0, 0);
-                    // acc[r] = partial[n = 16 nt + 4 kq + r][batch lr] -> bf16 image [batch][n]; the 16 x 16 tile is this wave's alone:
-                    // read back by rows (a wave's LDS operations are ordered), 32 chunks of 16 bytes = the (nt & 1) half of
-                    // destination nt >> 1's [16][32] tile
-                    *reinterpret_cast<uint2*>(out_img + lr * ORS + (16 * nt + 4 * kq) * 2) = pack_bf16x4(acc[0], acc[1], acc[2], acc[3]);
-                    if (lane < 32) {
-                        const int r = lane >> 1, hc = lane & 1;
-                        const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (16 * nt + 8 * hc) * 2);
-                        u32x4 d;
-                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                        const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + r * 32 + (nt & 1) * 16 + hc * 8) * 2);
-                        if (hand_fast) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
-                    }
-                }
-            }
-        }
-        // behind the hand-off: what other roles (or the dL/dCP product after the launch) read.  dA_t overwrites the gate stash in place
-        {
+        {   // dA_t overwrites the gate stash in place: read by a role of this launch (write-through) or by the dL/dCP product after it.
+            // Issued FIRST: by the time of the flag these stores are a tile phase old and do not sit in front of the next poll
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
             const unsigned o = (unsigned)(((size_t)erow * G4 + j) * 2);
             if (dA_sc1) {
@@ -562,7 +575,28 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
                 __builtin_amdgcn_raw_buffer_store_b32(po, rg, o + 3 * Hp * 2, 0, 0);
             }
         }
-        if constexpr (MEL) {
+        {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 32 + unit]
+            unsigned char* drow = da_img + erow * DRS + jq * 4;
+            *reinterpret_cast<unsigned*>(drow) = pi;
+            *reinterpret_cast<unsigned*>(drow + 64) = pf;
+            *reinterpret_cast<unsigned*>(drow + 128) = pg;
+            *reinterpret_cast<unsigned*>(drow + 192) = po;
+        }
+        // the look-ahead's answer, for everybody after the next barrier
+        if (wave == 3 && lane == 0) lflag[3] = 0;
+        if (wave == 3 && la_here) {
+            const bool seen = __all(la_pv != 0);
+            if (lane == 0) lflag[3] = seen ? 1 : 0;
+        }
+        __syncthreads();
+        known_cur = known_nxt;          // for step t - 1
+        known_nxt = lflag[3] != 0;      // for step t - 2
+        PL_ST(2);   // cell + dA stores + dA image
+        uint4 bfr[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) bfr[kc] = *reinterpret_cast<const uint4*>(da_img + lr * DRS + kc * 64 + kq * 16);
+        const bool hand_fast = fast;   // this step's own hand-off form
+        if constexpr (MEL) {   // before the recurrence's tiles: nothing but those then sits between the hand-off and the flag
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc)
@@ -577,22 +611,80 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
                 st16_sc1(ro, (unsigned)(((size_t)(wave >> 1) * P * TILE32 + r * 32 + (wave & 1) * 16 + hc * 8) * 2), v);
             }
         }
-        if (hand_fast && t > 0) {
-            // the wave's partial tiles are older than its dA stores (4) and its input-gradient store (1)
-            if constexpr (MEL) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
+        if (t > 0) {   // nobody consumes the recurrence's partials of step 0
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            // tiles in groups of TG: a group's 4 x TG MFMAs interleave over independent accumulators (one tile's four are a dependent
+            // chain).  acc[r] = partial[n = 16 nt + 4 kq + r][batch lr] -> bf16 image [batch][n]; a 16 x 16 tile is its wave's alone:
+            // read back by rows (a wave's LDS operations are ordered), 32 chunks of 16 bytes = the (nt & 1) half of destination
+            // nt >> 1's [16][32] tile.  Tile validity is a compile-time fact for all but a wave's last tile: a run-time test per
+            // tile cost 0.5 ms per iteration at T = 300 (branches inside the MFMA chains)
+            constexpr int TG = F16_TG, NGRP = (NT + TG - 1) / TG;
+            f32x4 accg[2][TG];
+            auto tiles_mfma = [&](int grp, f32x4 (&acc)[TG]) {
+#pragma unroll
+                for (int u = 0; u < TG; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) {
+                        const int i = grp * TG + u;
+                        if (i < NT && (4 * i + 3 < NTT || wave + 4 * i < NTT))
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[i < NT ? i : 0][kc]), __builtin_bit_cast(bf16x8, bfr[kc]), acc[u], 0, 0, 0);
+                    }
+            };
+            auto tiles_out = [&](int grp, const f32x4 (&acc)[TG]) {
+#pragma unroll
+                for (int u = 0; u < TG; ++u) {
+                    const int i = grp * TG + u, nt = wave + 4 * i;
+                    if (i < NT && (4 * i + 3 < NTT || nt < NTT))
+                        *reinterpret_cast<uint2*>(out_img + lr * ORS + (16 * nt + 4 * kq) * 2) = pack_bf16x4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+                }
+#pragma unroll
+                for (int u = 0; u < TG; ++u) {
+                    const int i = grp * TG + u, nt = wave + 4 * i;
+                    if (i < NT && (4 * i + 3 < NTT || nt < NTT) && lane < 32) {
+                        const int r = lane >> 1, hc = lane & 1;
+                        const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (16 * nt + 8 * hc) * 2);
+                        u32x4 d;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + r * 32 + (nt & 1) * 16 + hc * 8) * 2);
+                        if (hand_fast) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                    }
+                }
+            };
+            if (F16_PIPE) tiles_mfma(0, accg[0]);
+#pragma unroll
+            for (int grp = 0; grp < NGRP; ++grp) {
+                if (F16_PIPE) {
+                    if (grp + 1 < NGRP) tiles_mfma(grp + 1, accg[(grp + 1) & 1]);
+                    tiles_out(grp, accg[grp & 1]);
+                } else {
+                    tiles_mfma(grp, accg[0]);
+                    tiles_out(grp, accg[0]);
+                }
+            }
+        }
+        PL_ST(3);   // tiles: MFMA + stores issued
+        // Every store of this step (dA, input-gradient tiles, partial tiles) is older than nothing but itself at this point, and a
+        // wave's stores complete in order: once they have drained, so have the write-through stores of step t + 1 -- the
+        // write-through flag of step t + 1 goes up with the plain flag of step t, at a barrier the hand-off needs anyway.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (pub_pending) flag_store(Fpub + (size_t)(t + 1) * fs + p, 1);
+            if (hand_fast && t > 0) {
                 const __amdgpu_buffer_rsrc_t rf = make_rsrc(Ffast + (size_t)t * fs + p, 4u);
                 __builtin_amdgcn_raw_buffer_store_b32(1u, rf, 0u, 0, 0);
+            } else {
+                flag_store(Fpub + (size_t)t * fs + p, 1);
             }
-            pub_pending = true;
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) flag_store(Fpub + (size_t)t * fs + p, 1);
         }
+        pub_pending = hand_fast && t > 0;
+        PL_ST(4);   // drain + barrier + flag
     }
+    PL_ST_DUMP(a.stamps);
 }
 
 }  // namespace

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int k = wave + NW * i;
-                if (k >= P) break;
+                if (NW * i + NW - 1 >= P && k >= P) break;   // a compile-time fact for all but a wave's last tile
                 const int nt = (p + 1 + k) % P;
                 f32x16 acc;
 #pragma unroll

@@ -2307,6 +2307,19 @@ int pl_synchronize(pl_handle* h) {
         }
     }
 #endif
+    if (h->debug_fused && h->fused_rows16) {   // PAULE_HIP_DEBUG_FUSED: where the 16-row roles' workgroups sat in the last iteration
+        for (int bwd = 0; bwd < 2; ++bwd)
+            for (int r = 0; r < h->fused_n_roles; ++r) {
+                int ids[32] = {};
+                const int* xt = fused_slice(h, r, bwd != 0) + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
+                PL_HIP(hipMemcpyAsync(ids, xt, sizeof(ids), hipMemcpyDeviceToHost, h->stream));
+                PL_HIP(hipStreamSynchronize(h->stream));
+                if (!ids[0]) continue;   // not an LSTM role
+                fprintf(stderr, "[pl] fused16 %s role %d on XCDs:", bwd ? "backward" : "forward", r);
+                for (int i = 0; i < 32 && ids[i]; ++i) fprintf(stderr, " %d", ids[i] - 1);
+                fprintf(stderr, "\n");
+            }
+    }
     // on the handle's own stream: a copy on the legacy stream would collide with another handle's graph capture
     int st = 0;
     PL_HIP(hipMemcpyAsync(&st, h->sweep_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (-DPL_STAMPS build): where a chain-step of each role of the fused forward launch goes (lstm_fused.hip).
-usage: fused_stamps.py [B]   (reads the block -> role table the way the host builds it: roles by the stamp pattern)"""
+usage: fused_stamps.py [B [T]]   (reads the block -> role table the way the host builds it: roles by the stamp pattern)
+B <= 16 (the 16-row roles of lstm_fused16.h): the LSTM roles' phases are wait / operands->LDS / MFMA / cell / store issue / drain+flag
+(forward) and wait / ingest / cell+dA image / tiles / drain+flag (backward); the product roles keep the labels below."""
 import os
 import sys
 
@@ -15,8 +17,12 @@ from paule_amd import synthetic  # noqa: E402
 from paule_amd.engine import HipPlanner  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-wl = synthetic.make_workload(B, 300, "A")
-eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=300, objective="acoustic_semvec", dtype="bf16")
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+if B <= 16:
+    os.environ.pop("PAULE_HIP_FUSED", None)
+wl = synthetic.make_workload(B, T, "A")
+eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+print("plan:", eng.plan_info())
 eng.set_targets(wl.target_mel, wl.target_semvec)
 eng.set_cp(wl.cp0)
 eng.step(3)
@@ -32,6 +38,8 @@ for d, name in ((0, "forward"), (1, "backward")):
     print(f"=== {name} launch: {used.size} stamped workgroups; total stamped time per workgroup min {tot[used].min():.0f} / median {np.median(tot[used]):.0f} / max {tot[used].max():.0f} us")
     # group workgroups by their total time profile: roles differ in the share of phase 3 / 1
     key = np.round(blk[used] / tot[used, None], 1)
+    if B <= 16:
+        print("   (16-row LSTM roles: phases 0..5 = " + ("wait / operands->LDS / MFMA / cell / store issue / drain+flag" if d == 0 else "wait / ingest / cell+dA image / tiles / drain+flag") + ")")
     _, inv = np.unique(key, axis=0, return_inverse=True)
     for k in np.unique(inv):
         sel = used[inv == k]
