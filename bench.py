@@ -26,6 +26,8 @@ CONFIGS = {
     # cfg1: the reference's own case -- ONE utterance, Paule's default models, acoustic + semantic objective; the CPU baseline
     # of this config runs the oracle in float64 (the reference's dtype) on that one utterance
     "cfg1": dict(batch=1, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A", cpu_f64=True),
+    # the same single utterance in bf16: one 16-row group on the 16-row fused launches (lstm_fused16.h)
+    "cfg1_bf16": dict(batch=1, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A", cpu_f64=True),
     "cfg2": dict(batch=64, frames=300, objective="acoustic", dtype="f32", model_set="A"),
     "cfg3": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="bf16", model_set="A"),
     "cfg3_f32": dict(batch=256, frames=300, objective="acoustic_semvec", dtype="f32", model_set="A"),
@@ -391,7 +393,7 @@ def main():
         if fused_b is not None:   # name and rate the kernel the timed iteration runs; keep the per-layer kernel's figures beside it
             per_layer = {"kernel": kname, "avg_launch_us": ms * 1e3, "flops_per_launch": fl, "achieved": fl / (ms * 1e-3) / 1e12,
                          "note": "per-layer backward sweep of the predictive model, timed on its own (the A/B reference, PAULE_HIP_FUSED=1)"}
-            kname, (ms, fl) = "fused_bwd_kernel", fused_b
+            kname, (ms, fl) = ("fused_bwd16_kernel" if plan.get("fused_rows") == 16 else "fused_bwd_kernel"), fused_b   # 16: batches of up to 16 rows (lstm_fused16.h)
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc, profiles/README.md): a measurement of ANOTHER run of
@@ -444,7 +446,8 @@ def main():
                          "fwd_kernel_avg_launch_us": ms_f * 1e3,
                          "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12,
                          "fused_fwd_kernel": None if fused is None else {
-                             "kernel": "fused_fwd_kernel", "avg_launch_us": fused[0] * 1e3, "flops_per_launch": fused[1],
+                             "kernel": "fused_fwd16_kernel" if plan.get("fused_rows") == 16 else "fused_fwd_kernel",
+                             "avg_launch_us": fused[0] * 1e3, "flops_per_launch": fused[1],
                              "achieved": fused[1] / (fused[0] * 1e-3) / 1e12, "frac": fused[1] / (fused[0] * 1e-3) / 1e12 / peak}},
         }
         if gather_ms is not None:

@@ -27,6 +27,7 @@ def main():
     fetch, write = per_kernel(dfetch, "FETCH_SIZE"), per_kernel(dwrite, "WRITE_SIZE")
     res = {}
     for kname, key in (("fused_fwd_kernel", "fused_fwd_kernel"), ("fused_bwd_kernel", "fused_bwd_kernel"),
+                       ("fused_fwd16_kernel", "fused_fwd16_kernel"), ("fused_bwd16_kernel", "fused_bwd16_kernel"),
                        ("lstm_bwd16_rs_sweep_kernel", "lstm_bwd16_rs_sweep_kernel"), ("lstm_fwd16_sweep_kernel", "lstm_fwd16_sweep_kernel"),
                        ("lstm_bwd_sweep_f32_kernel", "lstm_bwd_sweep_f32_kernel"), ("lstm_fwd_sweep_f32_kernel", "lstm_fwd_sweep_f32_kernel"),
                        ("lstm_bwd_rs_stream_kernel", "lstm_bwd_rs_stream_kernel"),
