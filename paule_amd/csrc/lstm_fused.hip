@@ -836,7 +836,7 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
-                if (nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
+                if (4 * i + 3 < P || nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
             }
         }
         if constexpr (MEL) if (wave < n_mel) {
@@ -986,7 +986,7 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int nt = wave + 4 * i;
-            if (nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
+            if (4 * i + 3 < P || nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
         }
         PL_ST(2);
         raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRo
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int nt = wave + 4 * i;
-            if (nt < P) {
+            if (4 * i + 3 < P || nt < P) {   // a compile-time fact for all but a wave's last tile
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;

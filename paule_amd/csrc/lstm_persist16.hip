@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
-                if (nt >= NTT) break;
+                if (4 * i + 3 >= NTT && nt >= NTT) break;   // a compile-time fact for all but a wave's last tile
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc)

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_bwd_rs_sweep_kernel(LstmSweep
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + NW * i;
-                if (nt >= P) break;
+                if (NW * i + NW - 1 >= P && nt >= P) break;   // a compile-time fact for all but a wave's last tile
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
