@@ -37,10 +37,13 @@
 #include "fused_common.h"
 
 #ifndef F16_TG
-#define F16_TG 6     // backward: partial tiles whose MFMAs interleave (independent accumulators)
+#define F16_TG 3     // backward: partial tiles whose MFMAs interleave (independent accumulators)
 #endif
 #ifndef F16_PF
 #define F16_PF 4     // forward: B-fragment read-ahead of the MFMA chain (k-steps of 32)
+#endif
+#ifndef F16_DIRECT_STORE
+#define F16_DIRECT_STORE 1   // backward, same-XCD hand-off: partial tiles stored straight from the accumulator layout (8 bytes per lane)
 #endif
 #ifndef F16_PIPE
 #define F16_PIPE 0   // backward: 1 = the next group's MFMAs are issued before this group's epilogue
@@ -634,6 +637,22 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
                     }
             };
             auto tiles_out = [&](int grp, const f32x4 (&acc)[TG]) {
+#if F16_DIRECT_STORE
+                if (hand_fast) {   // same-XCD hand-off: the accumulator layout goes out as it is, 8 bytes per lane (a row's 32 bytes per tile contiguous)
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) {
+                        const int i = grp * TG + u, nt = wave + 4 * i;
+                        if (i < NT && (4 * i + 3 < NTT || nt < NTT)) {
+                            const uint2 v = pack_bf16x4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+                            u32x2 d;
+                            d[0] = v.x; d[1] = v.y;
+                            const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + lr * 32 + (nt & 1) * 16 + 4 * kq) * 2);
+                            __builtin_amdgcn_raw_buffer_store_b64(d, ro, off, 0, 0);
+                        }
+                    }
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int u = 0; u < TG; ++u) {
                     const int i = grp * TG + u, nt = wave + 4 * i;
