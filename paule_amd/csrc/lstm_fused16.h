@@ -242,6 +242,7 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
         }
         __syncthreads();
         PL_ST(1);   // operands -> LDS
+        if (t == 0 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());   // (not between the MFMA chain and the cell update: no branch there)
         // the projection rows of this step (written by a projection role: the blocking wait or the look-ahead has seen its flag)
         float gx[2][4];
         if constexpr (KSX == 0) {
@@ -289,7 +290,6 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[1][ks]), xb, acc[1], 0, 0, 0);
             }
         }
-        if (t == 0 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());
         PL_ST(2);   // MFMA
         // cell update (2 cells per lane) -> all six outputs into the staging image [array][row][unit]
 #pragma unroll
@@ -314,6 +314,9 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
         }
         __syncthreads();
         ext_known = lflag[3] != 0;
+#ifdef F16_NO_LOOKAHEAD
+        ext_known = false;
+#endif
         PL_ST(3);   // cell update
         // hand-off first (wave 0: 16 rows x four 16-byte pieces), then the five stash arrays (320 pieces)
         if (wave == 0) {
@@ -376,7 +379,7 @@ template <int KS>
 struct LstmBwd16Lds {
     static constexpr int Hp = 16 * KS;
     static constexpr int DRS = 128 * 2 + 16;      // dA image [16 batch rows][128 local gate rows] bf16
-    static constexpr int ORS = Hp * 2 + 16;       // partial image [16 batch rows][Hp] bf16
+    static constexpr int ORS = (Hp + 64) * 2 + 16;   // partial image [16 batch rows][Hp + 64] bf16 (a wave's surplus tile lands in the 64 spare columns)
     static constexpr int MRS = 64 * 2 + 16;       // input-gradient image [16 batch rows][64 mel columns] bf16
     static constexpr int RED_BYTES = 4 * 16 * 36 * 4;   // the four waves' f32 sums of the wide ingest
     static constexpr int O_DA = 0;
@@ -594,6 +597,9 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         __syncthreads();
         known_cur = known_nxt;          // for step t - 1
         known_nxt = lflag[3] != 0;      // for step t - 2
+#ifdef F16_NO_LOOKAHEAD
+        known_cur = known_nxt = false;
+#endif
         PL_ST(2);   // cell + dA stores + dA image
         uint4 bfr[4];
 #pragma unroll
@@ -620,8 +626,10 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             // tiles in groups of TG: a group's 4 x TG MFMAs interleave over independent accumulators (one tile's four are a dependent
             // chain).  acc[r] = partial[n = 16 nt + 4 kq + r][batch lr] -> bf16 image [batch][n]; a 16 x 16 tile is its wave's alone:
             // read back by rows (a wave's LDS operations are ordered), 32 chunks of 16 bytes = the (nt & 1) half of destination
-            // nt >> 1's [16][32] tile.  Tile validity is a compile-time fact for all but a wave's last tile: a run-time test per
-            // tile cost 0.5 ms per iteration at T = 300 (branches inside the MFMA chains)
+            // nt >> 1's [16][32] tile.  NO run-time branch anywhere between a tile's MFMAs and the reads of its accumulators: a wave's
+            // surplus tile (46 tiles over 4 waves: the twelfth of waves 2 and 3) is computed like the others (its weight rows are
+            // tile 0's) and only its store is dropped through the buffer range check.  With a branch around it the tile BEFORE it came
+            // out with a stale accumulator register in one run of four (the plan was not reproducible run to run)
             constexpr int TG = F16_TG, NGRP = (NT + TG - 1) / TG;
             f32x4 accg[2][TG];
             auto tiles_mfma = [&](int grp, f32x4 (&acc)[TG]) {
@@ -632,7 +640,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
 #pragma unroll
                     for (int u = 0; u < TG; ++u) {
                         const int i = grp * TG + u;
-                        if (i < NT && (4 * i + 3 < NTT || wave + 4 * i < NTT))
+                        if (i < NT)   // compile time.  A wave's surplus tile (waves 2, 3 of 46 tiles) is COMPUTED too and only its store dropped
                             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[i < NT ? i : 0][kc]), __builtin_bit_cast(bf16x8, bfr[kc]), acc[u], 0, 0, 0);
                     }
             };
@@ -642,11 +650,12 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
 #pragma unroll
                     for (int u = 0; u < TG; ++u) {
                         const int i = grp * TG + u, nt = wave + 4 * i;
-                        if (i < NT && (4 * i + 3 < NTT || nt < NTT)) {
+                        if (i < NT) {
                             const uint2 v = pack_bf16x4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
                             u32x2 d;
                             d[0] = v.x; d[1] = v.y;
-                            const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + lr * 32 + (nt & 1) * 16 + 4 * kq) * 2);
+                            const bool valid = 4 * i + 3 < NTT || nt < NTT;
+                            const unsigned off = valid ? (unsigned)(((size_t)(nt >> 1) * P * TILE + lr * 32 + (nt & 1) * 16 + 4 * kq) * 2) : kOob;
                             __builtin_amdgcn_raw_buffer_store_b64(d, ro, off, 0, 0);
                         }
                     }
@@ -656,18 +665,19 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
 #pragma unroll
                 for (int u = 0; u < TG; ++u) {
                     const int i = grp * TG + u, nt = wave + 4 * i;
-                    if (i < NT && (4 * i + 3 < NTT || nt < NTT))
+                    if (i < NT)
                         *reinterpret_cast<uint2*>(out_img + lr * ORS + (16 * nt + 4 * kq) * 2) = pack_bf16x4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
                 }
 #pragma unroll
                 for (int u = 0; u < TG; ++u) {
                     const int i = grp * TG + u, nt = wave + 4 * i;
-                    if (i < NT && (4 * i + 3 < NTT || nt < NTT) && lane < 32) {
+                    if (i < NT && lane < 32) {
                         const int r = lane >> 1, hc = lane & 1;
                         const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (16 * nt + 8 * hc) * 2);
                         u32x4 d;
                         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                        const unsigned off = (unsigned)(((size_t)(nt >> 1) * P * TILE + r * 32 + (nt & 1) * 16 + hc * 8) * 2);
+                        const bool valid = 4 * i + 3 < NTT || nt < NTT;
+                        const unsigned off = valid ? (unsigned)(((size_t)(nt >> 1) * P * TILE + r * 32 + (nt & 1) * 16 + hc * 8) * 2) : kOob;
                         if (hand_fast) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
                     }

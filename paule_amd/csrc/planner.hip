@@ -1460,6 +1460,7 @@ int* fused_slice(pl_handle* h, int r, bool bwd) {   // backward: r >= n_roles ar
 // the XCD ids follow where they do for the per-layer sweeps
 void fused16_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
     if (!h->fused_rows16) return;
+    if (!h->xcd_fast || !h->xcd_fast16) return;   // PAULE_HIP_XCD_FAST=0 / PAULE_HIP_XCD_FAST16=0: the write-through exchange everywhere (A/B, counter passes)
     R.fast_flags = slice + (size_t)h->T * h->flag_stride;
     R.xtab = slice + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
     R.hx = hx;
