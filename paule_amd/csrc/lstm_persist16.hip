@@ -176,7 +176,6 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
                 }
             }
             PL_ST(3);
-            if (t == t_begin && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // cell update (2 cells per lane) -> all six outputs into the staging image [array][row][unit]
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
@@ -192,6 +191,8 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_fwd16_sweep_kernel(LstmSwe
                 *reinterpret_cast<unsigned short*>(o + 4 * 16 * ORS) = bf16_bits(vo);
                 *reinterpret_cast<unsigned short*>(o + 5 * 16 * ORS) = bf16_bits(c_state[jt]);
             }
+            // (behind the cell update: no branch between the MFMA chain and the reads of its accumulators -- DESIGN.md section 11)
+            if (t == t_begin && tid == 0) __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             // hand-off first (threads 0..63: 16 rows x four 16-byte pieces), then the five stash arrays (320 pieces)
             if (tid < 64) {
