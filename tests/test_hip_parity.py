@@ -633,6 +633,32 @@ def test_fused16_launches_are_reproducible_run_to_run(HipPlanner):
     assert all(len(v) == 1 for v in seen.values()), {k: len(v) for k, v in seen.items()}
 
 
+@pytest.mark.parametrize("shape", [dict(B=256, T=150, set="A", what="fused forward launch + streamed 32-row backward sweeps (cfg3's schedule)"),
+                                   dict(B=100, T=300, set="A", what="32-row fused forward + backward launches"),
+                                   dict(B=40, T=300, set="A", what="chunk pipelines of the 16-row sweeps"),
+                                   dict(B=256, T=100, set="B", what="fused forward of two widths + 16-row wavefront bands")])
+def test_every_bf16_schedule_is_reproducible_run_to_run(HipPlanner, shape):
+    """The check that found the 16-row fused role's stale accumulator register, applied to the other bf16 schedules the planner picks:
+    six fresh engines, two iterations each -- every layer's dA, dL/dCP and the updated CP carry the same bits in all six."""
+    import hashlib
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, shape["set"])
+    n_pred = 4 if shape["set"] == "B" else 1
+    names = [f"pred.G{l}" for l in range(n_pred)] + ["emb.G0", "dX"]
+    seen = {}
+    for k in range(6):
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        eng.step(2, return_loss=False)
+        eng.synchronize()
+        for name in names:
+            seen.setdefault(name, set()).add(hashlib.md5(_n(eng.debug_read(name).float()).tobytes()).hexdigest())
+        seen.setdefault("cp", set()).add(hashlib.md5(_n(eng.get_cp()).tobytes()).hexdigest())
+        eng.close()
+    assert all(len(v) == 1 for v in seen.values()), (shape["what"], {k: len(v) for k, v in seen.items()})
+
+
 @pytest.mark.parametrize("shape", [dict(B=3, T=24, H=720), dict(B=16, T=40, H=96), dict(B=1, T=64, H=720)])
 def test_fused16_vs_oracle_and_rounding_emulation(HipPlanner, shape):
     """The 16-row fused launches against the float64 oracle (model gradient <= 2 %) and against the rounding emulation
