@@ -67,6 +67,10 @@ def load_library(path: str | None = None):
         raise HipLibraryError(
             f"{p} not found: build it with `make -C paule_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
             "g.build()'`).  paule_amd has no CPU fallback.")
+    # torch FIRST: its wheel ships its own HIP runtime, and whichever copy of libamdhip64 a process loads first is the one that
+    # initialises the device.  With this library (linked against /opt/rocm's) loaded before torch, pl_create found "no ROCm-capable
+    # device" on the GPU box (seen with build() and smoke() in ONE process: build() loads the library, smoke() then imported torch)
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(p)
     except OSError as e:  # missing libamdhip64 etc.
