@@ -178,7 +178,9 @@ void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedAr
 void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a);
 // the same role tables with the LSTM roles on 16 batch rows (v_mfma_f32_16x16x32_bf16, one chain): batches of up to 16 rows
 void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
-void launch_fused_bwd16(hipStream_t stream, int Hp, const FusedArgs& a);
+void launch_fused_bwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
+// the 16-row backward launch also takes a stacked predictor of one width in front of an embedder of another (model set B)
+bool fused_bwd16_supported(int Hp_pred, int Hp_emb);
 // zeroes n ints with write-through (sc1) stores: the arrival counters must not linger in any XCD's L2
 void launch_zero_counters(hipStream_t stream, int* p, int n);
 

@@ -1013,10 +1013,11 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
 // = loss part (computed before the launch) + 0.5 dL/dmel_t; dL/dh of the predictor's top layer for those two frames =
 // dL/dY W_p (one row per pooled frame: both frames get the same)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS>
+// KS: the predictor's width (the dL/dh rows written), KSS: the embedder's (the sources of the input-gradient tiles; model set B: 12 and 46)
+template <int KS, int KSS = KS>
 __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = LstmBwdLds<KS>;
-    constexpr int Hp = 16 * KS, P = Hp / 32, NT = (P + 3) / 4;
+    constexpr int Hp = 16 * KS, P = Hp / 32, NT = (P + 3) / 4, PS = KSS / 2;
     constexpr int TRS = L::TRS, MRS = L::MRS;
     constexpr size_t TILE = 32 * 32;
     unsigned char* dy_img = lds + L::O_MEL;     // [32 batch rows][64 mel columns] bf16
@@ -1039,21 +1040,21 @@ __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRo
         for (int ks = 0; ks < 4; ++ks) { wreg[i][ks] = gld<uint4>(WT + (size_t)n * 64 + 16 * ks + 8 * (lane >> 5)); pin(wreg[i][ks]); }
     }
     const bf16_t* __restrict__ XM = static_cast<const bf16_t*>(R.xchg_mel);   // [ring][groups][2][P src][32][32]
-    const size_t mgrp_stride = (size_t)2 * P * TILE, mslot_stride = (size_t)a.n_groups * mgrp_stride;
+    const size_t mgrp_stride = (size_t)2 * PS * TILE, mslot_stride = (size_t)a.n_groups * mgrp_stride;
     const float* __restrict__ Yl = static_cast<const float*>(R.dh_ext);       // loss part of dL/dY, f32 [2 T][Bp][64]
     bf16_t* __restrict__ Out = static_cast<bf16_t*>(R.out);                   // [T][Bp][Hp]
     const size_t slabH = (size_t)Bp * Hp;
     const int erow = tid >> 3, jq = tid & 7;   // thread -> batch row, mel columns 8 jq .. 8 jq + 7 (tile jq >> 2, columns 8 (jq & 3))
     const int out_dim = R.out_dim;
 
-    uint4 pm[P];
+    uint4 pm[PS];
     float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
     auto issue_loads = [&](int g2, int t2) {
-        const bf16_t* xs = XM + (size_t)(t2 % kFusedRing) * mslot_stride + (size_t)g2 * mgrp_stride + (size_t)(jq >> 2) * P * TILE;
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+        const bf16_t* xs = XM + (size_t)(t2 % kFusedRing) * mslot_stride + (size_t)g2 * mgrp_stride + (size_t)(jq >> 2) * PS * TILE;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(PS * TILE * 2));
         const unsigned o0 = (unsigned)((erow * 32 + 8 * (jq & 3)) * 2);
 #pragma unroll
-        for (int s = 0; s < P; ++s) pm[s] = ld16_sc1_so(rx, o0, (unsigned)(s * TILE * 2));
+        for (int s = 0; s < PS; ++s) pm[s] = ld16_sc1_so(rx, o0, (unsigned)(s * TILE * 2));
         int b2 = 32 * g2 + erow;
         b2 = b2 < Bp ? b2 : Bp - 1;
         const float* yr = Yl + ((size_t)(2 * t2) * Bp + b2) * 64 + 8 * jq;
@@ -1080,7 +1081,7 @@ __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRo
         {
             float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < P; ++s) {
+            for (int s = 0; s < PS; ++s) {
                 float f[4];
                 unpack_bf16x4(make_uint2(pm[s].x, pm[s].y), f);
                 sum[0] += f[0]; sum[1] += f[1]; sum[2] += f[2]; sum[3] += f[3];
@@ -1292,9 +1293,45 @@ __global__ __launch_bounds__(256, 1) void fused_bwd16_kernel(FusedArgs a) {
     }
 }
 
+// the backward launch of a STACKED predictor in front of an embedder of another width (model set B; 16-row roles): every role
+// runs at the width its descriptor names (`wide`: the embedder's), the backward mel head at both
+template <int KSP, int KSE>
+__global__ __launch_bounds__(256, 1) void fused_bwd16_kernel2(FusedArgs a) {
+    constexpr int l1 = LstmBwdLds<KSP>::BYTES > LstmBwdLds<KSE>::BYTES ? LstmBwdLds<KSP>::BYTES : LstmBwdLds<KSE>::BYTES;
+    constexpr int l2 = LstmBwd16Lds<KSP>::BYTES > LstmBwd16Lds<KSE>::BYTES ? LstmBwd16Lds<KSP>::BYTES : LstmBwd16Lds<KSE>::BYTES;
+    constexpr int kLds = l1 > l2 ? l1 : l2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(kLds + 15) / 16 * 16];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    const FusedRole R = uniform_role(a.roles[role]);
+    switch (R.type) {
+        case FR_LSTM_BWD:
+            if (R.wide) {
+                if (R.xchg_mel) fused_lstm_bwd16<KSE, true>(a, R, set, p, lds);
+                else fused_lstm_bwd16<KSE, false>(a, R, set, p, lds);
+            } else {
+                fused_lstm_bwd16<KSP, false>(a, R, set, p, lds);
+            }
+            break;
+        case FR_DX_BWD:
+            if (R.wide) fused_dx_bwd<KSE>(a, R, set, p, lds);
+            else fused_dx_bwd<KSP>(a, R, set, p, lds);
+            break;
+        case FR_HEAD_BWD: fused_head_bwd<KSP, KSE>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
 }  // namespace
 
 #define PL_FUSED_KS_LIST(X) X(6) X(46)
+// (predictor, embedder) widths / 16 of the two-width backward launch (16-row roles)
+#define PL_FUSED_BWD16_PAIRS(X) X(12, 46)
 // (predictor, embedder) hidden sizes / 16 of the forward launch: equal widths, and the class-default stacked predictor (4 x 180) in
 // front of a 720-wide embedder (model set B)
 #define PL_FUSED_FWD_PAIRS(X) X(6, 6) X(46, 46) X(12, 46)
@@ -1333,14 +1370,31 @@ void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const Fused
 #undef PL_CASE
 }
 
-void launch_fused_bwd16(hipStream_t stream, int Hp, const FusedArgs& a) {
+void launch_fused_bwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a) {
+    if (Hp_pred == Hp_emb) {
 #define PL_CASE(K)                                                                              \
-    if (Hp == 16 * K) {                                                                         \
+    if (Hp_pred == 16 * K) {                                                                    \
         hipLaunchKernelGGL(fused_bwd16_kernel<K>, dim3(a.grid), dim3(256), 0, stream, a);       \
         return;                                                                                 \
     }
     PL_FUSED_KS_LIST(PL_CASE)
 #undef PL_CASE
+    }
+#define PL_CASE(KP, KE)                                                                            \
+    if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) {                                                 \
+        hipLaunchKernelGGL((fused_bwd16_kernel2<KP, KE>), dim3(a.grid), dim3(256), 0, stream, a);  \
+        return;                                                                                    \
+    }
+    PL_FUSED_BWD16_PAIRS(PL_CASE)
+#undef PL_CASE
+}
+
+bool fused_bwd16_supported(int Hp_pred, int Hp_emb) {
+    if (Hp_pred == Hp_emb) return fused_supported(Hp_pred);
+#define PL_CASE(KP, KE) if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) return true;
+    PL_FUSED_BWD16_PAIRS(PL_CASE)
+#undef PL_CASE
+    return false;
 }
 
 void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a) {

@@ -246,6 +246,7 @@ struct pl_handle {
     bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
     bool fused_rows16 = false;  // batches of up to 16 rows: the LSTM roles of both launches run on 16-row tiles (lstm_fused16.h)
     void* fused_hx[kFusedMaxRoles] = {};        // rows16: the forward LSTM roles' own copies of their h hand-off [2][16][Hp]
+    void* fused_dh_pred[4] = {};                // stacked predictor in the backward launch: dL/dh rows of layer l < L - 1 (written by the product role of layer l + 1)
     short* fused_tab_bwd = nullptr;
     int fused_grid_bwd = 0;
     void* fused_xchg[kFusedMaxRoles] = {};      // recurrence exchange of every backward LSTM role (they run side by side)
@@ -356,7 +357,7 @@ void zero_all_sweep_slots(pl_handle* h, hipStream_t st) {
     // only what this handle's plan hands out is zeroed (a handle without fused launches does not pay for their slices: ADVICE r2)
     int n_used = h->n_sweep_slots;
     if (h->cfg.emb_layers > 0) {
-        const int n_roles = (2 * h->cfg.pred_layers - 1) + 1 + (2 * h->cfg.emb_layers - 1), n_fused = 2 * n_roles + (h->cfg.emb_layers - 1);
+        const int n_roles = (2 * h->cfg.pred_layers - 1) + 1 + (2 * h->cfg.emb_layers - 1), n_fused = 2 * n_roles + (h->cfg.emb_layers - 1) + (h->cfg.pred_layers - 1);
         n_used = h->n_sweep_slots - n_fused;
         if (h->fused_bwd_ok) n_used = h->n_sweep_slots;
         else if (h->fused_fwd_ok) n_used += n_roles;
@@ -1325,7 +1326,10 @@ int plan_fused(pl_handle* h) {
     // the forward launch takes a stacked predictor (all its layers one width) in front of an embedder of another width (round 3: the
     // class-default 4 x 180 predictor of model set B); the backward launch one predictor layer and equal widths, as before
     const bool fwd_shape = p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_fwd_supported(p.Hp, e.Hp) && p.Hp / 32 <= 31 && e.Hp / 32 <= 31;
-    const bool bwd_shape = p.L == 1 && p.Hp == e.Hp && fused_supported(p.Hp);
+    // backward launch: one predictor layer and equal widths on 32-row tiles; on 16-row tiles (up to 16 rows) also the stacked
+    // predictor of one width in front of an embedder of another (model set B)
+    const bool bwd_shape = rows16 ? (p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_bwd16_supported(p.Hp, e.Hp))
+                                  : (p.L == 1 && p.Hp == e.Hp && fused_supported(p.Hp));
     if (!fwd_shape && !bwd_shape) return PL_OK;
     if (rows16 && (!fwd_shape || !bwd_shape || h->bwd_mode != 1)) return PL_OK;   // the chunk pipelines keep the shape
     if (!fwd_shape) mode &= ~1;
@@ -1333,7 +1337,7 @@ int plan_fused(pl_handle* h) {
     if (!(mode & 3)) return PL_OK;
     if (p.layers[0].in_p != 32 || e.layers[0].in_p != 64 || h->Mp != 64 || h->emb_post > 0 || h->emb_blocks > 0) return PL_OK;
     if (!h->need_emb_in_step() || h->n_cu % 8 != 0) return PL_OK;
-    const int Pp = p.Hp / 32, Pe = e.Hp / 32, P = Pe, ng = (h->Bp + 31) / 32, n_emb_roles = 2 * e.L - 1, n_pred_roles = 2 * p.L - 1;
+    const int Pp = p.Hp / 32, Pe = e.Hp / 32, ng = (h->Bp + 31) / 32, n_emb_roles = 2 * e.L - 1, n_pred_roles = 2 * p.L - 1;
     if (fused_roles_count(p.L, e.L) > kFusedMaxRoles) return PL_OK;
     int forced_p = 0, forced_e = 0;
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CP")) forced_p = std::atoi(z);
@@ -1348,7 +1352,7 @@ int plan_fused(pl_handle* h) {
             // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward (equal widths):
             // one head workgroup per embedder set
             if (sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > h->n_cu) continue;
-            if ((mode & 2) && sp * Pp + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
+            if ((mode & 2) && sp * Pp * n_pred_roles + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
             const double tp = std::max(cp * 2.1, 4.2), te = std::max(ce * 2.1, 4.2) / 2.0;
             const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
             if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
@@ -1383,30 +1387,38 @@ int plan_fused(pl_handle* h) {
         }
     }
     if ((mode & 2) && h->bwd_mode == 1) {
-        // backward roles: 0 predictor, 1 backward mel head, 2 embedder layer 1; per further layer l: 3 + 2 (l - 1) its dL/dh product for
-        // the layer below, 4 + 2 (l - 1) its recurrence
+        // backward roles, numbered like the forward ones: fr_pred(l) the recurrence of predictor layer l, fr_pred_proj(l) (l >= 1) the
+        // dL/dh product of layer l for the layer below, fr_head the backward mel head, fr_emb / fr_emb_proj the embedder's.  With one
+        // predictor layer that is 0 predictor, 1 head, 2 embedder layer 1, 3 + 2 (l - 1) / 4 + 2 (l - 1) product / recurrence of layer l
         std::vector<FusedSet> sets;
-        for (int s = 0; s < sp; ++s) sets.push_back({0, s, P, true});
-        for (int s = 0; s < se; ++s) sets.push_back({2, s, P, true});
+        for (int l = 0; l < p.L; ++l)
+            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred(l), s, Pp, true});
+        for (int l = 0; l < e.L; ++l)
+            for (int s = 0; s < se; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
+        for (int l = 1; l < p.L; ++l)
+            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
         for (int l = 1; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({4 + 2 * (l - 1), s, P, true});
-        for (int l = 1; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({3 + 2 * (l - 1), s, P, false});
-        for (int s = 0; s < se; ++s) sets.push_back({1, s, 1, false});
+            for (int s = 0; s < se; ++s) sets.push_back({fr_emb_proj(p.L, l), s, Pe, false});
+        for (int s = 0; s < se; ++s) sets.push_back({fr_head(p.L), s, 1, false});
         int grid = 0;
         std::vector<short> tab = fused_block_table(h->n_cu, sets, &grid);
         if (grid > 0 && grid <= h->n_cu) {
             if ((rc = dev_alloc(h, &h->fused_tab_bwd, (size_t)h->n_cu * 4))) return rc;
             PL_HIP(hipMemcpyAsync(h->fused_tab_bwd, tab.data(), sizeof(short) * (size_t)grid * 4, hipMemcpyHostToDevice, h->stream));
             PL_HIP(hipStreamSynchronize(h->stream));
-            const size_t tile = 32 * 32 * 2, rec = 2 * (size_t)ng * P * P * tile, ring = (size_t)kFusedRing * ng * P * P * tile;
-            if ((rc = raw_alloc(h, &h->fused_xchg[0], rec))) return rc;
-            if ((rc = raw_alloc(h, &h->fused_xchg[2], rec))) return rc;
-            for (int l = 1; l < e.L; ++l) {
-                if ((rc = raw_alloc(h, &h->fused_xchg[4 + 2 * (l - 1)], rec))) return rc;
-                if ((rc = raw_alloc(h, &h->fused_xchg_ext[3 + 2 * (l - 1)], ring))) return rc;
+            const size_t tile = 32 * 32 * 2;
+            const size_t rec_p = 2 * (size_t)ng * Pp * Pp * tile, ring_p = (size_t)kFusedRing * ng * Pp * Pp * tile;
+            const size_t rec_e = 2 * (size_t)ng * Pe * Pe * tile, ring_e = (size_t)kFusedRing * ng * Pe * Pe * tile;
+            for (int l = 0; l < p.L; ++l) {
+                if ((rc = raw_alloc(h, &h->fused_xchg[fr_pred(l)], rec_p))) return rc;
+                if (l >= 1 && (rc = raw_alloc(h, &h->fused_xchg_ext[fr_pred_proj(l)], ring_p))) return rc;
+                if (l >= 1 && (rc = alloc_act(h, &h->fused_dh_pred[l - 1], (size_t)h->T * h->Bp * p.Hp))) return rc;
             }
-            if ((rc = raw_alloc(h, &h->fused_xchg_mel, (size_t)kFusedRing * ng * (h->Mp / 32) * P * tile))) return rc;
+            for (int l = 0; l < e.L; ++l) {
+                if ((rc = raw_alloc(h, &h->fused_xchg[fr_emb(p.L, l)], rec_e))) return rc;
+                if (l >= 1 && (rc = raw_alloc(h, &h->fused_xchg_ext[fr_emb_proj(p.L, l)], ring_e))) return rc;
+            }
+            if ((rc = raw_alloc(h, &h->fused_xchg_mel, (size_t)kFusedRing * ng * (h->Mp / 32) * Pe * tile))) return rc;
             h->fused_grid_bwd = grid;
             h->fused_active_bwd = 0;
             for (int b = 0; b < grid; ++b) h->fused_active_bwd += tab[(size_t)b * 4] >= 0 ? 1 : 0;
@@ -1451,7 +1463,7 @@ void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, c
 // flag slice of role r of the fused forward (bwd = false) / backward launch: the last 2 n_roles slices of an iteration
 int* fused_slice(pl_handle* h, int r, bool bwd) {   // backward: r >= n_roles are the second flag sets of the product roles
     const size_t ints = h->sweep_cnt_bytes / sizeof(int);
-    const int n_fused = 2 * h->fused_n_roles + (h->emb.L - 1);
+    const int n_fused = 2 * h->fused_n_roles + (h->emb.L - 1) + (h->pred.L - 1);
     return h->sweep_cnt + (size_t)(h->n_sweep_slots - n_fused + (bwd ? h->fused_n_roles : 0) + r) * ints;
 }
 
@@ -1469,7 +1481,7 @@ void fused16_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
 // the role tables (called once, at the end of pl_create: every buffer exists)
 int build_fused_roles(pl_handle* h) {
     Model &p = h->pred, &e = h->emb;
-    const int n_roles = h->fused_n_roles, T = h->T, Tp = h->Tp, P = p.Hp / 32;
+    const int n_roles = h->fused_n_roles, T = h->T, Tp = h->Tp;
     int rc;
     if (h->fused_fwd_ok) {
         std::vector<FusedRole> roles(n_roles);
@@ -1533,52 +1545,72 @@ int build_fused_roles(pl_handle* h) {
         std::vector<FusedRole> roles(n_roles);
         int* fl[kFusedMaxRoles];
         for (int r = 0; r < n_roles; ++r) fl[r] = fused_slice(h, r, true);
-        {   // 0: predictor recurrence; dL/dh from the backward mel head, one row per pooled frame
-            FusedRole& R = roles[0];
-            LstmLayer& ly = p.layers[0];
-            R.type = FR_LSTM_BWD; R.C = h->fused_Cp; R.T = T; R.flags = fl[0];
-            R.wait[0] = FusedWait{fl[0], T, P, 0, 0, 1};
-            R.wait[2] = FusedWait{fl[1], Tp, 1, 0, 1, 0};
+        const int Pp = p.Hp / 32, Pe = e.Hp / 32, pL = p.L;
+        const int r_head = fr_head(pL), r_emb0 = fr_emb(pL, 0);
+        // second flag sets ("the reduced dL/dh rows of a step are in place") of the product roles: the embedder's first, then the predictor's
+        auto flags2_emb = [&](int l) { return fused_slice(h, n_roles + (l - 1), true); };               // product role of embedder layer l >= 1
+        auto flags2_pred = [&](int l) { return fused_slice(h, n_roles + (e.L - 1) + (l - 1), true); };   // ... of predictor layer l >= 1
+        for (int l = 0; l < pL; ++l) {   // the predictor's recurrences: the top layer takes dL/dh from the backward mel head (one row per pooled
+            LstmLayer& ly = p.layers[l];                                   // frame), every lower layer from the product role of the layer above
+            const int rl = fr_pred(l);
+            const bool top = l == pL - 1;
+            FusedRole& R = roles[rl];
+            R.type = FR_LSTM_BWD; R.wide = 0; R.C = h->fused_Cp; R.T = T; R.flags = fl[rl];
+            R.wait[0] = FusedWait{fl[rl], T, Pp, 0, 0, 1};
             R.src_sc1 = 1;
-            R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.dh_ext = p.dh_ext; R.dh_ext_half = 1; R.dh_ext_rows = Tp; R.xchg = h->fused_xchg[0];
-            fused16_fields(h, R, fl[0], nullptr);
+            R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
+            if (top) {
+                R.wait[2] = FusedWait{fl[r_head], Tp, 1, 0, 1, 0};
+                R.dh_ext = p.dh_ext; R.dh_ext_half = 1; R.dh_ext_rows = Tp;
+            } else {
+                R.wait[1] = FusedWait{flags2_pred(l + 1), T, 1, 1, 0, 0};
+                R.dh_ext = h->fused_dh_pred[l]; R.dh_ext_half = 0; R.dh_ext_rows = T;
+            }
+            fused16_fields(h, R, fl[rl], nullptr);
+            if (l >= 1) {   // this layer's dA feeds its product role: dL/dh of the layer below
+                R.dA_sc1 = 1;
+                const int rdx = fr_pred_proj(l);
+                FusedRole& D = roles[rdx];
+                D.type = FR_DX_BWD; D.wide = 0; D.C = h->fused_Cp; D.T = T; D.flags = fl[rdx];
+                D.flags2 = flags2_pred(l);
+                D.wait[0] = FusedWait{D.flags2, T, Pp, 0, 0, kFusedRing};
+                D.wait[2] = FusedWait{fl[rl], T, 1, 1, 0, 0};
+                D.G = ly.G; D.Wg = ly.WihT; D.xchg_ext = h->fused_xchg_ext[rdx]; D.out = h->fused_dh_pred[l - 1];
+            }
         }
-        {   // 1: backward mel head
-            FusedRole& R = roles[1];
-            R.type = FR_HEAD_BWD; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[1];
-            R.wait[0] = FusedWait{fl[2], Tp, P, 0, 0, 0};
+        {   // backward mel head: input-gradient tiles of the embedder's first layer in, dL/dh rows of the predictor's top layer out
+            FusedRole& R = roles[r_head];
+            R.type = FR_HEAD_BWD; R.wide = 0; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[r_head];
+            R.wait[0] = FusedWait{fl[r_emb0], Tp, Pe, 0, 0, 0};
             R.Wg = p.WlinT; R.out = p.dh_ext; R.dh_ext = h->Y; R.out_dim = h->M; R.out_p = h->Mp; R.xchg_mel = h->fused_xchg_mel;
         }
         for (int l = 0; l < e.L; ++l) {
             LstmLayer& ly = e.layers[l];
-            const int rl = l == 0 ? 2 : 4 + 2 * (l - 1);
+            const int rl = fr_emb(pL, l);
             const bool top = l == e.L - 1;
             FusedRole& R = roles[rl];
-            R.type = FR_LSTM_BWD; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[rl];
-            R.wait[0] = FusedWait{fl[rl], Tp, P, 0, 0, 1};
+            R.type = FR_LSTM_BWD; R.wide = 1; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[rl];
+            R.wait[0] = FusedWait{fl[rl], Tp, Pe, 0, 0, 1};
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
             fused16_fields(h, R, fl[rl], nullptr);
             if (top) R.dh_last = h->dv;
             else {   // dL/dh rows from the layer above's product role (reduced there): this slice's columns come from its slice-p workgroup
-                const int rdx = 3 + 2 * l;
-                R.wait[1] = FusedWait{fused_slice(h, n_roles + l, true), Tp, 1, 1, 0, 0};
+                R.wait[1] = FusedWait{flags2_emb(l + 1), Tp, 1, 1, 0, 0};
                 R.dh_ext = e.dh_ext; R.dh_ext_rows = Tp; R.src_sc1 = 1;
-                (void)rdx;
             }
             if (l == 0) {   // input-gradient tiles for the backward mel head; a ring slot is free once the head has finished the step that used it
-                R.wait[2] = FusedWait{fl[1], Tp, 1, 0, 0, kFusedRing};
+                R.wait[2] = FusedWait{fl[r_head], Tp, 1, 0, 0, kFusedRing};
                 R.Wg = ly.WihT; R.out_p = h->Mp; R.xchg_mel = h->fused_xchg_mel;
             } else {        // this layer's dA feeds its product role
                 R.dA_sc1 = 1;
-                const int rdx = 3 + 2 * (l - 1), rbelow = l == 1 ? 2 : 4 + 2 * (l - 2);
+                const int rdx = fr_emb_proj(pL, l);
                 FusedRole& D = roles[rdx];
-                D.type = FR_DX_BWD; D.C = h->fused_Ce; D.T = Tp; D.flags = fl[rdx];
-                D.flags2 = fused_slice(h, n_roles + (l - 1), true);
+                D.type = FR_DX_BWD; D.wide = 1; D.C = h->fused_Ce; D.T = Tp; D.flags = fl[rdx];
+                D.flags2 = flags2_emb(l);
                 // a ring slot of partial tiles is free once every workgroup of the set has reduced the step that used it
-                D.wait[0] = FusedWait{D.flags2, Tp, P, 0, 0, kFusedRing};
+                D.wait[0] = FusedWait{D.flags2, Tp, Pe, 0, 0, kFusedRing};
                 D.wait[2] = FusedWait{fl[rl], Tp, 1, 1, 0, 0};
                 D.G = ly.G; D.Wg = ly.WihT; D.xchg_ext = h->fused_xchg_ext[rdx]; D.out = e.dh_ext;
-                (void)rbelow;
             }
         }
         if ((rc = dev_alloc(h, &h->fused_roles_bwd, (size_t)n_roles))) return rc;
@@ -1610,7 +1642,7 @@ bool fused_acoustic_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
     launch_dy(st, F32, la, nullptr, h->Y);
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
-    if (h->fused_rows16) launch_fused_bwd16(st, p.Hp, a);
+    if (h->fused_rows16) launch_fused_bwd16(st, p.Hp, h->emb.Hp, a);
     else launch_fused_bwd(st, p.Hp, a);
     LstmLayer& l0 = p.layers[0];
     launch_gemm_nt(st, h->dt, true, l0.G, 4 * p.Hp, l0.WihT, 4 * p.Hp, nullptr, h->dX, l0.in_p, h->T * h->Bp, l0.in_p, 4 * p.Hp);
@@ -2107,7 +2139,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
         // forward + backward sweep of every layer of an iteration, + the head / projection roles of the fused launches
         h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers) +
-                           (cfg->emb_layers > 0 ? 2 * fused_roles_count(cfg->pred_layers, cfg->emb_layers) + (cfg->emb_layers - 1) : 0);
+                           (cfg->emb_layers > 0 ? 2 * fused_roles_count(cfg->pred_layers, cfg->emb_layers) + (cfg->emb_layers - 1) + (cfg->pred_layers - 1) : 0);
         if ((rc = dev_alloc(h, &h->sweep_cnt, h->sweep_cnt_bytes / sizeof(int) * h->n_sweep_slots))) return bail(rc);
         if ((rc = dev_alloc(h, &h->sweep_status, 4))) return bail(rc);
 #ifdef PL_STAMPS
@@ -2778,7 +2810,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
             zero_all_sweep_slots(h, h->stream);   // time does not depend on the data, and every pl_step rebuilds what it overwrites
             FusedArgs a{};
             fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
-            if (h->fused_rows16) launch_fused_bwd16(h->stream, h->pred.Hp, a);
+            if (h->fused_rows16) launch_fused_bwd16(h->stream, h->pred.Hp, h->emb.Hp, a);
             else launch_fused_bwd(h->stream, h->pred.Hp, a);
             h->sweep_slot = -1;
         }

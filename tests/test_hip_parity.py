@@ -610,6 +610,31 @@ def test_fused16_launches_equal_pipelines_forward_and_fused32_throughout(HipPlan
     assert (e["fused16"].losses[-1, :, 0] < e["fused16"].losses[0, :, 0]).all()
 
 
+@pytest.mark.parametrize("shape", [dict(B=16, T=60, graph=True), dict(B=1, T=300, graph=True), dict(B=7, T=31, graph=False)])
+def test_fused16_stacked_predictor_of_another_width(HipPlanner, monkeypatch, shape):
+    """Model set B (the class-default stacked 4 x 180 predictor in front of a 720-wide embedder) at up to 16 rows: BOTH launches
+    fused on 16-row tiles -- backward: four predictor recurrences and the three dL/dh product roles between them at the predictor's
+    width, the backward mel head at both widths, the embedder's recurrence at its own (round 3; the 32-row backward launch still
+    takes one predictor layer).  Forward: every stash of every layer and the pooled mel bit-identical to the chunk pipelines; first
+    iteration: identical losses, dL/dCP cosine >= 0.99999; six iterations: losses and CP stay with the pipelines' (bf16 exchange
+    roundings only)."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "B")
+    bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
+    e = _pair16(HipPlanner, monkeypatch, wl, B, T, 1, False, "pipelines", stop_after_fwd=True)
+    for name in bufs:
+        np.testing.assert_array_equal(_n(e["fused16"].debug_read(name)), _n(e["pipelines"].debug_read(name)), err_msg=name)
+    e = _pair16(HipPlanner, monkeypatch, wl, B, T, 1, False, "pipelines")
+    np.testing.assert_array_equal(e["fused16"].losses, e["pipelines"].losses)
+    np.testing.assert_array_equal(_n(e["fused16"].debug_read("emb.G0")), _n(e["pipelines"].debug_read("emb.G0")))   # the top layer: same arithmetic
+    for name in ("pred.G3", "pred.G0", "dX"):
+        assert _cos(e["fused16"].debug_read(name), e["pipelines"].debug_read(name)) >= 0.99999, name
+    e = _pair16(HipPlanner, monkeypatch, wl, B, T, 6, shape["graph"], "pipelines")
+    np.testing.assert_allclose(e["fused16"].losses, e["pipelines"].losses, rtol=1e-4, atol=1e-6)
+    assert np.abs(_n(e["fused16"].get_cp()) - _n(e["pipelines"].get_cp())).max() <= 2e-4   # lr = 0.01: 2 % of one step
+    assert (e["fused16"].losses[-1, :, 0] < e["fused16"].losses[0, :, 0]).all()
+
+
 def test_fused16_launches_are_reproducible_run_to_run(HipPlanner):
     """Ten fresh engines, one iteration each of cfg5's shape (16 x 2000 frames, Paule's models): every layer's dA and dL/dCP carry
     the same bits in all ten.  Round 3 found the first version of the 16-row backward role NOT reproducible (one run in four
@@ -618,19 +643,20 @@ def test_fused16_launches_are_reproducible_run_to_run(HipPlanner):
     computed and only its store dropped (lstm_fused16.h); the tolerance-based parity tests had not seen it."""
     import hashlib
     B, T = 16, 2000
-    wl = synthetic.make_workload(B, T, "A")
-    seen = {}
-    for k in range(10):
-        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
-        assert eng.plan_info()["fused_rows"] == 16
-        eng.set_targets(wl.target_mel, wl.target_semvec)
-        eng.set_cp(wl.cp0)
-        eng.step(1, return_loss=False)
-        eng.synchronize()
-        for name in ("emb.G1", "emb.G0", "pred.G0", "dX"):
-            seen.setdefault(name, set()).add(hashlib.md5(_n(eng.debug_read(name).float()).tobytes()).hexdigest())
-        eng.close()
-    assert all(len(v) == 1 for v in seen.values()), {k: len(v) for k, v in seen.items()}
+    for mset, names in (("A", ("emb.G1", "emb.G0", "pred.G0", "dX")), ("B", ("emb.G0", "pred.G3", "pred.G2", "pred.G1", "pred.G0", "dX"))):
+        wl = synthetic.make_workload(B, T, mset)   # set B: the stacked 4 x 180 predictor in front of the 720-wide embedder (two-width launches)
+        seen = {}
+        for k in range(10 if mset == "A" else 6):
+            eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+            assert eng.plan_info()["fused_rows"] == 16
+            eng.set_targets(wl.target_mel, wl.target_semvec)
+            eng.set_cp(wl.cp0)
+            eng.step(1, return_loss=False)
+            eng.synchronize()
+            for name in names:
+                seen.setdefault(name, set()).add(hashlib.md5(_n(eng.debug_read(name).float()).tobytes()).hexdigest())
+            eng.close()
+        assert all(len(v) == 1 for v in seen.values()), (mset, {k: len(v) for k, v in seen.items()})
 
 
 @pytest.mark.parametrize("shape", [dict(B=256, T=150, set="A", what="fused forward launch + streamed 32-row backward sweeps (cfg3's schedule)"),
@@ -1669,6 +1695,10 @@ _GRAD_FAMILIES = [
     ("stacked predictor (set B), fused forward launch of two widths, ragged", dict(B=100, T=24, pred=(4, 180), emb=(1, 720), fused_fwd=1), {}),
     ("stacked predictor (set B), B = 256, fused forward launch", dict(B=256, T=20, pred=(4, 180), emb=(1, 720), fused_fwd=1), {}),
     ("stacked predictor (set B), B = 256, per-layer path", dict(B=256, T=20, pred=(4, 180), emb=(1, 720)), {"PAULE_HIP_FUSED": "0"}),
+    ("16-row fused launches, one utterance", dict(B=1, T=40, pred=(1, 720), emb=(2, 720), fused_rows=16), {}),
+    ("16-row fused launches, H = 96, 16 rows", dict(B=16, T=31, pred=(1, 96), emb=(2, 96), fused_rows=16), {}),
+    ("16-row fused launches, stacked predictor of another width (set B), ragged", dict(B=5, T=40, pred=(4, 180), emb=(1, 720), fused_rows=16), {}),
+    ("16-row fused launches, 2 x 180 predictor + 3 x 720 embedder", dict(B=12, T=26, pred=(2, 180), emb=(3, 720), fused_rows=16), {}),
     ("2 x 360 / 2 x 360", dict(B=40, T=30, pred=(2, 360), emb=(2, 360)), {}),
     ("tiny ragged model, odd T", dict(B=5, T=31, pred=(1, 48), emb=(1, 40)), {}),
     ("launch-per-step kernels", dict(B=20, T=30, pred=(1, 96), emb=(2, 96)), {"PAULE_HIP_NO_SWEEP": "1"}),
@@ -1694,6 +1724,8 @@ def test_bf16_model_gradient_across_kernel_families(HipPlanner, case, monkeypatc
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
     if "fused_fwd" in c:   # the family this case names is the one the library planned
         assert eng.plan_info()["fused_fwd"] == c["fused_fwd"], eng.plan_info()
+    if "fused_rows" in c:
+        assert eng.plan_info()["fused_rows"] == c["fused_rows"] and eng.plan_info()["fused_bwd"] == 1, eng.plan_info()
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     eng.step(1, return_loss=False)
