@@ -175,7 +175,7 @@ bool fused_supported(int Hp);
 // embedder's may have different hidden sizes (model set B: 4 x 180 in front of 720)
 bool fused_fwd_supported(int Hp_pred, int Hp_emb);
 void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
-void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a);
+void launch_fused_bwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 // the same role tables with the LSTM roles on 16 batch rows (v_mfma_f32_16x16x32_bf16, one chain): batches of up to 16 rows
 void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 void launch_fused_bwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);

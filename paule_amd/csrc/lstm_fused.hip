@@ -1327,6 +1327,37 @@ __global__ __launch_bounds__(256, 1) void fused_bwd16_kernel2(FusedArgs a) {
     }
 }
 
+// ... and the same on 32-row tiles (49 ... 128 rows)
+template <int KSP, int KSE>
+__global__ __launch_bounds__(256, 1) void fused_bwd_kernel2(FusedArgs a) {
+    constexpr int kLds = LstmBwdLds<KSP>::BYTES > LstmBwdLds<KSE>::BYTES ? LstmBwdLds<KSP>::BYTES : LstmBwdLds<KSE>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(kLds + 15) / 16 * 16];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    const FusedRole R = uniform_role(a.roles[role]);
+    switch (R.type) {
+        case FR_LSTM_BWD:
+            if (R.wide) {
+                if (R.xchg_mel) fused_lstm_bwd<KSE, false, true>(a, R, set, p, lds);
+                else fused_lstm_bwd<KSE, false, false>(a, R, set, p, lds);
+            } else {
+                fused_lstm_bwd<KSP, false, false>(a, R, set, p, lds);
+            }
+            break;
+        case FR_DX_BWD:
+            if (R.wide) fused_dx_bwd<KSE>(a, R, set, p, lds);
+            else fused_dx_bwd<KSP>(a, R, set, p, lds);
+            break;
+        case FR_HEAD_BWD: fused_head_bwd<KSP, KSE>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
 }  // namespace
 
 #define PL_FUSED_KS_LIST(X) X(6) X(46)
@@ -1397,13 +1428,22 @@ bool fused_bwd16_supported(int Hp_pred, int Hp_emb) {
     return false;
 }
 
-void launch_fused_bwd(hipStream_t stream, int Hp, const FusedArgs& a) {
+void launch_fused_bwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a) {
+    if (Hp_pred == Hp_emb) {
 #define PL_CASE(K)                                                                              \
-    if (Hp == 16 * K) {                                                                         \
+    if (Hp_pred == 16 * K) {                                                                    \
         hipLaunchKernelGGL(fused_bwd_kernel<K>, dim3(a.grid), dim3(256), 0, stream, a);         \
         return;                                                                                 \
     }
     PL_FUSED_KS_LIST(PL_CASE)
+#undef PL_CASE
+    }
+#define PL_CASE(KP, KE)                                                                          \
+    if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) {                                               \
+        hipLaunchKernelGGL((fused_bwd_kernel2<KP, KE>), dim3(a.grid), dim3(256), 0, stream, a);  \
+        return;                                                                                  \
+    }
+    PL_FUSED_BWD16_PAIRS(PL_CASE)
 #undef PL_CASE
 }
 

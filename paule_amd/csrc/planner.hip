@@ -1313,7 +1313,16 @@ int plan_fused(pl_handle* h) {
     // step latency hides); from 129 rows on the backward launch needs 2 - 4 chains per workgroup, its chain-step is bound by the
     // CU's memory pipe and the per-layer backward sweeps are faster (B = 256: 5.82 vs 7.19 ms) -- forward launch only.
     int mode = h->Bp >= 129 ? 1 : 3;
-    if (const char* z = std::getenv("PAULE_HIP_FUSED")) mode = std::atoi(z);
+    // A STACKED predictor of another width than the embedder (the class-default 4 x 180 in front of 720: model set B) keeps both
+    // launches at every batch size the roles fit: its recurrences are narrow (6 workgroups a set against 23), the chain counts stay
+    // low, and the backward launch wins up to 256 rows as well (B = 64: 3.57 -> 2.49 ms per iteration, B = 256: 5.47 -> 4.52;
+    // profiles/r03_ab_setB_fused_backward.txt).  PAULE_HIP_FUSED_BWD_STACKED=0: the backward stays on the per-layer sweeps.
+    const bool two_width = !(h->pred.L == 1 && h->pred.Hp == h->emb.Hp);
+    bool stacked32 = true;
+    if (const char* z = std::getenv("PAULE_HIP_FUSED_BWD_STACKED")) stacked32 = std::atoi(z) != 0;
+    bool mode_forced = false;
+    if (two_width && stacked32) mode = 3;
+    if (const char* z = std::getenv("PAULE_HIP_FUSED")) { mode = std::atoi(z); mode_forced = true; }
     int min_rows = 49;   // 17 .. 48 rows: the 16-row kernels' chunk pipelines (4.1f) are as fast or faster (T = 2000, B = 32: 19.2 vs 20.8 ms)
     if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
     // up to 16 rows (ONE 16-row group: the reference's own B = 1, continued learning's 8, cfg5's 16 per GPU): both launches with the
@@ -1328,8 +1337,8 @@ int plan_fused(pl_handle* h) {
     const bool fwd_shape = p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_fwd_supported(p.Hp, e.Hp) && p.Hp / 32 <= 31 && e.Hp / 32 <= 31;
     // backward launch: one predictor layer and equal widths on 32-row tiles; on 16-row tiles (up to 16 rows) also the stacked
     // predictor of one width in front of an embedder of another (model set B)
-    const bool bwd_shape = rows16 ? (p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_bwd16_supported(p.Hp, e.Hp))
-                                  : (p.L == 1 && p.Hp == e.Hp && fused_supported(p.Hp));
+    const bool bwd_shape = (rows16 || (stacked32 && two_width)) ? (p.L >= 1 && p.L <= 4 && e.L >= 1 && e.L <= 4 && fused_bwd16_supported(p.Hp, e.Hp))
+                                                 : (p.L == 1 && p.Hp == e.Hp && fused_supported(p.Hp));
     if (!fwd_shape && !bwd_shape) return PL_OK;
     if (rows16 && (!fwd_shape || !bwd_shape || h->bwd_mode != 1)) return PL_OK;   // the chunk pipelines keep the shape
     if (!fwd_shape) mode &= ~1;
@@ -1344,19 +1353,25 @@ int plan_fused(pl_handle* h) {
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CE")) forced_e = std::atoi(z);
     double best_cost = 1e30;
     int best_cp = 0, best_ce = 0;
-    const int cmax = ((mode & 2) && h->bwd_mode == 1) ? 4 : kFusedMaxChains;   // the backward roles have LDS for 4 chains (lstm_fused.hip)
-    for (int cp = 1; cp <= cmax; ++cp)
-        for (int ce = 1; ce <= cmax; ++ce) {
-            if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
-            const int sp = (ng + cp - 1) / cp, se = (ng + ce - 1) / ce;
-            // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward (equal widths):
-            // one head workgroup per embedder set
-            if (sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > h->n_cu) continue;
-            if ((mode & 2) && sp * Pp * n_pred_roles + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
-            const double tp = std::max(cp * 2.1, 4.2), te = std::max(ce * 2.1, 4.2) / 2.0;
-            const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
-            if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
+    for (int attempt = 0; attempt < 2 && !best_cp; ++attempt) {
+        if (attempt == 1) {   // both launches do not fit the chip at this batch: the forward launch alone (unless the mode was asked for)
+            if (mode_forced || rows16 || (mode & 3) != 3) break;
+            mode &= ~2;
         }
+        const int cmax = ((mode & 2) && h->bwd_mode == 1) ? 4 : kFusedMaxChains;   // the backward roles have LDS for 4 chains (lstm_fused.hip)
+        for (int cp = 1; cp <= cmax; ++cp)
+            for (int ce = 1; ce <= cmax; ++ce) {
+                if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
+                const int sp = (ng + cp - 1) / cp, se = (ng + ce - 1) / ce;
+                // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward: the
+                // predictor's roles, the embedder's, one head workgroup per embedder set
+                if ((mode & 1) && sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > h->n_cu) continue;
+                if ((mode & 2) && sp * Pp * n_pred_roles + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
+                const double tp = std::max(cp * 2.1, 4.2), te = std::max(ce * 2.1, 4.2) / 2.0;
+                const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
+                if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
+            }
+    }
     if (!best_cp) return PL_OK;
     const int sp = (ng + best_cp - 1) / best_cp, se = (ng + best_ce - 1) / best_ce;
     h->fused_Cp = best_cp; h->fused_Ce = best_ce;
@@ -1643,7 +1658,7 @@ bool fused_acoustic_backward(pl_handle* h, hipStream_t st, const LossArgs& la) {
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
     if (h->fused_rows16) launch_fused_bwd16(st, p.Hp, h->emb.Hp, a);
-    else launch_fused_bwd(st, p.Hp, a);
+    else launch_fused_bwd(st, p.Hp, h->emb.Hp, a);
     LstmLayer& l0 = p.layers[0];
     launch_gemm_nt(st, h->dt, true, l0.G, 4 * p.Hp, l0.WihT, 4 * p.Hp, nullptr, h->dX, l0.in_p, h->T * h->Bp, l0.in_p, 4 * p.Hp);
     return true;
@@ -2811,7 +2826,7 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
             FusedArgs a{};
             fused_common_args(h, a, h->fused_grid_bwd, h->fused_tab_bwd, h->fused_roles_bwd, true);
             if (h->fused_rows16) launch_fused_bwd16(h->stream, h->pred.Hp, h->emb.Hp, a);
-            else launch_fused_bwd(h->stream, h->pred.Hp, a);
+            else launch_fused_bwd(h->stream, h->pred.Hp, h->emb.Hp, a);
             h->sweep_slot = -1;
         }
         PL_HIP(hipEventRecord(e1, h->stream));

@@ -550,6 +550,39 @@ def test_fused_backward_matches_per_layer_path(HipPlanner, monkeypatch, shape):
     assert np.abs(_n(e["3"].get_cp()) - _n(e["0"].get_cp())).max() <= 2e-4   # lr = 0.01: 2 % of one step
 
 
+@pytest.mark.parametrize("shape", [dict(B=256, T=60, graph=True), dict(B=70, T=31, graph=False)])
+def test_fused_backward_stacked_predictor_tracks_the_per_layer_path(HipPlanner, monkeypatch, shape):
+    """Round 3: the fused BACKWARD launch takes the class-default stacked predictor too (model set B: four recurrences and three dL/dh
+    product roles at the predictor's width, the backward mel head at both widths, the embedder's recurrence at its own) and is the
+    default for such models at every batch the roles fit (cfg3_setB: 5.47 -> 4.52 ms per iteration).  Against the per-layer backward
+    (PAULE_HIP_FUSED_BWD_STACKED=0, same fused forward launch): the embedder's dA stash bit-identical (the top layer: same arithmetic),
+    every predictor layer's dA and dL/dCP to bf16 noise (cosine >= 0.99999), six iterations of the plan within 2 % of one step."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "B")
+    out = {}
+    for stacked in ("1", "0"):
+        monkeypatch.setenv("PAULE_HIP_FUSED_BWD_STACKED", stacked)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=shape["graph"])
+        plan = eng.plan_info()
+        assert plan["fused_fwd"] == 1 and plan["fused_bwd"] == int(stacked) and plan["fused_rows"] == 32, plan
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        l1 = _n(eng.step(1))
+        eng.synchronize()
+        bufs = {k: _n(eng.debug_read(k)) for k in ("emb.G0", "pred.G3", "pred.G2", "pred.G1", "pred.G0", "dX")}
+        l6 = _n(eng.step(5))
+        eng.synchronize()
+        out[stacked] = (l1, bufs, l6, _n(eng.get_cp()))
+        eng.close()
+    monkeypatch.delenv("PAULE_HIP_FUSED_BWD_STACKED")
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    np.testing.assert_array_equal(out["1"][1]["emb.G0"], out["0"][1]["emb.G0"])
+    for k in ("pred.G3", "pred.G2", "pred.G1", "pred.G0", "dX"):
+        assert _cos(out["1"][1][k], out["0"][1][k]) >= 0.99999, k
+    np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=1e-4, atol=1e-6)
+    assert np.abs(out["1"][3] - out["0"][3]).max() <= 2e-4
+
+
 # ---- fused launches on 16-row tiles (lstm_fused16.h): batches of up to 16 rows -- the reference's own B = 1 ---------------------
 def _pair16(HipPlanner, monkeypatch, wl, B, T, iters, use_graph, other, stop_after_fwd=False):
     """The same plan with the 16-row fused launches (the default for up to 16 rows) and on `other`: "pipelines" (PAULE_HIP_FUSED16=0:
@@ -662,7 +695,7 @@ def test_fused16_launches_are_reproducible_run_to_run(HipPlanner):
 @pytest.mark.parametrize("shape", [dict(B=256, T=150, set="A", what="fused forward launch + streamed 32-row backward sweeps (cfg3's schedule)"),
                                    dict(B=100, T=300, set="A", what="32-row fused forward + backward launches"),
                                    dict(B=40, T=300, set="A", what="chunk pipelines of the 16-row sweeps"),
-                                   dict(B=256, T=100, set="B", what="fused forward of two widths + 16-row wavefront bands")])
+                                   dict(B=256, T=100, set="B", what="fused forward + backward launches of two widths (stacked predictor)")])
 def test_every_bf16_schedule_is_reproducible_run_to_run(HipPlanner, shape):
     """The check that found the 16-row fused role's stale accumulator register, applied to the other bf16 schedules the planner picks:
     six fresh engines, two iterations each -- every layer's dA, dL/dCP and the updated CP carry the same bits in all six."""
@@ -1692,8 +1725,10 @@ _GRAD_FAMILIES = [
     ("fused forward launch, 32-row backward sweeps", dict(B=160, T=20, pred=(1, 720), emb=(2, 720)), {}),
     ("per-layer 32-row sweeps", dict(B=160, T=20, pred=(1, 720), emb=(2, 720)), {"PAULE_HIP_FUSED": "0"}),
     ("stacked predictor (set B), 16-row sweeps + wavefront", dict(B=100, T=24, pred=(4, 180), emb=(1, 720)), {"PAULE_HIP_FUSED": "0"}),
-    ("stacked predictor (set B), fused forward launch of two widths, ragged", dict(B=100, T=24, pred=(4, 180), emb=(1, 720), fused_fwd=1), {}),
-    ("stacked predictor (set B), B = 256, fused forward launch", dict(B=256, T=20, pred=(4, 180), emb=(1, 720), fused_fwd=1), {}),
+    ("stacked predictor (set B), fused forward + backward launches of two widths, ragged", dict(B=100, T=24, pred=(4, 180), emb=(1, 720), fused_fwd=1, fused_bwd=1), {}),
+    ("stacked predictor (set B), B = 256, fused forward + backward launches", dict(B=256, T=20, pred=(4, 180), emb=(1, 720), fused_fwd=1, fused_bwd=1), {}),
+    ("stacked predictor (set B), B = 256, fused forward launch + per-layer backward", dict(B=256, T=20, pred=(4, 180), emb=(1, 720), fused_fwd=1, fused_bwd=0), {"PAULE_HIP_FUSED_BWD_STACKED": "0"}),
+    ("2 x 180 predictor + 2 x 720 embedder, fused launches of two widths", dict(B=70, T=22, pred=(2, 180), emb=(2, 720), fused_fwd=1, fused_bwd=1), {}),
     ("stacked predictor (set B), B = 256, per-layer path", dict(B=256, T=20, pred=(4, 180), emb=(1, 720)), {"PAULE_HIP_FUSED": "0"}),
     ("16-row fused launches, one utterance", dict(B=1, T=40, pred=(1, 720), emb=(2, 720), fused_rows=16), {}),
     ("16-row fused launches, H = 96, 16 rows", dict(B=16, T=31, pred=(1, 96), emb=(2, 96), fused_rows=16), {}),
@@ -1726,6 +1761,8 @@ def test_bf16_model_gradient_across_kernel_families(HipPlanner, case, monkeypatc
         assert eng.plan_info()["fused_fwd"] == c["fused_fwd"], eng.plan_info()
     if "fused_rows" in c:
         assert eng.plan_info()["fused_rows"] == c["fused_rows"] and eng.plan_info()["fused_bwd"] == 1, eng.plan_info()
+    if "fused_bwd" in c:
+        assert eng.plan_info()["fused_bwd"] == c["fused_bwd"], eng.plan_info()
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     eng.step(1, return_loss=False)
