@@ -393,7 +393,10 @@ def main():
         if fused_b is not None:   # name and rate the kernel the timed iteration runs; keep the per-layer kernel's figures beside it
             per_layer = {"kernel": kname, "avg_launch_us": ms * 1e3, "flops_per_launch": fl, "achieved": fl / (ms * 1e-3) / 1e12,
                          "note": "per-layer backward sweep of the predictive model, timed on its own (the A/B reference, PAULE_HIP_FUSED=1)"}
-            kname, (ms, fl) = ("fused_bwd16_kernel" if plan.get("fused_rows") == 16 else "fused_bwd_kernel"), fused_b   # 16: batches of up to 16 rows (lstm_fused16.h)
+            kname = "fused_bwd16_kernel" if plan.get("fused_rows") == 16 else "fused_bwd_kernel"   # 16: batches of up to 16 rows (lstm_fused16.h)
+            if cfg["model_set"] == "B":
+                kname += "2"   # stacked predictor of another width than the embedder: the two-width kernels
+            ms, fl = fused_b
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc, profiles/README.md): a measurement of ANOTHER run of

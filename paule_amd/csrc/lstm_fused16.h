@@ -26,11 +26,13 @@
 //    hand-off loads of the step before: a wave's loads return in order, a memory-latency load in front of the flag poll or of
 //    the tile loads would hold them back by its whole latency.
 //
-// Measured (profiles/r03_ab_fused16.txt, r03_bench_cfg5.json): B = 1 .. 16 x 300 frames 3.08 -> 2.13 ms per iteration, cfg5
-// (16 x 2000) 18.8 -> 14.4 ms.  Phase stamps of the critical roles (tools/fused_stamps.py 16): forward 2.6 us per step (wait 0.7,
-// h tile -> LDS 0.6, MFMA chain 0.8, cell + stores + flag 0.5), backward 4.0 (wait 1.0, ingest 1.0, cell 0.45, tiles 1.2, drain +
-// flag 0.3).  Dropped after measurement: run-time tile-validity tests inside the MFMA chains (+ 0.5 ms per iteration), a deeper
-// B-fragment read-ahead (PF 6 / 8 / 12: 2.13 / 2.15 / 2.28 against 2.12 ms), software-pipelined tile groups (no gain over TG = 6).
+// Measured (profiles/r03_ab_fused16_final.txt, r03_bench_cfg5.json): B = 1 .. 16 x 300 frames 3.07 -> 2.05 ms per iteration, cfg5
+// (16 x 2000) 18.6 -> 13.8 ms; with the write-through form of the own exchange forced 2.33 ms at B = 16 x 300.  Phase stamps of the
+// critical roles (tools/fused_stamps.py 16): forward 2.6 us per step (wait 0.7, h tile -> LDS 0.6, MFMA chain 0.8, cell + stores +
+// flag 0.5), backward ~3.9 (wait 1.0, ingest 1.0, cell 0.45, tiles 1.1, drain + flag 0.3).  What was tried and dropped: DESIGN.md A.7.
+//
+// A stacked predictor of another width than the embedder (model set B) runs on the same roles through the two-width kernels of
+// lstm_fused.hip (fused_bwd16_kernel2): the predictor's layers and their dL/dh product roles at the predictor's width.
 //
 // One group, one chain: the host plans these roles for Bp = 16 only (planner.hip: plan_fused).
 #pragma once

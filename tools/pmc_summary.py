@@ -28,6 +28,7 @@ def main():
     res = {}
     for kname, key in (("fused_fwd_kernel", "fused_fwd_kernel"), ("fused_bwd_kernel", "fused_bwd_kernel"),
                        ("fused_fwd16_kernel", "fused_fwd16_kernel"), ("fused_bwd16_kernel", "fused_bwd16_kernel"),
+                       ("fused_bwd_kernel2", "fused_bwd_kernel2"), ("fused_bwd16_kernel2", "fused_bwd16_kernel2"),
                        ("lstm_bwd16_rs_sweep_kernel", "lstm_bwd16_rs_sweep_kernel"), ("lstm_fwd16_sweep_kernel", "lstm_fwd16_sweep_kernel"),
                        ("lstm_bwd_sweep_f32_kernel", "lstm_bwd_sweep_f32_kernel"), ("lstm_fwd_sweep_f32_kernel", "lstm_fwd_sweep_f32_kernel"),
                        ("lstm_bwd_rs_stream_kernel", "lstm_bwd_rs_stream_kernel"),
