@@ -207,6 +207,25 @@ __device__ __forceinline__ FlagPoll step_flags(const FusedArgs& a, const Waits& 
     return s;
 }
 __device__ __forceinline__ bool poll_empty(const FlagPoll& s) { return s.na == 0 && s.nb == 0 && !s.fc; }
+// 16-row LSTM roles (lstm_fused16.h) keep one row of flags per 16-ROW group; a product role working on the 32-row group g waits for
+// the rows of the 16-row groups 2 g and 2 g + 1 (the second only if the batch has it).  _w0: the role's wait 0 names an LSTM role
+// (mel head, projections, backward mel head); _w2: its wait 2 does (dL/dh product role: one flag per group, its partner's).
+__device__ __forceinline__ FlagPoll step_flags_lstm16_w0(const FusedArgs& a, const Waits& W, int g, int t, int p) {
+    FlagPoll s{nullptr, 0, nullptr, 0, nullptr};
+    int n2 = 0;
+    s.fa = wait_addr(a, W.w0, 2 * g, t, p, s.na);
+    if (16 * (2 * g + 1) < a.Bp) s.fb = wait_addr(a, W.w0, 2 * g + 1, t, p, s.nb);
+    s.fc = wait_addr(a, W.w2, g, t, p, n2);
+    return s;
+}
+__device__ __forceinline__ FlagPoll step_flags_lstm16_w2(const FusedArgs& a, const Waits& W, int g, int t, int p) {
+    FlagPoll s{nullptr, 0, nullptr, 0, nullptr};
+    int n2 = 0;
+    s.fa = wait_addr(a, W.w0, g, t, p, s.na);
+    if (16 * (2 * g + 1) < a.Bp) s.fb = wait_addr(a, W.w2, 2 * g + 1, t, p, s.nb);
+    s.fc = wait_addr(a, W.w2, 2 * g, t, p, n2);
+    return s;
+}
 
 }  // namespace
 }  // namespace pl

@@ -366,7 +366,7 @@ struct GemmFwdLds {
     static constexpr int BYTES = O_FLAG + 64;
 };
 
-template <int KS, bool HEAD>
+template <int KS, bool HEAD, bool G16 = false>   // G16: the role it waits for is a 16-row LSTM role (one flag row per 16-row group)
 __device__ __forceinline__ void fused_gemm_fwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = GemmFwdLds<KS>;
     constexpr int Hp = 16 * KS, KB = KS / 2, CH = L::CH, IRS = L::IRS, ORS = L::ORS, ROWB = Hp * 2;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void fused_gemm_fwd(const FusedArgs& a, const FusedRo
     PL_ST_DECL
     int c = 0, t = 0;
     {
-        const FlagPoll s0 = step_flags(a, WT_, set * RC, 0, p);
+        const FlagPoll s0 = (G16 ? step_flags_lstm16_w0(a, WT_, set * RC, 0, p) : step_flags(a, WT_, set * RC, 0, p));
         if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
         issue_loads(set * RC, 0);
     }
@@ -437,7 +437,7 @@ __device__ __forceinline__ void fused_gemm_fwd(const FusedArgs& a, const FusedRo
         }
         __syncthreads();
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
-        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        if (has_next) pn = (G16 ? step_flags_lstm16_w0(a, WT_, gn, tn, p) : step_flags(a, WT_, gn, tn, p));
         int pv = 1;
         const bool poll_here = wave == 0 && has_next;
         __builtin_amdgcn_sched_barrier(0);
@@ -868,7 +868,7 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
 // W_ih^T and hands the P partial tiles to the layer below (ring of kFusedRing steps; a slot is rewritten only after every
 // consumer has raised its flag of the step that used it).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS>
+template <int KS, bool G16 = false>
 __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = LstmBwdLds<KS>;
     constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32, NT = (P + 3) / 4;
@@ -951,7 +951,7 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
     PL_ST_DECL
     int c = 0, t = T - 1, pg = -1, pt = -1;
     {
-        const FlagPoll s0 = step_flags(a, WT_, set * RC, t, p);
+        const FlagPoll s0 = (G16 ? step_flags_lstm16_w2(a, WT_, set * RC, t, p) : step_flags(a, WT_, set * RC, t, p));
         if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
         issue_loads(set * RC, t);
     }
@@ -962,7 +962,7 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
         const bool has_next = tn >= 0;
         const int gn = set * RC + cn;
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
-        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        if (has_next) pn = (G16 ? step_flags_lstm16_w2(a, WT_, gn, tn, p) : step_flags(a, WT_, gn, tn, p));
         int pvl = 1;
         if (wave == 0 && has_next) pvl = poll_load(pn, lane);
 #pragma unroll
@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void fused_dx_bwd(const FusedArgs& a, const FusedRole
 // dL/dY W_p (one row per pooled frame: both frames get the same)
 // ---------------------------------------------------------------------------------------------------------------------
 // KS: the predictor's width (the dL/dh rows written), KSS: the embedder's (the sources of the input-gradient tiles; model set B: 12 and 46)
-template <int KS, int KSS = KS>
+template <int KS, int KSS = KS, bool G16 = false>
 __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = LstmBwdLds<KS>;
     constexpr int Hp = 16 * KS, P = Hp / 32, NT = (P + 3) / 4, PS = KSS / 2;
@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRo
     PL_ST_DECL
     int c = 0, t = T - 1;
     {
-        const FlagPoll s0 = step_flags(a, WT_, set * RC, t, p);
+        const FlagPoll s0 = (G16 ? step_flags_lstm16_w0(a, WT_, set * RC, t, p) : step_flags(a, WT_, set * RC, t, p));
         if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
         issue_loads(set * RC, t);
     }
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void fused_head_bwd(const FusedArgs& a, const FusedRo
         const bool has_next = tn >= 0;
         const int gn = set * RC + cn;
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
-        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        if (has_next) pn = (G16 ? step_flags_lstm16_w0(a, WT_, gn, tn, p) : step_flags(a, WT_, gn, tn, p));
         int pvl = 1;
         if (wave == 0 && has_next) pvl = poll_load(pn, lane);
         {
@@ -1244,8 +1244,8 @@ __device__ __forceinline__ void fused_fwd16_role(const FusedArgs& a, const Fused
             else if (R.ksx == 4) fused_lstm_fwd16<KS, 2>(a, R, set, p, lds);
             else fused_lstm_fwd16<KS, 0>(a, R, set, p, lds);
             break;
-        case FR_PROJ_FWD: fused_gemm_fwd<KS, false>(a, R, set, p, lds); break;
-        case FR_HEAD_FWD: fused_gemm_fwd<KS, true>(a, R, set, p, lds); break;
+        case FR_PROJ_FWD: fused_gemm_fwd<KS, false, true>(a, R, set, p, lds); break;
+        case FR_HEAD_FWD: fused_gemm_fwd<KS, true, true>(a, R, set, p, lds); break;
         default: break;
     }
 }
@@ -1287,8 +1287,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd16_kernel(FusedArgs a) {
             if (R.xchg_mel) fused_lstm_bwd16<KS, true>(a, R, set, p, lds);
             else fused_lstm_bwd16<KS, false>(a, R, set, p, lds);
             break;
-        case FR_DX_BWD: fused_dx_bwd<KS>(a, R, set, p, lds); break;
-        case FR_HEAD_BWD: fused_head_bwd<KS>(a, R, set, p, lds); break;
+        case FR_DX_BWD: fused_dx_bwd<KS, true>(a, R, set, p, lds); break;
+        case FR_HEAD_BWD: fused_head_bwd<KS, KS, true>(a, R, set, p, lds); break;
         default: break;
     }
 }
@@ -1319,10 +1319,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd16_kernel2(FusedArgs a) {
             }
             break;
         case FR_DX_BWD:
-            if (R.wide) fused_dx_bwd<KSE>(a, R, set, p, lds);
-            else fused_dx_bwd<KSP>(a, R, set, p, lds);
+            if (R.wide) fused_dx_bwd<KSE, true>(a, R, set, p, lds);
+            else fused_dx_bwd<KSP, true>(a, R, set, p, lds);
             break;
-        case FR_HEAD_BWD: fused_head_bwd<KSP, KSE>(a, R, set, p, lds); break;
+        case FR_HEAD_BWD: fused_head_bwd<KSP, KSE, true>(a, R, set, p, lds); break;
         default: break;
     }
 }

@@ -95,11 +95,11 @@ __device__ __forceinline__ bool wait16(const int* own, int n_own, bool own_fast,
 }
 
 // what a step waits for from OTHER roles (FusedWait 1 -> lanes 32.., FusedWait 2 -> lane 63)
-__device__ __forceinline__ FlagPoll ext_flags(const FusedArgs& a, const FusedRole& R, int t, int p) {
+__device__ __forceinline__ FlagPoll ext_flags(const FusedArgs& a, const FusedRole& R, int g32, int t, int p) {   // g32: the product roles' 32-row group
     FlagPoll s{nullptr, 0, nullptr, 0, nullptr};
     int n2 = 0;
-    s.fb = wait_addr(a, R.wait[1], 0, t, p, s.nb);
-    s.fc = wait_addr(a, R.wait[2], 0, t, p, n2);
+    s.fb = wait_addr(a, R.wait[1], g32, t, p, s.nb);
+    s.fc = wait_addr(a, R.wait[2], g32, t, p, n2);
     return s;
 }
 __device__ __forceinline__ bool ext_empty(const FlagPoll& s) { return s.nb == 0 && !s.fc; }
@@ -144,7 +144,10 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
     const int Bp = a.Bp, T = R.T;
-    if (set != 0 || Bp != 16 || a.n_groups != 1) return;   // one group of 16 (padded) rows: the host plans nothing else for these roles
+    // one 16-row group per set (one chain): set s serves batch rows 16 s .. 16 s + 15 (Bp is a multiple of 16: all of them exist).  Every
+    // pointer below is moved to the group's first row / the group's own region once, so the step loop indexes rows 0 .. 15
+    const int g = set, g32 = g >> 1, ng16 = Bp / 16;
+    if (16 * g >= Bp) return;
     const bf16_t* __restrict__ W = static_cast<const bf16_t*>(R.W);
 
     // weights -> registers: A row lr of tile j = unit 8 wave + 4 j + (lr >> 2), gate lr & 3; k = 32 ks + 8 kq .. + 7
@@ -170,16 +173,17 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
     // cell ownership (C layout): batch row lr, units 8 wave + kq (tile 0) and 8 wave + 4 + kq (tile 1); accumulator register = gate
     const int ul[2] = {8 * wave + kq, 8 * wave + 4 + kq};
     const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
-    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
-    bf16_t* __restrict__ Hs = static_cast<bf16_t*>(R.h);
-    bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c);
-    bf16_t* __restrict__ HX = static_cast<bf16_t*>(R.hx);        // [2][16][Hp], this role's own copy of the hand-off
-    const bf16_t* const x_in = static_cast<const bf16_t*>(R.x_in);
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G) + (size_t)16 * g * G4;
+    bf16_t* __restrict__ Hs = static_cast<bf16_t*>(R.h) + (size_t)16 * g * Hp;
+    bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c) + (size_t)16 * g * Hp;
+    const size_t hx_slot = (size_t)ng16 * 16 * Hp;
+    bf16_t* __restrict__ HX = R.hx ? static_cast<bf16_t*>(R.hx) + (size_t)g * 16 * Hp : nullptr;   // [2][groups][16][Hp], this role's own copy of the hand-off
+    const bf16_t* const x_in = R.x_in ? static_cast<const bf16_t*>(R.x_in) + (size_t)16 * g * INP : nullptr;
     const bool src_sc1 = R.src_sc1 != 0;
-    int* const Fpub = R.flags;
-    int* const Ffast = R.fast_flags;
-    int* const xtab = R.xtab;
     const int fs = a.flag_stride;
+    int* const Fpub = R.flags + (size_t)g * T * fs;
+    int* const Ffast = R.fast_flags ? R.fast_flags + (size_t)g * T * fs : nullptr;
+    int* const xtab = R.xtab ? R.xtab + g * 64 : nullptr;
 
     float c_state[2] = {0.f, 0.f};
     bool fast = false;          // the role's workgroups share one XCD (verified at step 1): own hand-off through its L2
@@ -198,11 +202,11 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
     fetch_x(0);
 
     for (int t = 0; t < T; ++t) {
-        const FlagPoll ext = ext_flags(a, R, t, p);
+        const FlagPoll ext = ext_flags(a, R, g32, t, p);
         const bool has_ext = !ext_empty(ext);
         // look-ahead at what step t + 1 needs from other roles: asked by a wave that does not poll, answered under this step
         FlagPoll ext_n{nullptr, 0, nullptr, 0, nullptr};
-        if (t + 1 < T) ext_n = ext_flags(a, R, t + 1, p);
+        if (t + 1 < T) ext_n = ext_flags(a, R, g32, t + 1, p);
         const bool la_here = !ext_empty(ext_n);
         if (wave == 3 && la_here) la_pv = ext_poll(ext_n, lane);
         uint4 xv = xv_n;   // fetched a step ago
@@ -222,7 +226,7 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
         f32x4 acc[2];
         if (t > 0) {
             const bool from_hx = fast && t >= 2;
-            const bf16_t* hsrc = from_hx ? HX + (size_t)((t - 1) & 1) * 16 * Hp : Hs + (size_t)(t - 1) * slabH;
+            const bf16_t* hsrc = from_hx ? HX + (size_t)((t - 1) & 1) * hx_slot : Hs + (size_t)(t - 1) * slabH;
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hsrc, (unsigned)(16 * ROWB));
             uint4 v[NLD];
 #pragma unroll
@@ -327,7 +331,7 @@ __device__ __forceinline__ void fused_lstm_fwd16(const FusedArgs& a, const Fused
             u32x4 d;
             d[0] = hv.x; d[1] = hv.y; d[2] = hv.z; d[3] = hv.w;
             if (fast) {   // the role's own copy: plain, stays in this XCD's L2
-                const __amdgpu_buffer_rsrc_t rx = make_rsrc(HX + (size_t)(t & 1) * 16 * Hp, (unsigned)(16 * ROWB));
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(HX + (size_t)(t & 1) * hx_slot, (unsigned)(16 * ROWB));
                 __builtin_amdgcn_raw_buffer_store_b128(d, rx, (unsigned)((row * Hp + 32 * p + 8 * qt) * 2), 0, 0);
             }
             const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
@@ -411,7 +415,8 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
     const int Bp = a.Bp, T = R.T;
-    if (set != 0 || Bp != 16 || a.n_groups != 1) return;
+    const int g = set, g32 = g >> 1, ng16 = Bp / 16;   // one 16-row group per set; pointers moved to the group once (see the forward role)
+    if (16 * g >= Bp) return;
     const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(R.W);   // Whh^T packed [Hp][4 Hp]
     // tile nt = wave + 4 i: A row lr = hidden column 16 nt + lr; k chunk kc (= gate kc): gate row kc * Hp + 32 p + 8 kq + jj
     uint4 wreg[NT][4];
@@ -432,20 +437,23 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     const int erow = tid >> 4, jq = tid & 15;
     const int j = 32 * p + 2 * jq;
     const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
-    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
-    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(R.c);
-    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(R.dh_ext);
-    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(R.dh_last);
-    bf16_t* __restrict__ X = static_cast<bf16_t*>(R.xchg);        // [2 slots][P destinations][P sources][16][32]
-    bf16_t* __restrict__ XM = static_cast<bf16_t*>(R.xchg_mel);   // [ring][2 tiles of 32 columns][P sources][32][32]
-    const size_t slot_stride = (size_t)P * P * TILE;
-    const size_t mslot_stride = (size_t)2 * P * TILE32;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G) + (size_t)16 * g * G4;
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(R.c) + (size_t)16 * g * Hp;
+    const bf16_t* __restrict__ dhe = R.dh_ext ? static_cast<const bf16_t*>(R.dh_ext) + (size_t)16 * g * Hp : nullptr;
+    const bf16_t* __restrict__ dhl = R.dh_last ? static_cast<const bf16_t*>(R.dh_last) + (size_t)16 * g * Hp : nullptr;
+    // own exchange [2 slots][groups][P destinations][P sources][16][32]
+    bf16_t* __restrict__ X = static_cast<bf16_t*>(R.xchg) + (size_t)g * P * P * TILE;
+    // input-gradient tiles in the backward mel head's layout [ring][32-row groups][2 tiles of 32 columns][P sources][32][32]: this group's
+    // rows are rows 16 (g & 1) .. of its 32-row group's tiles
+    bf16_t* __restrict__ XM = R.xchg_mel ? static_cast<bf16_t*>(R.xchg_mel) + (size_t)g32 * 2 * P * TILE32 + (size_t)(g & 1) * 16 * 32 : nullptr;
+    const size_t slot_stride = (size_t)ng16 * P * P * TILE;
+    const size_t mslot_stride = (size_t)a.n_groups * 2 * P * TILE32;
     const bool src_sc1 = R.src_sc1 != 0, dA_sc1 = R.dA_sc1 != 0;
     const int dh_ext_half = R.dh_ext_half, dh_ext_rows = R.dh_ext_rows;
-    int* const Fpub = R.flags;
-    int* const Ffast = R.fast_flags;
-    int* const xtab = R.xtab;
     const int fs = a.flag_stride;
+    int* const Fpub = R.flags + (size_t)g * T * fs;
+    int* const Ffast = R.fast_flags ? R.fast_flags + (size_t)g * T * fs : nullptr;
+    int* const xtab = R.xtab ? R.xtab + g * 64 : nullptr;
     auto pk2 = [](float x, float y) -> unsigned { return (unsigned)bf16_bits16(x) | ((unsigned)bf16_bits16(y) << 16); };
 
     float dc_next[2] = {0.f, 0.f};
@@ -488,10 +496,10 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     else if (!dhe) n_dh_valid = true;
 
     for (int t = T - 1; t >= 0; --t) {
-        const FlagPoll ext = ext_flags(a, R, t, p);
+        const FlagPoll ext = ext_flags(a, R, g32, t, p);
         const bool has_ext = !ext_empty(ext);
         FlagPoll ext_2{nullptr, 0, nullptr, 0, nullptr};
-        if (t > 1) ext_2 = ext_flags(a, R, t - 2, p);
+        if (t > 1) ext_2 = ext_flags(a, R, g32, t - 2, p);
         const bool la_here = !ext_empty(ext_2);
         if (wave == 3 && la_here) la_pv = ext_poll(ext_2, lane);
         // this step's operands: fetched one step ago
@@ -521,7 +529,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             asm volatile("" ::: "memory");   // the next step's operands behind the tile loads
             if (t > 0) {
                 fetch_stash(t - 1);
-                const bool ext1 = !ext_empty(ext_flags(a, R, t - 1, p));
+                const bool ext1 = !ext_empty(ext_flags(a, R, g32, t - 1, p));
                 n_dh_valid = !dhe || !ext1 || known_nxt;
                 n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
             }
@@ -541,7 +549,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             __syncthreads();
         } else if (t > 0) {
             fetch_stash(t - 1);
-            const bool ext1 = !ext_empty(ext_flags(a, R, t - 1, p));
+            const bool ext1 = !ext_empty(ext_flags(a, R, g32, t - 1, p));
             n_dh_valid = !dhe || !ext1 || known_nxt;
             n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
         }

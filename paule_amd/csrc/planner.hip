@@ -1327,7 +1327,7 @@ int plan_fused(pl_handle* h) {
     if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
     // up to 16 rows (ONE 16-row group: the reference's own B = 1, continued learning's 8, cfg5's 16 per GPU): both launches with the
     // LSTM roles on 16-row tiles and the same-XCD form of each role's own exchange (lstm_fused16.h) -- both or neither
-    bool rows16 = h->Bp == 16 && h->Bp < min_rows;
+    bool rows16 = h->Bp <= 48 && h->Bp < min_rows;   // one, two or three 16-row groups, each a set of its own in every LSTM role
     if (const char* z = std::getenv("PAULE_HIP_FUSED16")) rows16 = rows16 && std::atoi(z) != 0;
     if (rows16 && ((mode & 3) != 3 || !h->sweep16)) rows16 = false;   // PAULE_HIP_SWEEP16=0: no 16-row kernels of either kind
     const Model &p = h->pred, &e = h->emb;
@@ -1353,6 +1353,12 @@ int plan_fused(pl_handle* h) {
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CE")) forced_e = std::atoi(z);
     double best_cost = 1e30;
     int best_cp = 0, best_ce = 0;
+    const int ng16 = h->Bp / 16;
+    if (rows16) {   // 16-row LSTM roles: one set per 16-row group, one chain; the product roles keep one set per 32-row group
+        const int lstm_f = ng16 * (Pp * p.L + Pe * e.L), prod_f = ng * (Pp * (p.L - 1) + Pe * (e.L - 1) + 1);
+        if (lstm_f + prod_f > h->n_cu) return PL_OK;   // forward and backward launch have the same counts
+        best_cp = best_ce = 1;
+    }
     for (int attempt = 0; attempt < 2 && !best_cp; ++attempt) {
         if (attempt == 1) {   // both launches do not fit the chip at this batch: the forward launch alone (unless the mode was asked for)
             if (mode_forced || rows16 || (mode & 3) != 3) break;
@@ -1374,16 +1380,17 @@ int plan_fused(pl_handle* h) {
     }
     if (!best_cp) return PL_OK;
     const int sp = (ng + best_cp - 1) / best_cp, se = (ng + best_ce - 1) / best_ce;
+    const int sp_l = rows16 ? ng16 : sp, se_l = rows16 ? ng16 : se;   // sets of the LSTM roles
     h->fused_Cp = best_cp; h->fused_Ce = best_ce;
     h->fused_n_roles = fused_roles_count(p.L, e.L);
     int rc;
     if (mode & 1) {
         std::vector<FusedSet> sets;
         for (int l = 0; l < p.L; ++l)
-            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred(l), s, Pp, true});
-        for (int s = 0; s < se; ++s) sets.push_back({fr_emb(p.L, 0), s, Pe, true});
+            for (int s = 0; s < sp_l; ++s) sets.push_back({fr_pred(l), s, Pp, true});
+        for (int s = 0; s < se_l; ++s) sets.push_back({fr_emb(p.L, 0), s, Pe, true});
         for (int l = 1; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
+            for (int s = 0; s < se_l; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
         for (int l = 1; l < p.L; ++l)
             for (int s = 0; s < sp; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
         for (int l = 1; l < e.L; ++l)
@@ -1407,9 +1414,9 @@ int plan_fused(pl_handle* h) {
         // predictor layer that is 0 predictor, 1 head, 2 embedder layer 1, 3 + 2 (l - 1) / 4 + 2 (l - 1) product / recurrence of layer l
         std::vector<FusedSet> sets;
         for (int l = 0; l < p.L; ++l)
-            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred(l), s, Pp, true});
+            for (int s = 0; s < sp_l; ++s) sets.push_back({fr_pred(l), s, Pp, true});
         for (int l = 0; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
+            for (int s = 0; s < se_l; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
         for (int l = 1; l < p.L; ++l)
             for (int s = 0; s < sp; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
         for (int l = 1; l < e.L; ++l)
@@ -1444,9 +1451,9 @@ int plan_fused(pl_handle* h) {
         if (h->fused_fwd_ok && h->fused_bwd_ok) {
             h->fused_rows16 = true;
             for (int l = 0; l < p.L; ++l)
-                if ((rc = raw_alloc(h, &h->fused_hx[fr_pred(l)], (size_t)2 * 16 * p.Hp * 2))) return rc;
+                if ((rc = raw_alloc(h, &h->fused_hx[fr_pred(l)], (size_t)2 * ng16 * 16 * p.Hp * 2))) return rc;
             for (int l = 0; l < e.L; ++l)
-                if ((rc = raw_alloc(h, &h->fused_hx[fr_emb(p.L, l)], (size_t)2 * 16 * e.Hp * 2))) return rc;
+                if ((rc = raw_alloc(h, &h->fused_hx[fr_emb(p.L, l)], (size_t)2 * ng16 * 16 * e.Hp * 2))) return rc;
         } else {
             h->fused_fwd_ok = h->fused_bwd_ok = false;
         }
@@ -1488,7 +1495,9 @@ int* fused_slice(pl_handle* h, int r, bool bwd) {   // backward: r >= n_roles ar
 void fused16_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
     if (!h->fused_rows16) return;
     if (!h->xcd_fast || !h->xcd_fast16) return;   // PAULE_HIP_XCD_FAST=0 / PAULE_HIP_XCD_FAST16=0: the write-through exchange everywhere (A/B, counter passes)
-    R.fast_flags = slice + (size_t)h->T * h->flag_stride;
+    // the slice holds (Bp + 7) / 8 = 2 x (Bp / 16) groups' worth of arrival flags: the write-through set of the 16-row groups first, the
+    // plain set behind it; one XCD-id table of 64 per group follows, as for the per-layer sweeps
+    R.fast_flags = slice + (size_t)(h->Bp / 16) * h->T * h->flag_stride;
     R.xtab = slice + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
     R.hx = hx;
 }

@@ -614,9 +614,11 @@ def _pair16(HipPlanner, monkeypatch, wl, B, T, iters, use_graph, other, stop_aft
 
 
 @pytest.mark.parametrize("shape", [dict(B=16, T=61, H=720, graph=True), dict(B=1, T=300, H=720, graph=True), dict(B=5, T=41, H=96, graph=False),
-                                   dict(B=9, T=14, H=720, graph=False)])
+                                   dict(B=9, T=14, H=720, graph=False), dict(B=32, T=61, H=720, graph=True), dict(B=48, T=40, H=720, graph=False),
+                                   dict(B=20, T=33, H=720, graph=True), dict(B=37, T=30, H=96, graph=False)])
 def test_fused16_launches_equal_pipelines_forward_and_fused32_throughout(HipPlanner, monkeypatch, shape):
-    """Batches of up to 16 rows (ONE 16-row group: the reference's B = 1, cfg5's 16 per GPU) run both fused launches with the LSTM
+    """Batches of up to 48 rows (one to three 16-row groups, each a set of workgroups of its own in every LSTM role: the reference's
+    B = 1, cfg5's 16 per GPU, ragged batches of 20 and 37) run both fused launches with the LSTM
     roles on 16-row tiles, each role's own exchange in the verified same-XCD form (plain stores / nt loads, a second flag set; the
     write-through flags other roles wait for are raised a step late).
       * Forward: the arithmetic of the 16-row per-layer kernels, instruction for instruction -- every stash, the pooled mel and the
@@ -643,7 +645,8 @@ def test_fused16_launches_equal_pipelines_forward_and_fused32_throughout(HipPlan
     assert (e["fused16"].losses[-1, :, 0] < e["fused16"].losses[0, :, 0]).all()
 
 
-@pytest.mark.parametrize("shape", [dict(B=16, T=60, graph=True), dict(B=1, T=300, graph=True), dict(B=7, T=31, graph=False)])
+@pytest.mark.parametrize("shape", [dict(B=16, T=60, graph=True), dict(B=1, T=300, graph=True), dict(B=7, T=31, graph=False),
+                                   dict(B=30, T=40, graph=True), dict(B=48, T=26, graph=False)])
 def test_fused16_stacked_predictor_of_another_width(HipPlanner, monkeypatch, shape):
     """Model set B (the class-default stacked 4 x 180 predictor in front of a 720-wide embedder) at up to 16 rows: BOTH launches
     fused on 16-row tiles -- backward: four predictor recurrences and the three dL/dh product roles between them at the predictor's
@@ -694,7 +697,8 @@ def test_fused16_launches_are_reproducible_run_to_run(HipPlanner):
 
 @pytest.mark.parametrize("shape", [dict(B=256, T=150, set="A", what="fused forward launch + streamed 32-row backward sweeps (cfg3's schedule)"),
                                    dict(B=100, T=300, set="A", what="32-row fused forward + backward launches"),
-                                   dict(B=40, T=300, set="A", what="chunk pipelines of the 16-row sweeps"),
+                                   dict(B=40, T=300, set="A", what="16-row fused launches, three groups"),
+                                   dict(B=40, T=300, set="C", what="chunk pipelines of the 16-row sweeps (an embedder variant keeps them)"),
                                    dict(B=256, T=100, set="B", what="fused forward + backward launches of two widths (stacked predictor)")])
 def test_every_bf16_schedule_is_reproducible_run_to_run(HipPlanner, shape):
     """The check that found the 16-row fused role's stale accumulator register, applied to the other bf16 schedules the planner picks:
@@ -1734,6 +1738,8 @@ _GRAD_FAMILIES = [
     ("16-row fused launches, H = 96, 16 rows", dict(B=16, T=31, pred=(1, 96), emb=(2, 96), fused_rows=16), {}),
     ("16-row fused launches, stacked predictor of another width (set B), ragged", dict(B=5, T=40, pred=(4, 180), emb=(1, 720), fused_rows=16), {}),
     ("16-row fused launches, 2 x 180 predictor + 3 x 720 embedder", dict(B=12, T=26, pred=(2, 180), emb=(3, 720), fused_rows=16), {}),
+    ("16-row fused launches, three groups (41 rows)", dict(B=41, T=24, pred=(1, 720), emb=(2, 720), fused_rows=16), {}),
+    ("16-row fused launches, two groups, stacked predictor (set B)", dict(B=27, T=30, pred=(4, 180), emb=(1, 720), fused_rows=16), {}),
     ("2 x 360 / 2 x 360", dict(B=40, T=30, pred=(2, 360), emb=(2, 360)), {}),
     ("tiny ragged model, odd T", dict(B=5, T=31, pred=(1, 48), emb=(1, 40)), {}),
     ("launch-per-step kernels", dict(B=20, T=30, pred=(1, 96), emb=(2, 96)), {"PAULE_HIP_NO_SWEEP": "1"}),
