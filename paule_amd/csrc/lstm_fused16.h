@@ -1,4 +1,4 @@
-// LSTM roles of the fused launches for batches of UP TO 16 ROWS (the reference plans one utterance, paule/paule.py:585-588;
+// LSTM roles of the fused launches for batches of UP TO 48 ROWS, on 16-row tiles (the reference plans one utterance, paule/paule.py:585-588;
 // continued learning uses mini-batches of 8, :404; BASELINE configs[4] leaves 16 utterances per GPU).
 //
 // Why.  A recurrence of one 16-row group is pure latency: 2 x 23 MFMAs of 16 x 16 x 32 and a 23-KB operand per step.  The 32-row
@@ -34,7 +34,9 @@
 // A stacked predictor of another width than the embedder (model set B) runs on the same roles through the two-width kernels of
 // lstm_fused.hip (fused_bwd16_kernel2): the predictor's layers and their dL/dh product roles at the predictor's width.
 //
-// One group, one chain: the host plans these roles for Bp = 16 only (planner.hip: plan_fused).
+// One 16-row group per set of workgroups, one chain: the host plans these roles for up to 48 rows (one to three groups; planner.hip:
+// plan_fused).  The product roles keep one set per 32 rows and wait for the flag rows of both 16-row groups of their 32
+// (step_flags_lstm16_w0 / _w2, fused_common.h).
 #pragma once
 #include "fused_common.h"
 
