@@ -1323,10 +1323,11 @@ int plan_fused(pl_handle* h) {
     bool mode_forced = false;
     if (two_width && stacked32) mode = 3;
     if (const char* z = std::getenv("PAULE_HIP_FUSED")) { mode = std::atoi(z); mode_forced = true; }
-    int min_rows = 49;   // 17 .. 48 rows: the 16-row kernels' chunk pipelines (4.1f) are as fast or faster (T = 2000, B = 32: 19.2 vs 20.8 ms)
+    int min_rows = 49;   // fewest rows on the 32-row roles; below: 16-row roles (rows16), else the chunk pipelines (4.1f) -- they beat the
+                         // 32-row roles there (T = 2000, B = 32: 19.2 vs 20.8 ms)
     if (const char* z = std::getenv("PAULE_HIP_FUSED_MIN_B")) min_rows = std::atoi(z);
-    // up to 16 rows (ONE 16-row group: the reference's own B = 1, continued learning's 8, cfg5's 16 per GPU): both launches with the
-    // LSTM roles on 16-row tiles and the same-XCD form of each role's own exchange (lstm_fused16.h) -- both or neither
+    // up to 48 rows (one to three 16-row groups: the reference's own B = 1, continued learning's 8, cfg5's 16 per GPU): both launches
+    // with the LSTM roles on 16-row tiles and the same-XCD form of each role's own exchange (lstm_fused16.h) -- both or neither
     bool rows16 = h->Bp <= 48 && h->Bp < min_rows;   // one, two or three 16-row groups, each a set of its own in every LSTM role
     if (const char* z = std::getenv("PAULE_HIP_FUSED16")) rows16 = rows16 && std::atoi(z) != 0;
     if (rows16 && ((mode & 3) != 3 || !h->sweep16)) rows16 = false;   // PAULE_HIP_SWEEP16=0: no 16-row kernels of either kind
