@@ -179,13 +179,15 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return r;
 }
 
-// sum of squares of the correlation d[t] = sum_k taps[k] x[t+k]; d itself is kept (d_out [n][C]) for the gradient pass
+// sum of squares of the correlation d[t] = sum_k taps[k] x[t+k] over the frames t0 .. t1-1; d itself is kept (d_out [n][C]) for the
+// gradient pass
 template <int K>
 __device__ __forceinline__ double corr_sumsq(const double* __restrict__ x, int T, int C, const double* taps, int tid,
-                                             int nthreads, double* __restrict__ d_out) {
+                                             int nthreads, double* __restrict__ d_out, int t0, int t1) {
     const int n = T - K + 1;
+    const int u1 = t1 < n ? t1 : n;
     double s = 0.0;
-    for (int e = tid; e < n * C; e += nthreads) {
+    for (int e = t0 * C + tid; e < u1 * C; e += nthreads) {
         const int t = e / C, c = e % C;
         double d = 0.0;
 #pragma unroll
@@ -219,35 +221,43 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double (*sh)[N]) {
 }
 __device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh)[6]) { block_sum_n<6>(v, sh); }
 
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a) {
+// One workgroup per (utterance, chunk of kLossChunkT CP frames): B = 16 x 2000 frames on 16 workgroups took 0.2 ms (cfg5).  The
+// chunking is a function of T alone, so an utterance's sums are the same bits in whatever batch it is planned (the row-independence
+// tests); the chunks' partial sums are added in order by loss_finalize_kernel.
+constexpr int kLossChunkT = 256;
+// up to 511 frames one workgroup per utterance (T = 300 at B = 256: two half-size workgroups per utterance measured no faster), then
+// one per ~256 frames, of equal length
+int loss_chunks(int T) { return T < 2 * kLossChunkT ? 1 : (T + kLossChunkT - 1) / kLossChunkT; }
+
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a, int nchunk) {
     __shared__ double sh[16][8];
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    double* sc = a.scal + (size_t)b * 8;
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, tid = threadIdx.x, nt = blockDim.x;
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // mel SSE, semvec SSE, vel, jerk, ll, classifier logit sum, tube mel SSE, tube semvec SSE
 
     // RMSE over the utterance's T' x M mel frames (RMSELoss eps = 0, paule/util.py:570-572) and, in the same pass, the speech
-    // classifier's logit: mean over time of Linear(60 -> 1) (paule/models.py:899-908)
+    // classifier's logit: mean over time of Linear(60 -> 1) (paule/models.py:899-908); this chunk's share of the elements
     const int nm = a.Tp * a.M;
+    const int e0 = (int)((long long)nm * ch / nchunk), e1 = (int)((long long)nm * (ch + 1) / nchunk);
     const float* mel = a.mel + (size_t)b * nm;
     const float* tgt = a.target_mel + (size_t)b * nm;
-    for (int e = tid; e < nm; e += nt) {
+    for (int e = e0 + tid; e < e1; e += nt) {
         const double m = (double)mel[e], d = m - (double)tgt[e];
         s[0] += d * d;
         if (a.cls_wb) s[5] += (double)a.cls_wb[e % a.M] * m;
     }
-    if (a.sem)
+    if (a.sem && ch == 0)
         for (int e = tid; e < a.S; e += nt) {
             const double d = (double)a.sem[(size_t)b * a.Sp + e] - (double)a.target_sem[(size_t)b * a.S + e];
             s[1] += d * d;
         }
     if (a.mel2) {
         const float* m2 = a.mel2 + (size_t)b * nm;
-        for (int e = tid; e < nm; e += nt) {
+        for (int e = e0 + tid; e < e1; e += nt) {
             const double d = (double)m2[e] - (double)tgt[e];
             s[6] += d * d;
         }
     }
-    if (a.sem2)
+    if (a.sem2 && ch == 0)
         for (int e = tid; e < a.S; e += nt) {
             const double d = (double)a.sem2[(size_t)b * a.Sp + e] - (double)a.target_sem[(size_t)b * a.S + e];
             s[7] += d * d;
@@ -255,11 +265,35 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a) {
     const double* x = a.x + (size_t)b * a.T * a.C;
     const size_t per = (size_t)a.T * a.C;
     double* dws = a.dwork + (size_t)b * 3 * per;     // [vel | jerk | ll] correlations of this utterance
-    s[2] = corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws);
-    s[3] = corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per);
-    s[4] = corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per);
+    const int tc = (a.T + nchunk - 1) / nchunk;   // frames per chunk
+    const int t0 = ch * tc, t1 = ch == nchunk - 1 ? a.T : (ch + 1) * tc;
+    s[2] = corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws, t0, t1);
+    s[3] = corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per, t0, t1);
+    s[4] = corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per, t0, t1);
     block_sum_n<8>(s, sh);
     if (tid == 0) {
+        double* pr = a.part + ((size_t)b * nchunk + ch) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pr[k] = s[k];
+    }
+}
+
+void launch_loss_reduce(hipStream_t stream, const LossArgs& a) {
+    const int nchunk = loss_chunks(a.T);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(a.B * nchunk), dim3(1024), 0, stream, a, nchunk);   // 16 waves per workgroup
+}
+
+// weighted sub-losses, as the reference logs them (paule/paule.py:654-662, :942-945)
+__global__ void loss_finalize_kernel(LossArgs a, int nchunk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    double* sc = a.scal + (size_t)b * 8;
+    {   // the chunks' partial sums, in order -> the utterance's scalars (read by the gradient kernels of this iteration)
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < nchunk; ++ch)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += a.part[((size_t)b * nchunk + ch) * 8 + k];
+        const int nm = a.Tp * a.M;
         sc[6] = a.mel2 ? sqrt(s[6] / nm) : 0.0;
         sc[7] = a.sem2 ? sqrt(s[7] / a.S) : 0.0;
         sc[0] = sqrt(s[0] / nm);
@@ -269,17 +303,6 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a) {
         sc[4] = s[4] / ((double)(a.T - 2) * a.C);
         sc[5] = a.cls_wb ? s[5] / a.Tp + (double)a.cls_wb[a.M] : 0.0;
     }
-}
-
-void launch_loss_reduce(hipStream_t stream, const LossArgs& a) {
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(a.B), dim3(1024), 0, stream, a);   // one workgroup per utterance, 16 waves
-}
-
-// weighted sub-losses, as the reference logs them (paule/paule.py:654-662, :942-945)
-__global__ void loss_finalize_kernel(LossArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
-    const double* sc = a.scal + (size_t)b * 8;
     const double mel = a.w_mel * sc[0], sem = a.sem ? a.w_sem * sc[1] : 0.0;
     const double vel = a.w_vel * sc[2], jerk = a.w_jerk * sc[3], ll = a.w_ll * sc[4];
     // BCEWithLogits(z, 0) = softplus(z) (paule/paule.py:610-612), numerically stable form
@@ -302,7 +325,7 @@ __global__ void loss_finalize_kernel(LossArgs a) {
 }
 
 void launch_loss_finalize(hipStream_t stream, const LossArgs& a) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(blocks_for(a.B, 64)), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(blocks_for(a.B, 64)), dim3(64), 0, stream, a, loss_chunks(a.T));
 }
 
 // d(w_sem * rmse_sem)/d sem = w_sem (sem - tgt) / (S * rmse).  rmse == 0 (exact match) would be 0/0 in the

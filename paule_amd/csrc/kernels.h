@@ -218,6 +218,7 @@ struct LossArgs {
     const float* sem2;
     const float* target_sem;         // [B][S]
     double* dwork;                   // [B][3][T][C] velocity / jerk / local-linear correlations (kept for the gradient)
+    double* part;                    // [B][loss_chunks(T)][8] partial sums of the reduction's workgroups (one per 256 CP frames of an utterance)
     double* scal;                    // per-utterance scalars [B][8]: 0 mel rmse, 1 sem rmse, 2 vel mse, 3 jerk mse, 4 ll mse, 5 classifier logit,
                                      // 6 tube-mel rmse, 7 tube-semvec rmse
     const float* cls_wb;             // speech classifier: [M] weights then bias, or null (term off)
@@ -226,6 +227,7 @@ struct LossArgs {
     const int* iter_slot;            // device counter: row of loss_rows written by this iteration
 };
 // per-utterance reductions (deterministic, no atomics) -> scal
+int loss_chunks(int T);   // workgroups per utterance of the loss reduction: a function of T only (an utterance's sums do not depend on its batch)
 void launch_loss_reduce(hipStream_t stream, const LossArgs& a);
 // writes loss_rows[*iter_slot][b][0..7]
 void launch_loss_finalize(hipStream_t stream, const LossArgs& a);

@@ -182,6 +182,7 @@ struct pl_handle {
     float w_cls = 0.1f;
     float* out_tmp = nullptr;   // [B][max(S, ...)] staging for unpadded outputs
     double* scal = nullptr;
+    double* loss_part = nullptr;   // [B][loss_chunks(T)][8]: partial sums of the loss reduction
     float* loss_rows = nullptr;
     int loss_cap = 0;
     int* counters = nullptr;    // [0] Adam step count, [1] loss row of the running iteration
@@ -1686,7 +1687,7 @@ LossArgs loss_args(pl_handle* h, bool with_sem) {
     a.mel2 = h->tube_on() ? h->mel2_bm : nullptr;
     a.sem2 = h->tube_on() ? h->sem2 : nullptr;
     a.target_sem = h->target_sem;
-    a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1; a.dwork = h->dwork;
+    a.scal = h->scal; a.loss_rows = h->loss_rows; a.iter_slot = h->counters + 1; a.dwork = h->dwork; a.part = h->loss_part;
     a.cls_wb = h->cls_on ? h->cls_wb : nullptr; a.w_cls = h->w_cls;
     return a;
 }
@@ -2061,6 +2062,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if ((rc = dev_alloc(h, &h->target_mel, B * Tp * h->M))) return bail(rc);
     if ((rc = dev_alloc(h, &h->cls_wb, h->M + 1))) return bail(rc);
     if ((rc = dev_alloc(h, &h->scal, B * 8))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->loss_part, B * (size_t)loss_chunks(T) * 8))) return bail(rc);
     if ((rc = dev_alloc(h, &h->loss_rows, (size_t)h->loss_cap * B * PL_LOSS_COLS))) return bail(rc);
     if ((rc = dev_alloc(h, &h->counters, 4))) return bail(rc);
     {
