@@ -265,12 +265,13 @@ int pl_debug_read(pl_handle *h, const char *name, float *out, int64_t max_elems,
 enum { PL_KERNEL_LSTM_FWD_STEP = 0, PL_KERNEL_LSTM_BWD_STEP = 1,
        /* persistent sweeps: one launch = all T steps of layer 0 (+ its ~5 us counter-zeroing launch); FLOPs = 2*B*4H*H*(T-1) */
        PL_KERNEL_LSTM_FWD_SWEEP = 2, PL_KERNEL_LSTM_BWD_SWEEP = 3,
-       /* the fused acoustic forward launch (predictor + mel head + embedder layers as roles of one grid; bf16, batches of 49+
-        * rows): one launch = all steps of all its layers (+ the flag-zeroing launch); FLOPs = 2 * B * sum over layers of
+       /* the fused acoustic forward launch (predictor + mel head + embedder layers as roles of one grid; bf16; batches of up to
+        * 48 rows on 16-row tiles, 49+ rows on 32-row tiles): one launch = all steps of all its layers (+ the flag-zeroing launch); FLOPs = 2 * B * sum over layers of
         * 4H (in + H) T_layer + 2 * B * H * mel_dim * T; PL_ERR_UNSUPPORTED when the handle does not use it; model_id ignored */
        PL_KERNEL_FUSED_FWD = 4,
        /* the fused acoustic backward launch (embedder recurrences top-down, their dL/dh products, backward mel head, predictor
-        * recurrence; bf16, batches of 49 ... 128 rows by default): FLOPs = 2 * B * (sum over layers of 4H * H * (T_layer - 1)
+        * recurrence; bf16; by default batches of up to 128 rows -- up to 48 on 16-row tiles -- and, for a stacked predictor of another
+        * width than the embedder, every batch its roles fit the chip): FLOPs = 2 * B * (sum over layers of 4H * H * (T_layer - 1)
         * + the products between the roles); PL_ERR_UNSUPPORTED when the handle does not use it; model_id ignored */
        PL_KERNEL_FUSED_BWD = 5 };
 int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg_ms_out /* host */,
