@@ -49,6 +49,9 @@
 #ifndef F16_DIRECT_STORE
 #define F16_DIRECT_STORE 1   // backward, same-XCD hand-off: partial tiles stored straight from the accumulator layout (8 bytes per lane)
 #endif
+// -DF16_NO_LOOKAHEAD (diagnostic builds only): the look-ahead on other roles' flags never answers "seen" -- every step's blocking wait
+// polls them, every write-through row is fetched behind it.  Used to rule the look-ahead out while the reproducibility bug of the
+// first backward role was bisected; same results, a little slower.
 #ifndef F16_PIPE
 #define F16_PIPE 0   // backward: 1 = the next group's MFMAs are issued before this group's epilogue
 #endif
