@@ -73,6 +73,8 @@ struct LstmSweepArgs {
     int bwd_waves;         // lstm_persist_rs.hip: waves per workgroup, 4 or 8 (0 = 8, the default; PAULE_HIP_BWD_WAVES)
     int* tflags;           // lstm_persist_rs.hip, streamed form: per-tile flags [2 slots][groups][P destinations][32] (zeroed with the
                            // counters); null = the whole-workgroup hand-off (one flag per workgroup and step)
+    int token_handoff;     // lstm_persist_rs.hip, token form (round 4): 1 = the tiles carry their own step token, no flags, no drains; xchg
+                           // is then a buffer ONLY this form uses (zero at the start of every launch: the kernel leaves it retired)
 };
 bool lstm_sweep_supported(int dt, int Hp);
 // workgroups to launch (multiple of Hp / 32, all co-resident on n_cu CUs); 0 = does not fit

@@ -207,9 +207,15 @@ struct pl_handle {
     bool debug_fused = false;   // PAULE_HIP_DEBUG_FUSED
     bool census_hooks = false;  // PAULE_HIP_CENSUS_EXPECT_EXTRA / PAULE_HIP_CENSUS_LATE_MS were set when the handle was created: the test
                                 // hooks of the residency census are then re-read at every fused launch (never otherwise)
-    bool bwd_stream = true;     // PAULE_HIP_BWD_STREAM: reduce-scatter backward sweep with per-tile flags and streamed ingest (lstm_persist_rs.hip)
+    int bwd_stream = 1;         // PAULE_HIP_BWD_STREAM: form of the 32-row reduce-scatter backward sweep's hand-off (lstm_persist_rs.hip): 2 the tiles
+                                // carry their own step token (round 4: no flags, no drains), 1 per-tile flags and streamed ingest (round 3), 0 one
+                                // whole-workgroup hand-off per step
     int bwd_waves = 8;          // PAULE_HIP_BWD_WAVES: waves per workgroup of the reduce-scatter backward sweep (4: one per SIMD, round 2's form)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
+    int bwd_dma = 0;              // PAULE_HIP_BWD_DMA (A/B): the streamed backward sweep fetches its stash rows a step ahead by LDS-DMA (bit-identical)
+    bool token_early = true;          // PAULE_HIP_TOKEN_EARLY (A/B): the token form loads first / second-round tiles during its own tile phase
+    void* sweep_xchg_tok = nullptr;   // ... of its token form, which nobody else may write: all zero ("retired") between launches
+    size_t sweep_xchg_tok_bytes = 0;
     bool f32_sweep = true;      // PAULE_HIP_F32_SWEEP: persistent sweeps on the f32 path
     int f32_chains = -1;        // PAULE_HIP_F32_CHAINS: f32 batches of more groups than fit the chip: -1 auto, 0 off (groups take turns / launch-per-step), N forced
     bool stash_lds = true;      // PAULE_HIP_STASH_LDS: forward stash stores staged through LDS (whole 64-byte row pieces)
@@ -417,7 +423,13 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
         LstmSweepArgs s8 = s;
         s8.bwd_waves = h->bwd_waves;
         // per-tile flags of the streamed hand-off: behind the XCD-id table of the same flag slice (zeroed with it)
-        s8.tflags = h->bwd_stream && s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T) ? s.xcc_tab + (size_t)((h->Bp + 7) / 8) * 64 : nullptr;
+        const bool whole = s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T);   // time chunks (wavefront, pipelines) keep the flag forms
+        s8.tflags = h->bwd_stream && whole ? s.xcc_tab + (size_t)((h->Bp + 7) / 8) * 64 : nullptr;
+        s8.stash_via_lds |= h->bwd_dma << 3;
+        if (h->bwd_stream == 2 && whole && h->sweep_xchg_tok && h->bwd_waves != 4 && s.xchg == h->sweep_xchg) {
+            s8.token_handoff = h->token_early ? 1 : 2;   // 2: diagnostic, no early tile loads (PAULE_HIP_TOKEN_EARLY=0)
+            s8.xchg = h->sweep_xchg_tok;
+        }
         launch_lstm_bwd_rs_sweep(st, Hp, grid, s8);
     }
     else
@@ -2075,7 +2087,12 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
-        if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
+#ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
+        if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;
+        if (const char* z = std::getenv("PAULE_HIP_TOKEN_EARLY")) h->token_early = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) < 0 ? 0 : (std::atoi(z) > 2 ? 2 : std::atoi(z));
+#endif
         if (const char* z = std::getenv("PAULE_HIP_TN_BF16")) h->tn_bf16 = std::atoi(z) != 0;
         h->debug_fused = std::getenv("PAULE_HIP_DEBUG_FUSED") != nullptr;
         h->census_hooks = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA") != nullptr || std::getenv("PAULE_HIP_CENSUS_LATE_MS") != nullptr;
@@ -2113,6 +2130,10 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
                     xb = xb > xe ? xb : xe;
                 }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
+            if (xb && h->bwd_stream == 2) {   // the token form's own exchange (raw_alloc zeroes it: every granule "retired")
+                if ((rc = raw_alloc(h, &h->sweep_xchg_tok, xb))) return bail(rc);
+                h->sweep_xchg_tok_bytes = xb;
+            }
         }
         if (const char* z = std::getenv("PAULE_HIP_F32_VALU")) h->f32_valu = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WF_PIPELINE")) h->wf_pipeline = std::atoi(z) != 0;
@@ -2386,11 +2407,14 @@ int pl_synchronize(pl_handle* h) {
     PL_HIP(hipStreamSynchronize(h->stream));
     if (st == 2) {   // the residency census of a fused launch: not all of its workgroups got a CU
         (void)hipMemsetAsync(h->sweep_status, 0, sizeof(int), h->stream);
+        if (h->sweep_xchg_tok) (void)hipMemsetAsync(h->sweep_xchg_tok, 0, h->sweep_xchg_tok_bytes, h->stream);   // the sweeps behind it gave up too
         return fail(PL_ERR_STATE, "fused LSTM launch: its workgroups were not all resident within the census bound -- something else holds "
                                   "CUs of this GPU (one process per GPU, see paule_hip.h); results of the last pl_step are invalid");
     }
     if (st != 0) {
         (void)hipMemsetAsync(h->sweep_status, 0, sizeof(int), h->stream);
+        // an abandoned token-form sweep leaves tiles behind that a later launch could take for its own: back to "retired"
+        if (h->sweep_xchg_tok) (void)hipMemsetAsync(h->sweep_xchg_tok, 0, h->sweep_xchg_tok_bytes, h->stream);
         return fail(PL_ERR_HIP, "persistent LSTM sweep: a bounded in-kernel wait timed out (workgroups of one batch group were not "
                                 "co-resident?); results of the last pl_step are invalid");
     }

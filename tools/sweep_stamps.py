@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PAULE_HIP_LIB"] = os.path.join(ROOT, "paule_amd", "csrc", "libpaule_hip_stamps.so")
+os.environ["PAULE_HIP_LIB"] = os.path.join(ROOT, "paule_amd", "csrc", os.environ.get("PL_STAMP_LIB", "libpaule_hip_stamps.so"))
 os.environ.setdefault("PL_STAMP_FILE", os.path.join(ROOT, "gpurun_out", "stamps"))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 import numpy as np  # noqa: E402
@@ -28,8 +28,12 @@ for d, name, steps, labels in (
          150 if OBJ != "acoustic" else 300,
          ["step top/prefetch", "wait arrivals", "h tile sc1 loads+LDS", "MFMA chain", "cell+store issue", "store drain", "barrier+add"]),
         (1, "backward sweep (pred model, 300 steps), mode " + os.environ.get("PAULE_HIP_BWD_MODE", "1"), 300,
-         ["step top/prefetch", "wait arrivals", "partial ingest", "cell+stash+dA image", "MFMA+partial image", "hand-off store issue",
-          "drain+barrier+add"] if os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1" else
+         (["stash loads issued", "tile loads issued + landed", "sums", "cell+stash+dA image+barrier", "tiles", "token checks", "-", "stash loads landed (diagnostic wait)"]
+          if "stamps2" in os.environ.get("PL_STAMP_LIB", "") else
+          ["step top/stash loads", "tile loads + token checks", "sums", "cell+stash+dA image+barrier", "tiles", "SWEEPS per step (count)",
+           "TILE LOADS per step (count)"] if os.environ.get("PAULE_HIP_BWD_STREAM", "2") == "2" else
+          ["step top/prefetch", "wait arrivals", "partial ingest", "cell+stash+dA image", "MFMA+partial image", "hand-off store issue",
+           "drain+barrier+add"]) if os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1" else
          ["step top/prefetch", "wait arrivals", "dA loads+LDS+MFMA", "partial reduce", "cell+store issue", "store drain", "barrier+add"])):
     blk = raw[d]
     used = blk[blk.sum(axis=1) > 0]
