@@ -644,7 +644,11 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             // nt >> 1's [16][32] tile.  NO run-time branch anywhere between a tile's MFMAs and the reads of its accumulators: a wave's
             // surplus tile (46 tiles over 4 waves: the twelfth of waves 2 and 3) is computed like the others (its weight rows are
             // tile 0's) and only its store is dropped through the buffer range check.  With a branch around it the tile BEFORE it came
-            // out with a stale accumulator register in one run of four (the plan was not reproducible run to run)
+            // out with a stale accumulator register in one run of four (the plan was not reproducible run to run).  The cause,
+            // from the ISA (profiles/r04_isa_stale_accumulator.txt): hipcc put the conditional branch directly behind the previous tile's last
+            // MFMA and its target opened with the v_accvgpr_read of that MFMA's result -- one wait state on the taken path where gfx950 needs
+            // eight (the compiler pads only what it sees in straight-line code).  tools/isa_mfma_hazard_scan.py checks every kernel for it
+            // (tests/test_isa_hazards.py)
             constexpr int TG = F16_TG, NGRP = (NT + TG - 1) / TG;
             f32x4 accg[2][TG];
             auto tiles_mfma = [&](int grp, f32x4 (&acc)[TG]) {

@@ -414,6 +414,8 @@ __global__ __launch_bounds__(256, PL16_OCC) void lstm_bwd16_rs_sweep_kernel(Lstm
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
                 if (4 * i + 3 >= NTT && nt >= NTT) break;   // a compile-time fact for all but a wave's last tile
+                // (the break sits IN FRONT of a tile's MFMAs, behind the previous tile's epilogue: no MFMA result is read across it --
+                // tools/isa_mfma_hazard_scan.py, profiles/r04_isa_stale_accumulator.txt)
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc)

@@ -165,6 +165,8 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_bwd_rs_sweep_kernel(LstmSweep
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + NW * i;
                 if (NW * i + NW - 1 >= P && nt >= P) break;   // a compile-time fact for all but a wave's last tile
+                // (the break sits IN FRONT of a tile's MFMAs, behind the previous tile's epilogue: no MFMA result is read across it --
+                // tools/isa_mfma_hazard_scan.py, profiles/r04_isa_stale_accumulator.txt)
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -489,6 +491,8 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
             for (int i = 0; i < NT; ++i) {
                 const int k = wave + NW * i;
                 if (NW * i + NW - 1 >= P && k >= P) break;   // a compile-time fact for all but a wave's last tile
+                // (the break sits IN FRONT of a tile's MFMAs, behind the previous tile's epilogue: no MFMA result is read across it --
+                // tools/isa_mfma_hazard_scan.py, profiles/r04_isa_stale_accumulator.txt)
                 const int nt = (p + 1 + k) % P;
                 f32x16 acc;
 #pragma unroll

@@ -1,0 +1,74 @@
+"""CPU: the gfx950 device code of the kernels that branch near MFMA sequences holds no MFMA result that is read too early on any
+control-flow path (tools/isa_mfma_hazard_scan.py; the cause of round 3's stale-accumulator bug, profiles/r04_isa_stale_accumulator.txt)."""
+import importlib.util
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(ROOT, "tools", "isa_mfma_hazard_scan.py"))
+isa_scan = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(isa_scan)
+
+# the shape of the bug as hipcc compiled it at 81e779f^: an MFMA directly in front of a conditional branch whose target reads its result
+BUGGY = """
+_Z5buggyv:
+	v_mfma_f32_16x16x32_bf16 a[8:11], v[158:161], v[210:213], a[8:11]
+	s_and_b64 vcc, exec, s[20:21]
+	v_mfma_f32_16x16x32_bf16 a[12:15], v[174:177], v[210:213], a[12:15]
+	s_cbranch_vccnz .LBB0_2
+; %bb.1:
+	v_accvgpr_read_b32 v2, a56
+	v_accvgpr_read_b32 v3, a57
+	v_accvgpr_read_b32 v4, a58
+	v_accvgpr_read_b32 v5, a59
+	s_nop 1
+	v_mfma_f32_16x16x32_bf16 a[0:3], v[2:5], v[210:213], a[4:7]
+.LBB0_2:
+	v_accvgpr_read_b32 v2, a15
+	v_accvgpr_read_b32 v3, a14
+	s_endpgm
+.Lfunc_end0:
+"""
+FIXED = BUGGY.replace(".LBB0_2:\n", ".LBB0_2:\n\ts_nop 7\n")
+
+
+def _scan_text(text, tmp_path, name):
+    p = tmp_path / name
+    p.write_text(text)
+    out = []
+    for fn, lines in isa_scan.functions(str(p)):
+        res, _ = isa_scan.scan_function(fn, lines)
+        out += res
+    return out
+
+
+def test_scanner_finds_the_branch_hazard_and_accepts_the_padded_form(tmp_path):
+    bad = _scan_text(BUGGY, tmp_path, "buggy.s")
+    assert any("a15" in f[4] and f[5].startswith("1 wait") for f in bad), bad
+    assert _scan_text(FIXED, tmp_path, "fixed.s") == []
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_shipped_kernels_have_no_mfma_read_hazard(tmp_path):
+    files = ["lstm_fused.hip", "lstm_persist_rs.hip", "lstm_persist16.hip", "lstm_persist.hip"]   # the kernels with wave-dependent branches next to MFMA sequences
+
+    def build(f):
+        out = str(tmp_path / (f[:-4] + ".s"))
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-w", "-S", "--cuda-device-only", "-o", out,
+                               os.path.join(ROOT, "paule_amd", "csrc", f)])
+        return out
+
+    with ThreadPoolExecutor(4) as ex:
+        outs = list(ex.map(build, files))
+    findings, n_mfma = [], 0
+    for o in outs:
+        for fn, lines in isa_scan.functions(o):
+            res, cnt = isa_scan.scan_function(fn, lines)
+            findings += res
+            n_mfma += cnt
+    assert n_mfma > 3000, n_mfma   # the scan really saw the kernels
+    assert findings == [], findings[:3]
