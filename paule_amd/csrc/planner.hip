@@ -211,6 +211,7 @@ struct pl_handle {
                                 // carry their own step token (round 4: no flags, no drains), 1 per-tile flags and streamed ingest (round 3), 0 one
                                 // whole-workgroup hand-off per step
     int bwd_waves = 8;          // PAULE_HIP_BWD_WAVES: waves per workgroup of the reduce-scatter backward sweep (4: one per SIMD, round 2's form)
+    int n_layer_slots_zeroed = 0;   // per-layer flag slices zeroed at the top of the running iteration (take_sweep_slice hands out no other)
     void* sweep_xchg = nullptr; // exchange buffer of the reduce-scatter backward sweep
     int bwd_dma = 0;              // PAULE_HIP_BWD_DMA (A/B): the streamed backward sweep fetches its stash rows a step ahead by LDS-DMA (bit-identical)
     bool token_early = true;          // PAULE_HIP_TOKEN_EARLY (A/B): the token form loads first / second-round tiles during its own tile phase
@@ -352,7 +353,10 @@ inline char* off(void* p, size_t elems, size_t esz) { return static_cast<char*>(
 // out in turn; elsewhere (forward-only calls, training, timing) slice 0 is zeroed right before the sweep
 int* take_sweep_slice(pl_handle* h, hipStream_t st) {
     const size_t ints = h->sweep_cnt_bytes / sizeof(int);
-    if (h->sweep_slot >= 0 && h->sweep_slot < h->n_sweep_slots) return h->sweep_cnt + (size_t)(h->sweep_slot++) * ints;
+    // only slices that zero_all_sweep_slots zeroed at the top of this iteration AND that no fused role owns are handed out (a
+    // stale non-zero flag makes every in-kernel wait fall through); beyond them slice 0 is zeroed on the spot, as outside an iteration
+    if (h->sweep_slot >= 0 && h->sweep_slot < h->n_layer_slots_zeroed) return h->sweep_cnt + (size_t)(h->sweep_slot++) * ints;
+    if (h->sweep_slot >= 0) h->sweep_slot = h->n_sweep_slots;   // (stays past the bound for the rest of the iteration)
     if (h->zero_mode == 1)
         (void)hipMemsetAsync(h->sweep_cnt, 0, h->sweep_cnt_bytes, st);
     else
@@ -362,10 +366,11 @@ int* take_sweep_slice(pl_handle* h, hipStream_t st) {
 void zero_all_sweep_slots(pl_handle* h, hipStream_t st) {
     // the per-layer slices come first, then the flag slices of the fused forward launch's roles, then the fused backward launch's:
     // only what this handle's plan hands out is zeroed (a handle without fused launches does not pay for their slices: ADVICE r2)
-    int n_used = h->n_sweep_slots;
+    int n_used = h->n_sweep_slots, n_layer = h->n_sweep_slots;
     if (h->cfg.emb_layers > 0) {
         const int n_roles = (2 * h->cfg.pred_layers - 1) + 1 + (2 * h->cfg.emb_layers - 1), n_fused = 2 * n_roles + (h->cfg.emb_layers - 1) + (h->cfg.pred_layers - 1);
         n_used = h->n_sweep_slots - n_fused;
+        n_layer = n_used;
         if (h->fused_bwd_ok) n_used = h->n_sweep_slots;
         else if (h->fused_fwd_ok) n_used += n_roles;
     }
@@ -374,6 +379,7 @@ void zero_all_sweep_slots(pl_handle* h, hipStream_t st) {
         (void)hipMemsetAsync(h->sweep_cnt, 0, ints * sizeof(int), st);
     else
         launch_zero_counters(st, h->sweep_cnt, (int)ints);
+    h->n_layer_slots_zeroed = n_layer;   // the per-layer slices come first; what follows belongs to the fused launches' roles
     h->sweep_slot = 0;
 }
 
@@ -646,7 +652,7 @@ int acoustic_pipeline_chunks(pl_handle* h) {
     if (e.L < 1 || p.L + e.L > 8 || h->emb_blocks > 0 || !p.layers[0].carry_f || !e.layers[0].carry_f) return 0;
     const int pp = pipe_per_xcd(h, p), pe = pipe_per_xcd(h, e);
     if (pp == 0 || pe == 0 || p.L * pp + e.L * pe > h->n_cu / 8) return 0;
-    if (h->sweep_slot != 0 || 2 * (p.L + e.L) > h->n_sweep_slots) return 0;
+    if (h->sweep_slot != 0 || 2 * (p.L + e.L) > h->n_layer_slots_zeroed) return 0;
     int nc = h->wavefront < 32 ? h->wavefront : 32;
     if (nc > h->Tp / 4) nc = h->Tp / 4;
     return nc >= 2 ? nc : 0;
@@ -655,7 +661,7 @@ int acoustic_pipeline_chunks(pl_handle* h) {
 int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb) {
     if (h->wavefront <= 0 || h->sweep_slot < 0 || train_nb > 0 || !md.layers[0].carry_f) return 0;
     if (wavefront_depth(h, md) < 2) return 0;
-    if (h->sweep_slot + md.L > h->n_sweep_slots) return 0;
+    if (h->sweep_slot + md.L > h->n_layer_slots_zeroed) return 0;
     int nc = h->wavefront < 32 ? h->wavefront : 32;
     if (nc > Tl / 4) nc = Tl / 4;
     return nc >= 2 ? nc : 0;
@@ -1175,7 +1181,7 @@ int tube_pipeline_chunks(pl_handle* h) {
         per += md->L * px;
     }
     if (per > h->n_cu / 8) return 0;
-    if (h->sweep_slot + u.L + m.L + e.L > h->n_sweep_slots) return 0;
+    if (h->sweep_slot + u.L + m.L + e.L > h->n_layer_slots_zeroed) return 0;
     int nc = h->wavefront < 32 ? h->wavefront : 32;
     if (nc > h->Tp / 4) nc = h->Tp / 4;
     return nc >= 2 ? nc : 0;
@@ -2874,7 +2880,8 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         *avg_ms_out = ms / reps;
         if (flops_per_launch_out) {   // backward-data recurrences of all layers, the dL/dh products between the embedder's layers, the
             const double Hh = h->pred.H, He = h->emb.H;   // embedder's input gradient (-> mel) and the backward mel head
-            double f = 2.0 * 4 * Hh * Hh * (h->T - 1) + 2.0 * Hh * h->M * h->Tp;
+            // predictor: every layer's recurrence and, for a stacked one, the dL/dh product between two layers (one layer was counted)
+            double f = h->pred.L * 2.0 * 4 * Hh * Hh * (h->T - 1) + (h->pred.L - 1) * 2.0 * 4 * Hh * Hh * h->T + 2.0 * Hh * h->M * h->Tp;
             f += h->emb.L * 2.0 * 4 * He * He * (h->Tp - 1) + (h->emb.L - 1) * 2.0 * 4 * He * He * h->Tp + 2.0 * 4 * He * h->M * h->Tp;
             *flops_per_launch_out = (double)h->B * f;
         }

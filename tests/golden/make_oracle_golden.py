@@ -18,7 +18,12 @@ import numpy as np  # noqa: E402
 import oracle_golden as og  # noqa: E402
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(og.CASES)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    names = args or ([] if "--record-sources" in sys.argv else list(og.CASES))
+    if not args:   # all cases (or --record-sources alone, when the oracle's text changed but not its arithmetic): the fixtures belong to today's oracle code
+        with open(og.SOURCES_RECORD, "w") as fh:
+            fh.write(og.oracle_sources_sha1() + "  oracle/" + ",".join(og.ORACLE_FILES) + "\n")
+        print("recorded", og.SOURCES_RECORD)
     for name in names:
         t0 = time.time()
         out = og.compute(name)

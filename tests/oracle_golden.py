@@ -9,9 +9,12 @@ the repo's code) and nothing here is on the product path.
 
 Safety against stale fixtures.  A fixture stores the SHA-1 of its inputs (the rows of the synthetic workload it was computed for and
 a fingerprint of the weights): ``get()`` regenerates the workload, compares the digest and refuses a fixture that does not belong to
-today's generator.  ``tests/test_oracle.py::test_oracle_golden_is_what_the_oracle_computes`` recomputes one case on the CPU and
-compares it with the committed file; ``::test_oracle_golden_fixtures_match_their_workloads`` checks every digest.  A missing
-fixture is computed on the spot (slow, never wrong).
+today's generator.  ``tests/test_oracle.py::test_oracle_golden_is_what_the_oracle_computes`` recomputes two cases on the CPU and
+compares them with the committed files, ``::test_oracle_golden_emulation_is_what_the_emulation_computes`` does so for the rounding
+emulation's arrays of cfg3; ``::test_oracle_golden_fixtures_match_their_workloads`` checks every digest; and
+``::test_oracle_sources_are_the_ones_the_fixtures_were_computed_with`` compares a hash of oracle/*.py with the one recorded when the
+fixtures were made (the input digest does not see a change of the oracle's CODE).  A missing fixture is computed on the
+spot (slow, never wrong).
 """
 from __future__ import annotations
 
@@ -102,18 +105,49 @@ def compute(name, wl=None):
             out["g_model"] = (orc.last_grad.numpy() - mo.smoothness_loss_grad(wl.cp0[rows].numpy())[3]).astype(np.float32)
     out["loss"] = np.concatenate(losses, axis=0)          # [iters, rows, columns]
     out["cp_after"] = np.stack(cps)                        # [iters, rows, T, 30]
-    if c.get("emul"):
-        from oracle import bf16_emul as be
-        em = be.EmulPlanner(wl.pred_sd, wl.emb_sd, objective=c["objective"])
-        em.set_targets(wl.target_mel[rows].numpy(), wl.target_semvec[rows].numpy())
-        em.set_cp(wl.cp0[rows].numpy())
-        _, _, pe = be.loss_and_grad(em.models, c["objective"], em.x, em.target_mel, em.target_semvec)
-        if c["emul"] is True:
-            out["emul_pred_h0_bits"] = bf16_bits(pe["pred_h"][0])   # [rows, T, H] bf16 patterns of the predictor's h stash
-        out["emul_dX"] = np.asarray(pe["dX"], dtype=np.float32)
+    out.update(compute_emul(name, wl))
     out["digest"] = np.array(_digest(c, wl))
     out["rows"] = np.array(rows)
     return out
+
+
+def compute_emul(name, wl=None):
+    """The rounding emulation's part of a case (oracle/bf16_emul.py: the emul_* arrays), on its own: cheap enough to be recomputed on
+    the CPU in tests/test_oracle.py, so that a change of the emulation cannot leave a stale fixture behind."""
+    c = CASES[name]
+    out = {}
+    if not c.get("emul"):
+        return out
+    from oracle import bf16_emul as be
+    wl = wl or workload(name)
+    rows = c["rows"]
+    em = be.EmulPlanner(wl.pred_sd, wl.emb_sd, objective=c["objective"])
+    em.set_targets(wl.target_mel[rows].numpy(), wl.target_semvec[rows].numpy())
+    em.set_cp(wl.cp0[rows].numpy())
+    _, _, pe = be.loss_and_grad(em.models, c["objective"], em.x, em.target_mel, em.target_semvec)
+    if c["emul"] is True:
+        out["emul_pred_h0_bits"] = bf16_bits(pe["pred_h"][0])   # [rows, T, H] bf16 patterns of the predictor's h stash
+    out["emul_dX"] = np.asarray(pe["dX"], dtype=np.float32)
+    return out
+
+
+ORACLE_FILES = ("planner.py", "manual.py", "bf16_emul.py")
+
+
+def oracle_sources_sha1():
+    """SHA-1 over the oracle's source files (line endings and trailing blanks normalised).  tests/golden/oracle_sources.sha1 records the
+    value the committed fixtures were computed with: a change of the oracle's code fails tests/test_oracle.py until the fixtures are
+    regenerated (python tests/golden/make_oracle_golden.py, which rewrites the record)."""
+    h = hashlib.sha1()
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    for f in ORACLE_FILES:
+        with open(os.path.join(root, f), "rb") as fh:
+            for line in fh.read().decode().splitlines():
+                h.update(line.rstrip().encode() + b"\n")
+    return h.hexdigest()
+
+
+SOURCES_RECORD = os.path.join(GOLDEN_DIR, "oracle_sources.sha1")
 
 
 def get(name):

@@ -283,3 +283,23 @@ def test_oracle_golden_is_what_the_oracle_computes(name):
     assert str(got["digest"]) == str(want["digest"])
     np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(got["cp_after"], want["cp_after"], rtol=0, atol=2e-7)
+
+
+def test_oracle_golden_emulation_is_what_the_emulation_computes():
+    """The emul_* arrays of the cfg3 fixture (the rounding emulation's predictor h stash and dL/dCP for utterances 0 and 255 of the
+    headline batch) recomputed here from oracle/bf16_emul.py: a change of the emulation cannot leave them stale."""
+    import oracle_golden as og
+    want = dict(np.load(og.path("cfg3_rows")))
+    got = og.compute_emul("cfg3_rows")
+    np.testing.assert_array_equal(got["emul_pred_h0_bits"], want["emul_pred_h0_bits"])
+    np.testing.assert_allclose(got["emul_dX"], want["emul_dX"], rtol=1e-6, atol=1e-12)
+
+
+def test_oracle_sources_are_the_ones_the_fixtures_were_computed_with():
+    """tests/golden/oracle_sources.sha1 = hash of oracle/{planner,manual,bf16_emul}.py when the oracle_*.npz fixtures were computed.
+    The fixtures' own digests cover their INPUTS only; this covers the code: after a change of the oracle regenerate the fixtures
+    (python tests/golden/make_oracle_golden.py rewrites the record) -- only cfg2 / cfg4 / the cfg3 emulation are recomputed per test run."""
+    import oracle_golden as og
+    assert os.path.exists(og.SOURCES_RECORD), "python tests/golden/make_oracle_golden.py --record-sources"
+    assert open(og.SOURCES_RECORD).read().split()[0] == og.oracle_sources_sha1(), (
+        "oracle/*.py changed since tests/golden/oracle_*.npz were computed: regenerate them with python tests/golden/make_oracle_golden.py")

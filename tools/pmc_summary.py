@@ -8,8 +8,17 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
+
+
+def is_kernel(recorded, kname):
+    """EXACT function name (a substring match made fused_bwd_kernel also collect fused_bwd_kernel2): the name as a whole
+    identifier in a demangled signature, or as a length-prefixed component of a mangled one."""
+    if recorded.startswith("_Z"):
+        return re.search(r"%d%s(?=[IE])" % (len(kname), re.escape(kname)), recorded) is not None
+    return re.search(r"(?<![A-Za-z0-9_])%s(?![A-Za-z0-9_])" % re.escape(kname), recorded) is not None
 
 
 def per_kernel(dirname, counter):
@@ -36,8 +45,8 @@ def main():
                        ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
                        ("lstm_bwd_step_kernel", "lstm_bwd_step_kernel"), ("lstm_fwd_step_kernel", "lstm_fwd_step_kernel"),
                        ("gemm_nt_kernel", "gemm_nt_kernel")):
-        fv = [v for k, vs in fetch.items() if kname in k for v in vs]
-        wv = [v for k, vs in write.items() if kname in k for v in vs]
+        fv = [v for k, vs in fetch.items() if is_kernel(k, kname) for v in vs]
+        wv = [v for k, vs in write.items() if is_kernel(k, kname) for v in vs]
         if not fv and not wv:
             continue
         # the predictive model's sweep (T = 300) is the longest launch of its kind: take the upper half by value
