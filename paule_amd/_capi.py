@@ -58,7 +58,13 @@ _lib = None
 
 
 def load_library(path: str | None = None):
-    """Loads libpaule_hip.so once and declares the prototypes.  Raises HipLibraryError if absent."""
+    """Loads libpaule_hip.so once and declares the prototypes.  Raises HipLibraryError if absent.
+
+    libpaule_hip.so is a LOADER (csrc/shim.cpp): it links no HIP runtime.  On the first pl_* call that needs the kernels it binds
+    libpaule_hip_core.so to the HIP runtime the process already has (PyTorch's, if torch was imported -- in whatever order) or, when there
+    is none, to /opt/rocm's.  So nothing here depends on import order any more; loading the library and asking
+    pl_version() touch no runtime at all.  PAULE_HIP_LIB = another build of the CORE (diagnostic builds: libpaule_hip_stamps.so, an A/B
+    build) or another directory's libpaule_hip.so."""
     global _lib
     if _lib is not None and path is None:
         return _lib
@@ -67,13 +73,15 @@ def load_library(path: str | None = None):
         raise HipLibraryError(
             f"{p} not found: build it with `make -C paule_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
             "g.build()'`).  paule_amd has no CPU fallback.")
-    # torch FIRST: its wheel ships its own HIP runtime, and whichever copy of libamdhip64 a process loads first is the one that
-    # initialises the device.  With this library (linked against /opt/rocm's) loaded before torch, pl_create found "no ROCm-capable
-    # device" on the GPU box (seen with build() and smoke() in ONE process: build() loads the library, smoke() then imported torch)
-    import torch  # noqa: F401
+    if os.path.basename(p) != "libpaule_hip.so":   # a core variant: the shipped loader with that core
+        os.environ["PAULE_HIP_CORE"] = os.path.abspath(p)
+        p = LIB_PATH
+    core = os.environ.get("PAULE_HIP_CORE", os.path.join(os.path.dirname(os.path.abspath(p)), "libpaule_hip_core.so"))
+    if not os.path.exists(p) or not os.path.exists(core):
+        raise HipLibraryError(f"{p if not os.path.exists(p) else core} not found: build it with `make -C paule_amd/csrc`.  paule_amd has no CPU fallback.")
     try:
         lib = C.CDLL(p)
-    except OSError as e:  # missing libamdhip64 etc.
+    except OSError as e:
         raise HipLibraryError(f"cannot load {p}: {e}") from e
 
     vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as raw addresses
