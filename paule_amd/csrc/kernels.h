@@ -159,6 +159,8 @@ struct FusedRole {
 };
 struct FusedArgs {
     int Bp, B, n_groups, flag_stride, n_roles, grid;
+    int gpp;                  // forward launch, batches of more groups than one chip-load (round 4): groups per PASS -- a role's set s serves the groups of sets
+                              // s, s + gpp / C, s + 2 gpp / C, ... one after the other (gpp is a multiple of every role's C); 0: all groups at once
     int* status;
     unsigned long long spin_ticks;
     unsigned poll_mask;

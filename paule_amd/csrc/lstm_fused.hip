@@ -1218,11 +1218,22 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
     if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
     __syncthreads();
     const FusedRole R = uniform_role(a.roles[role]);
-    if constexpr (KSP == KSE) {
-        fused_fwd_role<KSE>(a, R, set, p, lds);
-    } else {
-        if (R.wide) fused_fwd_role<KSE>(a, R, set, p, lds);
-        else fused_fwd_role<KSP>(a, R, set, p, lds);
+    // Batches of more groups than the roles hold at once (round 4: cfg4's 2048 rows on one GPU are 64 groups) are taken in PASSES: the role
+    // table is the one of a chip-load of a.gpp groups, and a workgroup walks its role over the sets s, s + gpp / C, s + 2 gpp / C, ... --
+    // every role function starts from scratch (weights, cell state at t = 0), flags and stashes are indexed by the absolute group, so a
+    // pass is exactly the launch a batch of those groups alone would run (tests: test_full_size_cfg4_one_gpu..., bit-equal rows).  Roles
+    // drift apart by passes as they please: a wait is per (group, step) and every role walks the passes in the same order.
+    const int set_step = a.gpp > 0 ? uni(a.gpp / R.C) : 0;
+    for (int s2 = set;; s2 += set_step) {
+        if constexpr (KSP == KSE) {
+            fused_fwd_role<KSE>(a, R, s2, p, lds);
+        } else {
+            if (R.wide) fused_fwd_role<KSE>(a, R, s2, p, lds);
+            else fused_fwd_role<KSP>(a, R, s2, p, lds);
+        }
+        if (set_step <= 0 || (s2 + set_step) * R.C >= a.n_groups) break;
+        __syncthreads();   // nobody starts the next pass's LDS images while a wave still reads this one's
+        if (uni(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;   // a wait gave up: everybody leaves
     }
 }
 

