@@ -49,6 +49,16 @@ __device__ __forceinline__ void flag_store(int* ptr, int v) {
     __hip_atomic_store((PL_GLOBAL int*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// flags that stay inside ONE XCD (a role's own exchange once its workgroups have verified that they share one): stored plainly, they
+// sit in that XCD's L2; polled with nt loads (bypass only the polling CU's L1) they are answered by that L2 instead of the memory side
+__device__ __forceinline__ int flag_load_nt(const int* ptr) {
+    asm volatile("" ::: "memory");   // a poll loop must issue the load every time round
+    return __builtin_nontemporal_load((const PL_GLOBAL int*)ptr);
+}
+__device__ __forceinline__ void flag_store_plain(int* ptr, int v) {   // a buffer store without cache-policy bits (a volatile store would be written through)
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, make_rsrc(ptr, 4u), 0u, 0, 0);
+}
+
 // what one chain-step waits for, resolved to addresses: lanes 0 .. na-1 read fa[lane], lanes 32 .. 32+nb-1 read fb[lane - 32],
 // lane 63 reads fc
 struct FlagPoll {
@@ -57,11 +67,12 @@ struct FlagPoll {
     const int* fb;
     int nb;
     const int* fc;
+    int fa_nt;   // 1: fa is a same-XCD (plain) flag set: nt loads
 };
 
 __device__ __forceinline__ int poll_load(const FlagPoll& s, int lane) {
     int v = 1;
-    if (lane < s.na) v = flag_load(s.fa + lane);
+    if (lane < s.na) v = s.fa_nt ? flag_load_nt(s.fa + lane) : flag_load(s.fa + lane);
     else if (lane >= 32 && lane - 32 < s.nb) v = flag_load(s.fb + (lane - 32));
     else if (lane == 63 && s.fc) v = flag_load(s.fc);
     return v;

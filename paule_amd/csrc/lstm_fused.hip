@@ -593,12 +593,27 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc_uniform, unsigned la
         : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst_uniform)
         : "memory");
 }
+// the same through the XCD's own L2 (nt: bypasses only this CU's L1): for tiles that workgroups of the SAME XCD stored plainly
+__device__ __forceinline__ void glds16_nt(const void* gsrc_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst_uniform)
+        : "memory");
+}
 typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
 // one partial tile: 8 k-steps over the workgroup's 128 local gate rows; acc[r] = out[n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31]
 // -> bf16 image [batch][n], read back by rows by the same wave (a wave's LDS operations are ordered) and stored as 2 KB
+// plain = true (a scalar): the tile is stored without write-through -- only for a role's OWN exchange once its workgroups have verified
+// that they share one XCD (fused_lstm_bwd); everything another role may read stays sc1
 __device__ __forceinline__ void partial_tile(const uint4 (&w)[8], const uint4 (&bfr)[8], unsigned char* img_row0, int rs, int col0,
-                                             __amdgpu_buffer_rsrc_t ro, unsigned tile_off, int lane) {
+                                             __amdgpu_buffer_rsrc_t ro, unsigned tile_off, int lane, bool plain = false) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -613,7 +628,13 @@ __device__ __forceinline__ void partial_tile(const uint4 (&w)[8], const uint4 (&
     for (int q = 0; q < 2; ++q) {
         const int cidx = lane + 64 * q, r = cidx >> 2, c4 = cidx & 3;
         const uint4 v = *reinterpret_cast<const uint4*>(img_row0 + r * rs + (col0 + 8 * c4) * 2);
-        st16_sc1_so(ro, (unsigned)(cidx * 16), tile_off, v);
+        if (plain) {
+            u32x4 d;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            __builtin_amdgcn_raw_buffer_store_b128(d, ro, (unsigned)(cidx * 16), tile_off, 0);
+        } else {
+            st16_sc1_so(ro, (unsigned)(cidx * 16), tile_off, v);
+        }
     }
 }
 
@@ -677,6 +698,20 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
     const bool src_sc1 = R.src_sc1 != 0, dA_sc1 = R.dA_sc1 != 0;
     const int dh_ext_half = R.dh_ext_half, dh_ext_rows = R.dh_ext_rows;
 
+    // The role's OWN exchange through the shared L2 once its P workgroups have found themselves on one XCD (round 4; the verified
+    // same-XCD form of sweep_common.h, data path only).  Written through, the tiles drop out of the XCD's L2 and every consumer's
+    // LDS-DMA re-reads them from the memory side: 27.9 GB fetched per launch at 128 x 2000 frames against 8 GB of algorithmic
+    // reads (profiles/r03_pmc_summary_cfg5_128.txt).  Plain stores keep the lines in the L2 the consumers read through (nt).
+    // The flags stay write-through: other roles poll them too, and a tile is acknowledged by that L2 before its flag is even
+    // stored.  Placement is never assumed: every workgroup publishes its XCD with its first hand-off (drained with it), the members
+    // compare after their first completed wait on each other, and only a set that is whole on one XCD switches -- for good.
+    // Same tiles, same order of every sum: bit-identical to the write-through form.
+    // The flags of the own exchange follow (a second, PLAIN set beside the write-through one, polled nt): other roles keep polling the
+    // write-through set, which every hand-off raises as before.  The members switch at the same chain-step (c = 0, t = T - 2), so the
+    // plain set holds the flags of steps <= T - 2 and a wait for step T - 1 stays on the write-through set.
+    int* const xtab = R.xtab ? R.xtab + set * 64 : nullptr;
+    const long fdelta = (R.fast_flags && R.xtab) ? (long)(R.fast_flags - R.flags) : 0;
+    bool fast = false;
     unsigned char* tst = lds + L::O_TST + wave * 32 * TRS;   // this wave's outgoing tile
     const unsigned xr_lds = (unsigned)(uintptr_t)(lds_ptr_t)xr_img, xe_lds = (unsigned)(uintptr_t)(lds_ptr_t)xe_img;
     // operands of the NEXT chain-step: the stash rows in registers, the partial tiles by LDS-DMA (held in registers across the
@@ -708,10 +743,18 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
         constexpr int NPC = P * 2;   // 1-KB pieces of a destination's P tiles (contiguous in the exchange)
         if (t2 + 1 < T) {   // the P partial tiles of step t2 + 1 that belong to this workgroup's cells
             const unsigned char* xs = reinterpret_cast<const unsigned char*>(X + (size_t)((t2 + 1) & 1) * slot_stride + (size_t)g2 * grp_stride + (size_t)p * P * TILE);
+            if (fast) {
 #pragma unroll
-            for (int k = 0; k < (NPC + 3) / 4; ++k) {
-                const int pc = wave + 4 * k;
-                if (pc < NPC) glds16_sc1(uni(xs + pc * 1024), (unsigned)(lane * 16), (unsigned)uni((int)(xr_lds + (unsigned)(pc * 1024))));
+                for (int k = 0; k < (NPC + 3) / 4; ++k) {
+                    const int pc = wave + 4 * k;
+                    if (pc < NPC) glds16_nt(uni(xs + pc * 1024), (unsigned)(lane * 16), (unsigned)uni((int)(xr_lds + (unsigned)(pc * 1024))));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (NPC + 3) / 4; ++k) {
+                    const int pc = wave + 4 * k;
+                    if (pc < NPC) glds16_sc1(uni(xs + pc * 1024), (unsigned)(lane * 16), (unsigned)uni((int)(xr_lds + (unsigned)(pc * 1024))));
+                }
             }
         }
         if constexpr (EXT) {   // ... and the P partial tiles of dL/dh_t2 from the layer above
@@ -744,6 +787,7 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
         // together and in order, so a poll issued behind hand-off stores would only be answered after their write-through round trips
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr};
         if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        if (fast && fdelta != 0 && has_next && tn + 1 <= T - 2 && pn.na > 0) { pn.fa += fdelta; pn.fa_nt = 1; }   // own flags of step tn + 1, plain set
         // A. dL/dh_t of this thread's cells: from above + the partial sums (fixed order).  Every wave's DMA pieces have landed:
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -819,7 +863,16 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
             *reinterpret_cast<uint2*>(drow + 128) = pg;
             *reinterpret_cast<uint2*>(drow + 192) = po;
         }
+        const bool xcd_look = xtab && c == 0 && t == T - 2;   // the wait of this chain-step saw every member's first flag: their ids are in place
+        if (xcd_look && wave == 1) {
+            const int mine = xcc_id_plus1();
+            int v = mine;
+            if (lane < P) v = flag_load(xtab + lane);
+            const bool same = __all(v == mine);
+            if (lane == 0) lflag[2] = same ? 1 : 0;
+        }
         __syncthreads();
+        if (xcd_look) fast = uni(lflag[2]) != 0;
         PL_ST(1);   // cell + stash stores + dA image
         uint4 bfr[8];   // B fragments of the dA image, shared by all tiles of the wave
 #pragma unroll
@@ -836,9 +889,10 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int nt = wave + 4 * i;
-                if (4 * i + 3 < P || nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane);
+                if (4 * i + 3 < P || nt < P) partial_tile(wreg[i], bfr, tst, TRS, 0, ro, (unsigned)((size_t)nt * P * TILE * 2), lane, fast);
             }
         }
+        if (xtab && c == 0 && t == T - 1 && tid == 0) flag_store(xtab + p, xcc_id_plus1());   // with the first hand-off: drained before its flag
         if constexpr (MEL) if (wave < n_mel) {
             bf16_t* xd = XM + (size_t)(t % kFusedRing) * mslot_stride + (size_t)g * mgrp_stride + (size_t)p * TILE;   // [tile][this source]
             const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(n_mel - 1) * P + 1) * TILE * 2));
@@ -849,6 +903,7 @@ __device__ __forceinline__ void fused_lstm_bwd(const FusedArgs& a, const FusedRo
         }
         PL_ST(2);   // MFMA + hand-off stores (+ flag answer, prefetch issue)
         raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
+        if (fast && fdelta != 0 && wave == 0 && lane == 0) flag_store_plain(rflags + ((size_t)g * T + t) * a.flag_stride + p + fdelta, 1);
         PL_ST(3);   // drain + barrier + flag
         if (!has_next) break;
         if (!ready) {

@@ -249,6 +249,7 @@ struct pl_handle {
     // fused acoustic sweeps (lstm_fused.hip): one persistent launch per direction, workgroups take roles from these tables
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles
+    bool fused_xcd = true;            // PAULE_HIP_FUSED_XCD: the 32-row fused backward roles' own exchange through the shared L2 when a set sits on one XCD
     int fused_gpp = 0;                // forward launch in passes: groups per pass (0: every group has its own set, one pass)
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
     int fused_grid_fwd = 0;
@@ -1527,6 +1528,19 @@ int* fused_slice(pl_handle* h, int r, bool bwd) {   // backward: r >= n_roles ar
 // 16-row LSTM roles (fused_rows16): the second, plain flag set and the XCD-id table of the role sit in its own flag slice -- a slice
 // has room for (Bp + 7) / 8 = 2 groups of arrival flags and these launches have one: the second group's area holds the plain set,
 // the XCD ids follow where they do for the per-layer sweeps
+// 32-row backward LSTM roles (round 4): the XCD-id table only -- a verified same-XCD set hands its own partial tiles over through the
+// shared L2 (plain stores, nt LDS-DMA; flags unchanged).  One row of 64 per SET of the role, where the per-layer sweeps keep one per group.
+// PAULE_HIP_XCD_FAST bit 1 = 0 or PAULE_HIP_FUSED_XCD=0: write-through everywhere (A/B, counter passes)
+void fused32_xcd_fields(pl_handle* h, FusedRole& R, int* slice) {
+    if (h->fused_rows16 || !(h->xcd_fast & 2) || !h->fused_xcd) return;
+    // three and more chains per workgroup hide the hand-off behind the other chains' work: nothing to gain there (set B at 256 rows: 4.66
+    // against 4.68 ms per iteration), so the role keeps the one write-through form (profiles/r04_ab_fused_bwd_xcd.txt)
+    if (R.C > 2) return;
+    R.xtab = slice + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
+    // the plain flag set of the own exchange: the second quarter of the slice (the 32-row groups' write-through flags fill the first)
+    R.fast_flags = slice + (size_t)((h->Bp + 31) / 32) * h->T * h->flag_stride;
+}
+
 void fused16_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
     if (!h->fused_rows16) return;
     if (!h->xcd_fast || !h->xcd_fast16) return;   // PAULE_HIP_XCD_FAST=0 / PAULE_HIP_XCD_FAST16=0: the write-through exchange everywhere (A/B, counter passes)
@@ -1626,6 +1640,7 @@ int build_fused_roles(pl_handle* h) {
                 R.dh_ext = h->fused_dh_pred[l]; R.dh_ext_half = 0; R.dh_ext_rows = T;
             }
             fused16_fields(h, R, fl[rl], nullptr);
+            fused32_xcd_fields(h, R, fl[rl]);
             if (l >= 1) {   // this layer's dA feeds its product role: dL/dh of the layer below
                 R.dA_sc1 = 1;
                 const int rdx = fr_pred_proj(l);
@@ -1652,6 +1667,7 @@ int build_fused_roles(pl_handle* h) {
             R.wait[0] = FusedWait{fl[rl], Tp, Pe, 0, 0, 1};
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
             fused16_fields(h, R, fl[rl], nullptr);
+            fused32_xcd_fields(h, R, fl[rl]);
             if (top) R.dh_last = h->dv;
             else {   // dL/dh rows from the layer above's product role (reduced there): this slice's columns come from its slice-p workgroup
                 R.wait[1] = FusedWait{flags2_emb(l + 1), Tp, 1, 1, 0, 0};
@@ -2109,6 +2125,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
+        if (const char* z = std::getenv("PAULE_HIP_FUSED_XCD")) h->fused_xcd = std::atoi(z) != 0;
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;
         if (const char* z = std::getenv("PAULE_HIP_TOKEN_EARLY")) h->token_early = std::atoi(z) != 0;
