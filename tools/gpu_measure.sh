@@ -36,7 +36,10 @@ for part in $parts; do
     pmc_others) pmc_pair cfg3_setB "" PAULE_HIP_XCD_FAST=2
                 pmc_pair cfg5_128 "" PAULE_HIP_XCD_FAST=2
                 pmc_pair cfg2 "" PAULE_HIP_XCD_FAST=2
-                pmc_pair cfg5 "" PAULE_HIP_XCD_FAST=2 ;;
+                pmc_pair cfg5 "" PAULE_HIP_XCD_FAST=2
+                pmc_pair cfg3_soma "" PAULE_HIP_XCD_FAST=2
+                pmc_pair cfg4_1gpu "" PAULE_HIP_XCD_FAST=2
+                pmc_pair cfg1_bf16 "" PAULE_HIP_XCD_FAST=2 ;;
     others) for c in cfg1 cfg1_bf16 cfg2 cfg2_setB cfg3_setB cfg3_setC cfg3_f32 cfg5 cfg5_setB cfg5_128 cfg4_1gpu cfg3_soma train8; do   # train8 etc. print one JSON line each
               run bench_$c 400 python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline
               grep '^{' gpurun_out/${tag}_bench_$c.log > gpurun_out/${tag}_bench_$c.json
