@@ -1841,7 +1841,12 @@ void drop_graph(pl_handle* h) {
     // hipGraphLaunch of a later branched exec crashed inside the runtime about once in a hundred handles (ROCm 7.2;
     // tools/microbench/capture_stress.py reproduces it with PAULE_HIP_DESTROY_BRANCHED=1, 720 handles pass without).  The exec
     // of a retired handle stays allocated for the life of the process (kernel arguments only; device buffers are freed).
-    if (h->graph_exec && (h->wf_regions.empty() || std::getenv("PAULE_HIP_DESTROY_BRANCHED"))) (void)hipGraphExecDestroy(h->graph_exec);
+#ifdef PL_EXPERIMENTS   // PAULE_HIP_DESTROY_BRANCHED reproduces the runtime crash of DESIGN.md section 10 (tools/microbench/capture_stress.py)
+    const bool destroy_branched = std::getenv("PAULE_HIP_DESTROY_BRANCHED") != nullptr;
+#else
+    const bool destroy_branched = false;
+#endif
+    if (h->graph_exec && (h->wf_regions.empty() || destroy_branched)) (void)hipGraphExecDestroy(h->graph_exec);
     else if (h->graph_exec) g_retained_branched_execs.fetch_add(1, std::memory_order_relaxed);
     DBG_G("drop: graph destroy");
     if (h->graph) (void)hipGraphDestroy(h->graph);
@@ -2121,7 +2126,9 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         h->n_cu = prop.multiProcessorCount;
         const char* env = std::getenv("PAULE_HIP_NO_SWEEP");
         h->use_sweep = !(env && env[0] == '1');
+#ifdef PL_EXPERIMENTS   // A/B-only switch (its measured winner is the fixed default of the shipped library: DESIGN.md 4.1c)
         if (const char* z = std::getenv("PAULE_HIP_ZERO_MODE")) h->zero_mode = std::atoi(z);
+#endif
         if (const char* z = std::getenv("PAULE_HIP_BWD_MODE")) h->bwd_mode = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
@@ -2140,17 +2147,23 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
                             "no backward pass, no update -- loss logs and the CP do not change)\n");
         }
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
+#ifdef PL_EXPERIMENTS   // A/B-only switch (its measured winner is the fixed default of the shipped library: DESIGN.md 4.1c)
         if (const char* z = std::getenv("PAULE_HIP_POLL_MASK")) h->poll_mask = (unsigned)std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSE_INPUT")) h->fuse_input = std::atoi(z) != 0;
+#endif
         if (const char* z = std::getenv("PAULE_HIP_F32_SWEEP")) h->f32_sweep = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_F32_CHAINS")) h->f32_chains = std::atoi(z);
+#ifdef PL_EXPERIMENTS   // A/B-only switch (its measured winner is the fixed default of the shipped library: DESIGN.md 4.1c)
         if (const char* z = std::getenv("PAULE_HIP_SMALL_GRID")) h->small_grid = std::atoi(z) != 0;
+#endif
         if (const char* z = std::getenv("PAULE_HIP_SWEEP16")) h->sweep16 = std::atoi(z) != 0;
+#ifdef PL_EXPERIMENTS   // A/B-only switch (its measured winner is the fixed default of the shipped library: DESIGN.md 4.1c)
         if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST16")) h->wide_ingest16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WIDE_INGEST")) h->wide_ingest = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_OWN_STORE")) h->own_store = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST16")) h->xcd_fast16 = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_STASH_LDS")) h->stash_lds = std::atoi(z) != 0;
+#endif
         if (h->dt == F32 && h->use_sweep && h->f32_sweep) {
             size_t xb = 0;
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb})
@@ -2175,9 +2188,13 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         }
         if (const char* z = std::getenv("PAULE_HIP_F32_VALU")) h->f32_valu = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_WF_PIPELINE")) h->wf_pipeline = std::atoi(z) != 0;
+#ifdef PL_EXPERIMENTS   // A/B-only switch (its measured winner is the fixed default of the shipped library: DESIGN.md 4.1c)
         if (const char* z = std::getenv("PAULE_HIP_PIPE_SPREAD")) h->pipe_spread = std::atoi(z) != 0;
+#endif
         if (const char* z = std::getenv("PAULE_HIP_WAVEFRONT")) h->wavefront = std::atoi(z);
+#ifdef PL_EXPERIMENTS   // A/B-only switch (its measured winner is the fixed default of the shipped library: DESIGN.md 4.1c)
         if (const char* z = std::getenv("PAULE_HIP_WF_DIRS")) h->wf_dirs = std::atoi(z);
+#endif
         if (h->wavefront > 0 && h->use_sweep) {
             for (Model* md : {&h->pred, &h->emb, &h->tube, &h->tmel, &h->temb}) {
                 const int ppx = pipe_per_xcd(h, *md);

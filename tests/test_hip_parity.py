@@ -575,6 +575,38 @@ def test_fused_backward_matches_per_layer_path(HipPlanner, monkeypatch, shape):
     assert np.abs(_n(e["3"].get_cp()) - _n(e["0"].get_cp())).max() <= 2e-4   # lr = 0.01: 2 % of one step
 
 
+@pytest.mark.parametrize("shape", [dict(B=64, T=41, set="A"), dict(B=100, T=33, set="A"), dict(B=128, T=300, set="A"), dict(B=64, T=30, set="B")])
+def test_fused_backward_same_xcd_exchange_is_bit_identical(HipPlanner, monkeypatch, shape):
+    """Round 4: a 32-row fused backward role whose workgroups find themselves on one XCD hands its OWN partial tiles over through that
+    XCD's L2 (plain stores, nt LDS-DMA, a second plain flag set; lstm_fused.hip: fused_lstm_bwd) -- same tiles, same order of every
+    sum.  Against the write-through form (PAULE_HIP_FUSED_XCD=0): every layer's dA, dL/dCP, the losses and the plan after four
+    iterations are bit-identical; full and ragged groups, one and two chains, the two-width launch of model set B."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, shape["set"])
+    names = ["emb.G0", "pred.G0", "dX"] + (["emb.G1"] if shape["set"] == "A" else ["pred.G3"])
+    out = {}
+    for xcd in ("0", "1"):
+        monkeypatch.setenv("PAULE_HIP_FUSED_XCD", xcd)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        plan = eng.plan_info()
+        assert plan["fused_bwd"] == 1 and plan["fused_rows"] == 32, plan
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        l1 = _n(eng.step(1))
+        eng.synchronize()
+        bufs = {k: _n(eng.debug_read(k)) for k in names}
+        l4 = _n(eng.step(3))
+        eng.synchronize()
+        out[xcd] = (l1, bufs, l4, _n(eng.get_cp()))
+        eng.close()
+    monkeypatch.delenv("PAULE_HIP_FUSED_XCD")
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    for k in names:
+        np.testing.assert_array_equal(out["1"][1][k], out["0"][1][k], err_msg=k)
+    np.testing.assert_array_equal(out["1"][2], out["0"][2])
+    np.testing.assert_array_equal(out["1"][3], out["0"][3])
+
+
 @pytest.mark.parametrize("shape", [dict(B=256, T=60, graph=True), dict(B=70, T=31, graph=False)])
 def test_fused_backward_stacked_predictor_tracks_the_per_layer_path(HipPlanner, monkeypatch, shape):
     """Round 3: the fused BACKWARD launch takes the class-default stacked predictor too (model set B: four recurrences and three dL/dh
