@@ -73,6 +73,13 @@ struct LstmSweepArgs {
     int bwd_waves;         // lstm_persist_rs.hip: waves per workgroup, 4 or 8 (0 = 8, the default; PAULE_HIP_BWD_WAVES)
     int* tflags;           // lstm_persist_rs.hip, streamed form: per-tile flags [2 slots][groups][P destinations][32] (zeroed with the
                            // counters); null = the whole-workgroup hand-off (one flag per workgroup and step)
+    // lstm_persist_rs.hip, streamed form, first layer of a model with a narrow input (round 4): the workgroup's partial input gradient
+    // dA_t[its 128 gate rows] * W_ih rides along as one more tile of the step (the free tile slot of the last wave: 23 tiles on 8 x 3
+    // slots) and leaves as f32 to xpart [T][groups][P][32 x 32]; launch_dx_reduce then sums the P partials in a fixed order.  The batched
+    // product dA * W_ih with its re-read of the whole dA stash (452 MB at cfg3) disappears.  null = off
+    const void* WihT;      // [in_p = 32][4*Hp] packed like Whh^T
+    float* xpart;
+    int skip_dA;           // with xpart: 1 = dA_t is NOT written to the stash (nothing reads the predictor's dA in a planning iteration)
     int token_handoff;     // lstm_persist_rs.hip, token form (round 4): 1 = the tiles carry their own step token, no flags, no drains; xchg
                            // is then a buffer ONLY this form uses (zero at the start of every launch: the kernel leaves it retired)
 };
@@ -84,6 +91,11 @@ void launch_lstm_sweep(hipStream_t stream, bool backward, int Hp, int grid, cons
 // backward sweep in reduce-scatter form (lstm_persist_rs.hip): same arguments + a.xchg of lstm_rs_exchange_bytes()
 size_t lstm_rs_exchange_bytes(int Hp, int Bp);
 void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSweepArgs& a);
+// the ride-along input gradient (LstmSweepArgs::xpart): supported shape, scratch size, and the fixed-order sum of the partials into
+// dX f32 [T][Bp][32] (what the batched product wrote)
+bool lstm_rs_ride_along_supported(int Hp, int in_p);
+size_t lstm_rs_xpart_bytes(int Hp, int Bp, int T);
+void launch_dx_reduce(hipStream_t stream, const float* xpart, int Hp, int Bp, int T, float* dX);
 // bf16 sweeps on groups of 16 rows for batches of up to 128 rows (lstm_persist16.hip); same arguments, group_rows <= 16
 bool lstm_sweep16_wanted(int Hp, int Bp, int n_cu);
 int lstm_sweep16_grid(int Hp, int Bp, int n_cu, bool spread_small);

@@ -257,7 +257,12 @@ typedef __attribute__((address_space(3))) unsigned char* rs_lds_ptr_t;
 // poll's answer and every tile load queued behind them.  dA_t leaves for the gate stash from the LDS image as 16-byte pieces, stored by
 // waves 4 .. 7 behind the barrier (2 store instructions per lane instead of 4 in the cell waves' critical phase).  Same values, same
 // order of every sum: bit-identical to DMA = 0 (tests/test_hip_parity.py::test_backward_sweep_forms_are_bit_identical).
-template <int KS, int DMAV>   // bit 0: stash rows by LDS-DMA a step ahead; bit 1: dA_t stored by waves 4 .. 7 from the image
+// XT = 1 (round 4): the partial input gradient of the step rides along -- the last wave's free tile slot (P tiles on 8 x NT slots)
+// holds this workgroup's 128 rows of W_ih^T, its product with the dA image (the B operand every tile of the step uses) is one more
+// tile of 8 MFMAs, produced behind the wave's exchange tiles and stored as f32 straight from the accumulators (no flag, nobody waits
+// for it in the launch).  launch_dx_reduce sums the P partials afterwards; the batched product, which re-read the whole dA stash,
+// is gone (cfg3: 107 us -> ~45 us).  The recurrence itself is untouched: every dA and every exchange tile keep their bits.
+template <int KS, int DMAV, int XT = 0>   // DMAV bit 0: stash rows by LDS-DMA a step ahead; bit 1: dA_t stored by waves 4 .. 7 from the image
 __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArgs a) {
     constexpr bool DMA = (DMAV & 1) != 0, DAW = (DMAV & 2) != 0;
     constexpr int Hp = 16 * KS;
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
     constexpr int DRS = 128 * 2 + 16;
     constexpr int ORS = Hp * 2 + 16;
     static_assert(P <= 32, "one flag word per source in a 32-int row");
+    static_assert(!XT || NW * NT > P, "the ride-along tile needs a free tile slot in the last wave");
     __shared__ __attribute__((aligned(16))) unsigned char da_img[2][32 * DRS];
     __shared__ __attribute__((aligned(16))) unsigned char out_img[32 * ORS];
     __shared__ __attribute__((aligned(16))) unsigned char st_img[DMA ? 2 : 1][DMA ? 7 : 1][DMA ? 2048 : 16];   // stash rows: [i, f, g, o, c_t, c_{t-1}, dh][32 rows][64 B]
@@ -288,9 +294,11 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
         const int k = wave + NW * i;
         const int nt = k < P ? (p + 1 + k) % P : 0;
         const int n = 32 * nt + (lane & 31);
+        // the last wave's last slot is free (k >= P): with XT it holds W_ih^T -- row n = input column lane & 31, the same 128 gate rows
+        const bf16_t* wsrc = (XT && i == NT - 1 && wave == NW - 1) ? static_cast<const bf16_t*>(a.WihT) + (size_t)(lane & 31) * G4 : WT + (size_t)n * G4;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
-            wreg[i][ks] = *reinterpret_cast<const uint4*>(WT + (size_t)n * G4 + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
+            wreg[i][ks] = *reinterpret_cast<const uint4*>(wsrc + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
     }
 
     const int erow = (tid & 255) >> 3, jq = tid & 7;
@@ -448,14 +456,14 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
                 for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
                 const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
                 const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
-                if (ok && (!DAW || t == 0)) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                if (ok && (!DAW || t == 0) && !(XT && a.skip_dA)) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
                     bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
                     *reinterpret_cast<uint2*>(go_) = pi;
                     *reinterpret_cast<uint2*>(go_ + Hp) = pf;
                     *reinterpret_cast<uint2*>(go_ + 2 * Hp) = pg;
                     *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
                 }
-                if (t > 0) {
+                if (t > 0 || XT) {   // (XT: step 0 has an input gradient too, though nobody consumes its recurrent partials)
                     unsigned char* drow = dimg + erow * DRS + jq * 8;
                     *reinterpret_cast<uint2*>(drow) = pi;
                     *reinterpret_cast<uint2*>(drow + 64) = pf;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
                     *reinterpret_cast<uint2*>(drow + 192) = po;
                 }
             }
-            if (t == 0) break;   // nobody consumes the partials of step 0
+            if (t == 0 && !XT) break;   // nobody consumes the partials of step 0
             if (t == T - 1 && tid == 0) {   // this workgroup's XCD, in place before ANY of its flags (they are raised behind the barrier below)
                 __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int k = wave + NW * i;
+                if (XT && t == 0) break;                      // step 0: nobody consumes recurrent partials (only the input gradient below)
                 if (NW * i + NW - 1 >= P && k >= P) break;   // a compile-time fact for all but a wave's last tile
                 // (the break sits IN FRONT of a tile's MFMAs, behind the previous tile's epilogue: no MFMA result is read across it --
                 // tools/isa_mfma_hazard_scan.py, profiles/r04_isa_stale_accumulator.txt)
@@ -525,6 +534,28 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise(nt_prev);
             }
+            if (XT && wave == NW - 1) {
+                // the ride-along tile, BEHIND the wave's last flag (nobody in the launch waits for its stores): partial dX[n = input column][batch] over this workgroup's 128 gate rows, f32 from the accumulators;
+                // acc[4 rg + e] = partial[n = 8 rg + 4 (lane >> 5) + e][batch lane & 31] -> 16 bytes at rg * 1 KB + lane * 16
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[NT - 1][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+                float* xp = a.xpart + (((size_t)t * n_groups + g) * P + p) * 1024;
+                const __amdgpu_buffer_rsrc_t rp = make_rsrc(xp, 4096u);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    // (through scalars: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 -- hipcc stored acc[0] sixteen times)
+                    const float f0 = acc[4 * rg], f1 = acc[4 * rg + 1], f2 = acc[4 * rg + 2], f3 = acc[4 * rg + 3];
+                    u32x4 d;
+                    d[0] = __float_as_uint(f0); d[1] = __float_as_uint(f1); d[2] = __float_as_uint(f2); d[3] = __float_as_uint(f3);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rp, (unsigned)(rg * 1024 + lane * 16), 0, 0);
+                }
+            }
+            if (XT && t == 0) break;
             if (DAW && !cellw) {   // dA_t -> the gate stash, from the image (double-buffered: intact until step t - 2), as 16-byte pieces (gate ch >> 2,
                 // units 8 (ch & 3) .. + 7) -- BEHIND the tiles: in front of them the acknowledge of these stores (HBM, ~1 us) sat in the way of every
                 // tile flag's counted wait (tile phase 1.23 -> 2.20 us, profiles/r04_ab_bwd_dma.txt)
@@ -936,6 +967,26 @@ size_t lstm_rs_exchange_bytes(int Hp, int Bp) {
     return 2 * groups * P * P * 32 * 32 * 2;
 }
 
+// fixed-order sum of the P partial input-gradient tiles of every (step, group): dX f32 [T][Bp][32]
+__global__ __launch_bounds__(256) void dx_reduce_kernel(const float* __restrict__ xpart, int P, int n_groups, int Bp, float* __restrict__ dX) {
+    const int tg = blockIdx.x, t = tg / n_groups, g = tg % n_groups;
+    const int rg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4* src = reinterpret_cast<const float4*>(xpart + (size_t)tg * P * 1024) + rg * 64 + lane;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < P; ++p) {
+        const float4 v = src[(size_t)p * 256];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int b = 32 * g + (lane & 31), n = 8 * rg + 4 * (lane >> 5);
+    if (b < Bp) *reinterpret_cast<float4*>(dX + ((size_t)t * Bp + b) * 32 + n) = s;
+}
+bool lstm_rs_ride_along_supported(int Hp, int in_p) { return in_p == 32 && Hp == 16 * 46; }   // P = 23: one free slot on 8 waves x 3 tiles
+size_t lstm_rs_xpart_bytes(int Hp, int Bp, int T) { return (size_t)T * ((Bp + 31) / 32) * (Hp / 32) * 4096; }
+void launch_dx_reduce(hipStream_t stream, const float* xpart, int Hp, int Bp, int T, float* dX) {
+    const int ng = (Bp + 31) / 32;
+    hipLaunchKernelGGL(dx_reduce_kernel, dim3(T * ng), dim3(256), 0, stream, xpart, Hp / 32, ng, Bp, dX);
+}
+
 #ifdef PL_EXPERIMENTS   // the token form and the LDS-DMA variants of the streamed form (profiles/r04_token_handoff.txt)
 #define PL_CASE_EXPERIMENTS(K)                                                                        \
         if (a.token_handoff && K <= 64) {                                                                 \
@@ -958,7 +1009,9 @@ void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSw
 #define PL_CASE(K)                                                                                        \
     if (Hp == 16 * K) {                                                                                   \
         PL_CASE_EXPERIMENTS(K)                                                                            \
-        if (a.tflags && a.bwd_waves != 4 && K <= 64)                                                      \
+        if (a.tflags && a.bwd_waves != 4 && K == 46 && a.xpart)                                           \
+            hipLaunchKernelGGL((lstm_bwd_rs_stream_kernel<46, 0, 1>), dim3(grid), dim3(512), 0, stream, a);   \
+        else if (a.tflags && a.bwd_waves != 4 && K <= 64)                                                 \
             hipLaunchKernelGGL((lstm_bwd_rs_stream_kernel<(K <= 64 ? K : 2), 0>), dim3(grid), dim3(512), 0, stream, a); \
         else if (a.bwd_waves == 4)                                                                        \
             hipLaunchKernelGGL((lstm_bwd_rs_sweep_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a);    \

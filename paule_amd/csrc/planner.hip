@@ -249,6 +249,8 @@ struct pl_handle {
     // fused acoustic sweeps (lstm_fused.hip): one persistent launch per direction, workgroups take roles from these tables
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles
+    int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
+    float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
     bool fused_xcd = true;            // PAULE_HIP_FUSED_XCD: the 32-row fused backward roles' own exchange through the shared L2 when a set sits on one XCD
     int fused_gpp = 0;                // forward launch in passes: groups per pass (0: every group has its own set, one pass)
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
@@ -532,6 +534,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
         LstmLayer& ly = md.layers[l];
         const bool sparse_top = (l == md.L - 1) && dh_last;
         const int sweep_grid = sweep_grid_for(h, Hp, true);
+        bool ride_along = false;
         if (sweep_grid > 0) {
             LstmSweepArgs s{};
             s.Bp = Bp;
@@ -552,6 +555,11 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.stamps = h->sweep_stamps ? h->sweep_stamps + 256 * 8 : nullptr;
             s.xchg = h->sweep_xchg;
             s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
+            // the predictor's first layer in a planning iteration: dL/dCP = dA W_ih rides along in the sweep (partial tiles to dx_part,
+            // summed by launch_dx_reduce below) where the streamed 32-row form runs the whole sequence; otherwise the batched product
+            ride_along = l == 0 && &md == &h->pred && train_nb == 0 && dIn == h->dX && h->dx_part && Tl == h->T && h->dt == BF16 &&
+                         !use_sweep16(h, Hp, true) && h->bwd_mode == 1 && h->sweep_xchg && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_dma == 0;
+            if (ride_along) { s.WihT = ly.WihT; s.xpart = h->dx_part; s.skip_dA = h->bwd_xt == 2 ? 1 : 0; }
             launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
@@ -583,6 +591,8 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             launch_gemm_nt(st, h->dt, false, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, md.dh_ext, Hp, Tl * Bp, Hp, 4 * Hp);
         else if (train_nb > 0)
             ;
+        else if (ride_along)
+            launch_dx_reduce(st, h->dx_part, Hp, Bp, Tl, dIn);
         else
             launch_gemm_nt(st, h->dt, true, ly.G, 4 * Hp, ly.WihT, 4 * Hp, nullptr, dIn, ly.in_p, Tl * Bp, ly.in_p, 4 * Hp);
     }
@@ -2133,6 +2143,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_XCD")) h->fused_xcd = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;
         if (const char* z = std::getenv("PAULE_HIP_TOKEN_EARLY")) h->token_early = std::atoi(z) != 0;
@@ -2181,6 +2192,12 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
                     xb = xb > xe ? xb : xe;
                 }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
+            if (xb && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_xt && h->pred.L >= 1 &&
+                lstm_rs_ride_along_supported(h->pred.Hp, h->pred.layers[0].in_p)) {
+                void* q = nullptr;
+                if ((rc = raw_alloc(h, &q, lstm_rs_xpart_bytes(h->pred.Hp, h->Bp, h->T)))) return bail(rc);
+                h->dx_part = static_cast<float*>(q);
+            }
             if (xb && h->bwd_stream == 2) {   // the token form's own exchange (raw_alloc zeroes it: every granule "retired")
                 if ((rc = raw_alloc(h, &h->sweep_xchg_tok, xb))) return bail(rc);
                 h->sweep_xchg_tok_bytes = xb;

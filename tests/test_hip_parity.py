@@ -358,6 +358,7 @@ def test_backward_sweep_forms_are_bit_identical(HipPlanner, monkeypatch, shape):
     B, T = shape["B"], shape["T"]
     wl = synthetic.make_workload(B, T, shape["set"])
     monkeypatch.setenv("PAULE_HIP_FUSED", "1")   # fused forward launch + per-layer backward sweeps, as cfg3 runs
+    monkeypatch.setenv("PAULE_HIP_BWD_XT", "0")  # dL/dCP by the batched product in all three forms (round 4's ride-along tile sums it in another order)
     out = {}
     for form, env in (("w4", dict(PAULE_HIP_BWD_WAVES="4")), ("w8", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="0")),
                       ("stream", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1"))):
@@ -376,6 +377,41 @@ def test_backward_sweep_forms_are_bit_identical(HipPlanner, monkeypatch, shape):
     for form in ("w8", "stream"):
         for k in ("loss", "cp", "dX", "G"):
             np.testing.assert_array_equal(out[form][k], out["w4"][k], err_msg=f"{form}: {k}")
+
+
+@pytest.mark.parametrize("shape", [dict(B=256, T=300), dict(B=144, T=61), dict(B=270, T=17), dict(B=16, T=40)])
+def test_ride_along_input_gradient_equals_the_batched_product(HipPlanner, monkeypatch, shape):
+    """Round 4: in the predictor's streamed backward sweep the workgroup's partial dL/dCP = dA_t[its 128 gate rows] W_ih rides along as
+    one more tile per step (the last wave's free tile slot) and a reduce kernel sums the 23 partials in a fixed order; the batched
+    product dA W_ih -- which re-read the whole dA stash -- is gone.  Against PAULE_HIP_BWD_XT=0 (the product): the recurrence is
+    untouched (every layer's dA and the losses bit-identical), dL/dCP agrees to f32 summation order (both accumulate the same bf16
+    products in f32), the plans stay together; full, ragged and multi-pass groups, and the 32-row kernel on a 16-row batch."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "A")
+    monkeypatch.setenv("PAULE_HIP_FUSED", "1")
+    monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
+    monkeypatch.setenv("PAULE_HIP_SWEEP16", "0")
+    out = {}
+    for xt in ("0", "1"):
+        monkeypatch.setenv("PAULE_HIP_BWD_XT", xt)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        l1 = _n(eng.step(1))
+        eng.synchronize()
+        bufs = {k: _n(eng.debug_read(k)) for k in ("emb.G1", "emb.G0", "pred.G0", "dX")}
+        l5 = _n(eng.step(4))
+        eng.synchronize()
+        out[xt] = (l1, bufs, l5, _n(eng.get_cp()))
+        eng.close()
+    monkeypatch.delenv("PAULE_HIP_BWD_XT")
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    for k in ("emb.G1", "emb.G0", "pred.G0"):
+        np.testing.assert_array_equal(out["1"][1][k], out["0"][1][k], err_msg=k)
+    a, b = out["1"][1]["dX"], out["0"][1]["dX"]
+    assert np.isfinite(a).all() and np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=1e-6, atol=1e-9)
+    assert np.abs(out["1"][3] - out["0"][3]).max() <= 2e-5   # Adam: where |g| ~ eps a last-bit difference of g moves the update by a fraction of lr
 
 
 def test_fused_launch_census_late_sign_in_keeps_the_first_cause(HipPlanner, monkeypatch):
