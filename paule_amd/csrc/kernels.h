@@ -192,6 +192,9 @@ bool fused_supported(int Hp);
 bool fused_fwd_supported(int Hp_pred, int Hp_emb);
 void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 void launch_fused_bwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
+// the forward launch at TWO workgroups per CU (lstm_fused2.hip, round 4): the same role table, planned for 2 x n_cu workgroup slots
+bool fused_fwd2_supported(int Hp_pred, int Hp_emb);
+void launch_fused_fwd2(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 // the same role tables with the LSTM roles on 16 batch rows (v_mfma_f32_16x16x32_bf16, one chain): batches of up to 16 rows
 void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 void launch_fused_bwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);

@@ -578,35 +578,6 @@ struct LstmBwdLds {
     static constexpr int BYTES = O_FLAG + 64;
 };
 
-// LDS-DMA, write-through read (sc1): 64 lanes x 16 bytes land at lds_dst_uniform + 16 * lane.  Issued from inline asm: the
-// compiler does not see the LDS write (callers wait with s_waitcnt vmcnt and a barrier before reading the region) and does not
-// count the operation (its own counted waits only get more conservative: vmcnt retires in order).
-__device__ __forceinline__ void glds16_sc1(const void* gsrc_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2 sc1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst_uniform)
-        : "memory");
-}
-// the same through the XCD's own L2 (nt: bypasses only this CU's L1): for tiles that workgroups of the SAME XCD stored plainly
-__device__ __forceinline__ void glds16_nt(const void* gsrc_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst_uniform)
-        : "memory");
-}
-typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
 // one partial tile: 8 k-steps over the workgroup's 128 local gate rows; acc[r] = out[n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][batch lane & 31]
 // -> bf16 image [batch][n], read back by rows by the same wave (a wave's LDS operations are ordered) and stored as 2 KB

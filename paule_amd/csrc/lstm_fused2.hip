@@ -1,0 +1,644 @@
+// The forward launch of lstm_fused.hip at TWO workgroups per CU (round 4; `fused_fwd2_kernel`).
+//
+// Why.  A chain-step of the forward launch keeps its workgroup busy for 3.2 - 3.7 us of which 1.0 us is matrix time (the rest: the h tile
+// on its way into LDS, the poll's answer, the memory pipe taking the next tile's requests, cell arithmetic, stores, drain), and with one
+// wave per SIMD those phases run one after the other: nothing fills the matrix core while a wave does cell arithmetic, and nothing issues
+// loads while it multiplies.  lstm_fused.hip answers with CHAINS (a second group whose hand-off flies meanwhile); cutting the work of one
+// workgroup into wave stages that overlap was tried twice and lost to the lock-step of its barriers.  This file lets the
+// HARDWARE do the overlapping: the same roles, written to fit 256 registers and 80 KB of LDS, so that TWO workgroups share a CU -- two
+// waves per SIMD that belong to different workgroups (different groups, often different roles), each with its own barriers, and the CU's
+// schedulers interleave one's MFMA chain with the other's memory and cell phases.
+//
+// What had to go to get there (the slice of W_hh alone takes 184 of the 256 registers):
+//  * the prefetched h tile (48 registers) -- the tile goes global -> LDS by LDS-DMA (`global_load_lds_dwordx4`), no registers, no
+//    ds_write phase.  The image is laid out for that: [64-byte column block kb][row][4 x 16 B], one wave instruction fills 16 rows x 64 B
+//    = 1 KB of contiguous LDS, and the 16-byte chunk c of row r sits in slot c ^ s(r) so that the MFMA operand reads (ds_read_b128 in the
+//    lane groups of gfx950) stay conflict-free -- the permutation is applied on the GLOBAL side (which chunk of its 64-byte piece a lane
+//    fetches), so coalescing is untouched;
+//  * operands of the NEXT chain-step in flight under this one (one image, one set of rows): the latency this exposes is what the other
+//    workgroup on the CU covers.  One chain per workgroup is the normal shape now; two are supported (cell state in LDS);
+//  * the bias in 16 registers -> LDS; B fragments three k-steps ahead instead of six.
+// Arithmetic, MFMA shapes and k order are those of lstm_fused.hip / the per-layer sweeps: bit-identical results
+// (tests/test_hip_parity.py::test_fused_forward_two_per_cu_is_bit_identical).  Hand-off protocol, flags, bounded waits, census: unchanged
+// (fused_common.h); the role table is the same, planned for 2 x n_cu workgroup slots (planner.hip: plan_fused).
+#include "fused_common.h"
+
+#ifndef FUSED2_STREAMED_W
+#define FUSED2_STREAMED_W 4   // W_hh fragments (k-steps) of a recurrence role that are fetched per chain-step instead of staying in registers
+#endif
+#ifndef FUSED2_SPLIT_TILE
+#define FUSED2_SPLIT_TILE 1   // 1: the h tile's landing is waited for in two halves around the MFMA chain (measured: DESIGN.md 4.0d)
+#endif
+
+namespace pl {
+namespace {
+
+constexpr int kFused2MaxChains = 2;
+
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    bf16x2_t o;
+    o[0] = (bf16_t)a; o[1] = (bf16_t)b;
+    return __builtin_bit_cast(unsigned, o);
+}
+__device__ __forceinline__ float bf16_lo_hi(unsigned u, int k) { return __uint_as_float(k ? (u & 0xffff0000u) : (u << 16)); }   // element k of a bf16 pair, widened (exact)
+
+// slot of the 16-byte chunk c of image row r: LSTM roles read B fragments as (row lane & 31, chunk 2 (ks & 1) + (lane >> 5)), product roles
+// read A fragments as (row lane & 15 (+ 16), chunk lane >> 4) -- each needs its own permutation to keep the 16 lanes of a ds_read_b128
+// group on 16 different bank quads (worked through in DESIGN.md 4.0d)
+template <bool GEMM>
+__device__ __forceinline__ int img_swz(int row) {
+    const int q = (row >> 2) & 3;
+    return GEMM ? ((0x78 >> (2 * q)) & 3) : q;
+}
+
+// rows 32 g .. 32 g + 31 of a row-major [Bp][Hp] bf16 slab -> image, by LDS-DMA (write-through reads).  Wave w fills the half tiles
+// (kb = 2 j + (w >> 1), rows 16 (w & 1) ...): P tiles x 2 halves, 12 or 11 pieces a wave at Hp = 736.  Rows beyond the batch read row
+// Bp - 1 (their results are never stored: every store's offset goes through the range check).
+template <int P, int ROWB, bool GEMM>
+__device__ __forceinline__ void dma_image(const void* slab, int g, int Bp, unsigned img_lds, int wave, int lane) {
+    const int half = wave & 1, hi = wave >> 1;
+    const int row = 16 * half + (lane >> 2);
+    int rb = 32 * g + row;
+    rb = rb < Bp ? rb : Bp - 1;
+    const unsigned voff = (unsigned)(rb * ROWB + (((lane & 3) ^ img_swz<GEMM>(row)) * 16));
+    const unsigned char* src = static_cast<const unsigned char*>(slab) + hi * 64;
+    const unsigned dst = img_lds + (unsigned)(hi * 2048 + half * 1024);
+#pragma unroll
+    for (int j = 0; j < (P + 1) / 2; ++j)
+        if (2 * j + hi < P) glds16_sc1(uni(src + j * 128), voff, (unsigned)uni((int)(dst + (unsigned)(j * 4096))));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward recurrence of one layer (arithmetic of lstm_fwd_sweep_kernel / fused_lstm_fwd)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int KSX>
+struct LstmFwd2Lds {
+    static constexpr int Hp = 16 * KS, P = Hp / 32;
+    static constexpr int HRS = 64 + 16;           // outgoing tiles [32 rows][32 units] bf16
+    static constexpr int XRS = KSX * 32 + 16;
+    static constexpr int GRS = 4 * 64 + 16;       // KSX = 0: the workgroup's projection rows [32 rows][4 gates x 32 units] bf16
+    static constexpr int O_HIMG = 0;
+    static constexpr int O_HST = O_HIMG + P * 2048;
+    static constexpr int O_XIMG = O_HST + 6 * 32 * HRS;
+    static constexpr int O_CST = O_XIMG + (KSX ? 32 * XRS : 32 * GRS);
+    static constexpr int O_BIAS = O_CST + kFused2MaxChains * 256 * 16;
+    static constexpr int O_FLAG = O_BIAS + 512;
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+template <int KS, int KSX>
+__device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = LstmFwd2Lds<KS, KSX>;
+    static_assert(KS % 2 == 0, "whole 32-unit tiles");
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32;
+    constexpr int ROWB = Hp * 2, HRS = L::HRS, XRS = L::XRS;
+    constexpr int PF = 3;                             // B-fragment read-ahead
+    constexpr int NP1 = FUSED2_SPLIT_TILE ? (P + 3) / 4 : (P + 1) / 2;   // pieces per wave in the first half of the tile (tiles 0 .. 2 NP1 - 1)
+    constexpr int KH = FUSED2_SPLIT_TILE ? 4 * NP1 : KS;                 // ... = k-steps 0 .. KH - 1
+    constexpr int PK = KS / 2;                        // k-step of the look at the next chain-step's flags (two chains)
+    constexpr int INP = KSX ? 16 * KSX : 16, XC = INP / 8;
+    unsigned char* himg = lds + L::O_HIMG;
+    unsigned char* hst = lds + L::O_HST;
+    unsigned char* ximg = lds + L::O_XIMG;
+    float4* cst = reinterpret_cast<float4*>(lds + L::O_CST);
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+    const unsigned himg_lds = (unsigned)(uintptr_t)(lds_ptr_t)himg;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const bf16_t* __restrict__ W = static_cast<const bf16_t*>(R.W);
+
+    // weights -> registers: A-operand row (lane & 31) = gate (row >> 3), unit 32p + 8 wave + (row & 7).  All but the first NWT k-steps'
+    // fragments stay resident; those NWT are fetched again every chain-step (from L2, in front of the flag wait, into registers the cell
+    // update uses later): resident, the compiler spilled exactly these to scratch and reloaded each in front of its MFMA behind an
+    // s_waitcnt vmcnt(0) -- which also waited for the second half of the tile and for the last chain-step's stash stores
+    constexpr int NWT = KS >= 16 ? FUSED2_STREAMED_W : 0;
+    uint4 wreg[KS];
+    const unsigned woff = (unsigned)((((lane & 31) >> 3) * Hp + 32 * p + 8 * wave + (lane & 7)) * Hp + 8 * (lane >> 5)) * 2u;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, (unsigned)((size_t)G4 * Hp * 2));
+    {
+        const int ar = lane & 31;
+        const bf16_t* wrow = W + (size_t)((ar >> 3) * Hp + 32 * p + 8 * wave + (ar & 7)) * Hp + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = NWT; ks < KS; ++ks) { wreg[ks] = gld<uint4>(wrow + 16 * ks); pin(wreg[ks]); }
+    }
+    const int bl = lane & 31, hh = lane >> 5;
+    // the input projection's weight fragments are fetched per chain-step as well, half way through the MFMA chain (they multiply last):
+    // they take the registers the streamed W_hh fragments have left by then
+    uint4 wx[KSX ? KSX : 1];
+    const unsigned wxoff = (unsigned)((((lane & 31) >> 3) * Hp + 32 * p + 8 * wave + (lane & 7)) * INP + 8 * (lane >> 5)) * 2u;
+    const __amdgpu_buffer_rsrc_t rwx = make_rsrc(KSX ? R.Wih : R.W, (unsigned)((size_t)G4 * INP * 2));
+    auto fetch_wx = [&]() {
+        if constexpr (KSX > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rwx, wxoff + 32u * ks, 0, 0);
+                wx[ks] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    if constexpr (KSX > 0) {
+        // bias of accumulator element r of (wave w, lane half h): [w][h][r] in LDS, read back as four float4 per chain-step
+        if (wave < 2) {
+            const int w2 = tid >> 5, h2 = (tid >> 4) & 1, r = tid & 15;
+            reinterpret_cast<float*>(lds + L::O_BIAS)[tid] = gld<float>(R.bias + (r >> 2) * Hp + 32 * p + 8 * w2 + 4 * h2 + (r & 3));
+        }
+    }
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
+    bf16_t* __restrict__ Hs = static_cast<bf16_t*>(R.h);
+    bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c);
+    const bool src_sc1 = R.src_sc1 != 0;   // x / G rows come from a role of this launch: write-through loads
+    const bf16_t* const x_in = static_cast<const bf16_t*>(R.x_in);
+    // B fragment of k-step ks: tile ks >> 1, row bl, chunk 2 (ks & 1) + hh
+    const unsigned char* const bsrc0 = himg + bl * 64 + ((hh ^ img_swz<false>(bl)) * 16);
+    const unsigned char* const bsrc1 = himg + bl * 64 + (((2 + hh) ^ img_swz<false>(bl)) * 16);
+
+    // the five stash arrays of a chain-step (gates i f g o, c; nobody inside the launch waits for them) leave LDS BEHIND the flag: issued
+    // in front of it they sat on the group's critical path (0.9 us a chain-step; behind the next chain-step's tile requests they delayed
+    // the tile's landing by as much)
+    auto stash_stores = [&](const int g, const int t, const int tid) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = tid + 256 * i;   // piece: array e / 128, row (e % 128) / 4, quarter e % 4
+        if (i < 2 || wave < 2) {   // 640 pieces: all threads twice, waves 0 and 1 a third time
+            const int arr = e >> 7, row = (e & 127) >> 2, qt = e & 3, rb = 32 * g + row;
+            const uint4 sv = *reinterpret_cast<const uint4*>(hst + (arr + 1) * 32 * HRS + row * HRS + qt * 16);
+            u32x4 d;
+            d[0] = sv.x; d[1] = sv.y; d[2] = sv.z; d[3] = sv.w;
+            if (i < 2) {   // pieces 0 .. 511: the four gate arrays (128 pieces = 2 waves each); 512 .. 639: c
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+                __builtin_amdgcn_raw_buffer_store_b128(d, rg, rb < Bp ? (unsigned)(((size_t)rb * G4 + arr * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+            } else {
+                const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                __builtin_amdgcn_raw_buffer_store_b128(d, rc, rb < Bp ? (unsigned)(((size_t)rb * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+            }
+        }
+    }
+    };
+    PL_ST_DECL
+    int c = 0, t = 0;
+    bool ready = false;   // the flags of the coming chain-step were seen up during the last one
+    for (;;) {
+        // per-lane_q indices of this chain-step, opaque to the optimizer: derived from plain `tid` every address of the x loads, the staging
+        // image, the stores ... is loop-invariant (one chain), gets hoisted in front of the loop and held in registers the kernel does not
+        // have -- the weight fragments paid for that in scratch.  Recomputing them per chain-step is a few dozen VALU operations.
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lane_q = tq & 63, bl_q = lane_q & 31, hh_q = lane_q >> 5;
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t + 1; }
+        const bool has_next = tn < T;
+        const int gn = set * RC + cn;
+
+        // the streamed weight fragments of this chain-step (they do not depend on anybody's flag)
+#pragma unroll
+        for (int ks = 0; ks < NWT; ++ks) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff + 32u * ks, 0, 0);
+            wreg[ks] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        // 0. what this chain-step waits for (bounded; the barrier inside also closes the last chain-step's LDS reads)
+        if (!ready) {
+            const FlagPoll s0 = step_flags(a, WT_, g, t, p);
+            if (!poll_empty(s0) && !flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        }
+        PL_ST(0);   // wait for the chain-step's flags
+
+        // A. operands: the small x / projection rows into registers, the h tile straight into LDS
+        uint4 xv = make_uint4(0, 0, 0, 0);
+        uint2 gxn[4] = {};
+        uint4 gv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if constexpr (KSX > 0) {
+            if (wave < XC / 2) {   // 32 x XC threads = XC / 2 whole waves: a scalar branch
+                const int row = tq / XC, cc = tq % XC;
+                int rb = 32 * g + row;
+                rb = rb < Bp ? rb : Bp - 1;
+                if (src_sc1) {
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x_in + (size_t)t * Bp * INP, (unsigned)((size_t)Bp * INP * 2));
+                    xv = ld16_sc1(rx, (unsigned)((rb * INP + cc * 8) * 2));
+                } else {
+                    xv = gld<uint4>(x_in + ((size_t)t * Bp + rb) * INP + cc * 8);
+                }
+            }
+        } else {
+            if (src_sc1) {
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = tq + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                    const int rb = 32 * g + row;
+                    gv[q] = ld16_sc1(rg, rb < Bp ? (unsigned)(((size_t)rb * G4 + gate * Hp + 32 * p + 8 * q4) * 2) : kOob);
+                }
+            } else {
+                int b2 = 32 * g + bl_q;
+                b2 = b2 < Bp ? b2 : Bp - 1;
+                const bf16_t* g_row = G + (size_t)t * slabG + (size_t)b2 * G4 + (32 * p + 8 * wave + 4 * hh_q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gxn[q] = gld<uint2>(g_row + q * Hp);
+            }
+        }
+        if (t > 0) {
+            dma_image<P, ROWB, false>(Hs + (size_t)(t - 1) * slabH, g, Bp, himg_lds, wave, lane_q);
+            // the tile in two halves: the first KH k-steps' pieces (a wave's first NP1, and everything older) have landed when all but
+            // its youngest pieces have; the second half lands under the first half's MFMAs
+            if (!FUSED2_SPLIT_TILE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P + 1) / 2 - NP1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P / 2 - NP1 > 0 ? P / 2 - NP1 : 0) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (KSX > 0) {
+            if (wave < XC / 2) *reinterpret_cast<uint4*>(ximg + (tq / XC) * XRS + (tq % XC) * 16) = xv;
+        } else {
+            if (src_sc1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = tq + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                    *reinterpret_cast<uint4*>(ximg + row * L::GRS + gate * 64 + q4 * 16) = gv[q];
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (KSX == 0) {
+            if (src_sc1) {
+                const unsigned char* gsrc = ximg + bl_q * L::GRS + (8 * wave + 4 * hh_q) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const uint2*>(gsrc + q * 64);
+            }
+        }
+
+        PL_ST(1);   // operands: issue -> landed -> barrier
+        // B. with a second chain: a look at ITS flags from inside the MFMA chain (with one chain the next chain-step waits for the
+        // flag this one raises at its end)
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr, 0};
+        const bool look = has_next && Ca > 1;
+        if (look) pn = step_flags(a, WT_, gn, tn, p);
+        int pv = 1;
+        const bool poll_here = wave == 0 && look;
+
+        // C. gates = W_hh h_{t-1} (+ W_ih x_t + b)
+        f32x16 acc;
+        if constexpr (KSX > 0) {
+            const float4* bs = reinterpret_cast<const float4*>(lds + L::O_BIAS) + (wave * 2 + hh_q) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 bv = bs[i];
+                acc[4 * i] = bv.x; acc[4 * i + 1] = bv.y; acc[4 * i + 2] = bv.z; acc[4 * i + 3] = bv.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        if (t > 0) {
+            uint4 bq[PF];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                constexpr int K0[2] = {0, KH}, K1[2] = {KH, KS};
+                if (half == 1 && K0[1] < K1[1]) {   // the second half of the tile
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                if (half == 1) fetch_wx();
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (K0[half] + i < K1[half]) bq[i] = *reinterpret_cast<const uint4*>((((K0[half] + i) & 1) ? bsrc1 : bsrc0) + ((K0[half] + i) >> 1) * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = K0[half]; ks < K1[half]; ++ks) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks]), __builtin_bit_cast(bf16x8, bq[(ks - K0[half]) % PF]), acc, 0, 0, 0);
+                    if (ks + PF < K1[half])
+                        bq[(ks - K0[half]) % PF] = *reinterpret_cast<const uint4*>((((ks + PF) & 1) ? bsrc1 : bsrc0) + ((ks + PF) >> 1) * 2048);
+                    if (ks == PK && poll_here) pv = poll_load(pn, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            fetch_wx();
+            if (poll_here) pv = poll_load(pn, lane);
+        }
+        if constexpr (KSX > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                const uint4 xb = *reinterpret_cast<const uint4*>(ximg + bl_q * XRS + ks * 32 + hh_q * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wx[ks]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+            }
+        }
+        PL_ST(2);   // MFMA chain
+        if (wave == 0) {   // the look's answer, handed to everybody behind the barrier of the output staging
+            const bool rdy = look && __all(pv != 0);
+            if (lane_q == 0) lflag[0] = rdy ? 1 : 0;
+        }
+
+        // F. cell update: acc[4 * gate + unit], two units at a time (the six outputs of a pair leave for the staging image before the next
+        // pair is touched: all four at once kept 24 outputs + 16 widened inputs alive on top of the accumulators, and the weight
+        // fragments paid for it in scratch)
+        // G. the h tile (hand-off) and the five stash arrays leave through LDS as whole 64-byte row pieces
+        {
+            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t > 0) cs = cst[c * 256 + tq];
+            float c_state[4] = {cs.x, cs.y, cs.z, cs.w};
+            unsigned char* o = hst + bl_q * HRS + (8 * wave + 4 * hh_q) * 2;
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const unsigned xi = u2 ? gxn[0].y : gxn[0].x, xf = u2 ? gxn[1].y : gxn[1].x, xg = u2 ? gxn[2].y : gxn[2].x, xo = u2 ? gxn[3].y : gxn[3].x;
+                float vi[2], vf[2], vg[2], vo[2], vh[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int u = 2 * u2 + k;
+                    vi[k] = sigmoid_fast(acc[u] + bf16_lo_hi(xi, k));
+                    vf[k] = sigmoid_fast(acc[4 + u] + bf16_lo_hi(xf, k));
+                    vg[k] = tanh_fast(acc[8 + u] + bf16_lo_hi(xg, k));
+                    vo[k] = sigmoid_fast(acc[12 + u] + bf16_lo_hi(xo, k));
+                    c_state[u] = cell_c(vf[k], c_state[u], vi[k], vg[k]);
+                    vh[k] = vo[k] * tanh_fast(c_state[u]);
+                }
+                *reinterpret_cast<unsigned*>(o + 4 * u2) = pack_bf16x2(vh[0], vh[1]);
+                *reinterpret_cast<unsigned*>(o + 4 * u2 + 32 * HRS) = pack_bf16x2(vi[0], vi[1]);
+                *reinterpret_cast<unsigned*>(o + 4 * u2 + 2 * 32 * HRS) = pack_bf16x2(vf[0], vf[1]);
+                *reinterpret_cast<unsigned*>(o + 4 * u2 + 3 * 32 * HRS) = pack_bf16x2(vg[0], vg[1]);
+                *reinterpret_cast<unsigned*>(o + 4 * u2 + 4 * 32 * HRS) = pack_bf16x2(vo[0], vo[1]);
+                *reinterpret_cast<unsigned*>(o + 4 * u2 + 5 * 32 * HRS) = pack_bf16x2(c_state[2 * u2], c_state[2 * u2 + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cst[c * 256 + tq] = make_float4(c_state[0], c_state[1], c_state[2], c_state[3]);
+        }
+        __syncthreads();
+        PL_ST(3);   // cell update, staging, barrier
+        ready = lflag[0] != 0;
+        if (wave < 2) {
+            const int row = tq >> 2, qt = tq & 3;
+            const int rb = 32 * g + row;
+            const uint4 hvv = *reinterpret_cast<const uint4*>(hst + row * HRS + qt * 16);
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+            st16_sc1(ro, rb < Bp ? (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2) : kOob, hvv);
+        }
+        PL_ST(4);   // hand-off store issue
+        raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);   // only the hand-off is in flight: the stash stores follow the flag
+        PL_ST(5);   // drain + barrier + flag
+        stash_stores(g, t, tq);
+        PL_ST(6);   // stash store issue (behind the flag: they drain under the next wait)
+        if (!has_next) break;
+        c = cn;
+        t = tn;
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row-tile products on a producing layer's h (arithmetic of gemm_nt_kernel / fused_gemm_fwd): the input projection of the
+// layer above (G_t = h_t Wih^T + b, bf16) and the mel head with its pooling
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+struct GemmFwd2Lds {
+    static constexpr int Hp = 16 * KS, P = Hp / 32;
+    static constexpr int ORS = 128 * 2 + 16;
+    static constexpr int O_IMG = 0;
+    static constexpr int O_OST = O_IMG + P * 2048;
+    static constexpr int O_YB = O_OST + 32 * ORS;
+    static constexpr int O_FLAG = O_YB + kFused2MaxChains * 256 * 32;
+    static constexpr int BYTES = O_FLAG + 64;
+};
+
+template <int KS, bool HEAD>
+__device__ __forceinline__ void fused_gemm_fwd2(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
+    using L = GemmFwd2Lds<KS>;
+    static_assert(KS % 2 == 0, "whole 32-unit tiles");
+    constexpr int Hp = 16 * KS, KB = KS / 2, P = Hp / 32, ORS = L::ORS, ROWB = Hp * 2;
+    constexpr int NJ = HEAD ? 1 : 2;
+    constexpr int PF = 2;
+    unsigned char* img = lds + L::O_IMG;
+    unsigned char* ost = lds + L::O_OST;
+    float4* yb = reinterpret_cast<float4*>(lds + L::O_YB);
+    int* lflag = reinterpret_cast<int*>(lds + L::O_FLAG);
+    const unsigned img_lds = (unsigned)(uintptr_t)(lds_ptr_t)img;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int Bp = a.Bp, T = R.T, RC = R.C;
+    int* const rflags = R.flags;
+    const Waits WT_{R.wait[0], R.wait[1], R.wait[2]};
+    int Ca = a.n_groups - set * RC;
+    Ca = Ca < RC ? Ca : RC;
+    if (Ca <= 0) return;
+    const int G4 = 4 * Hp;   // PROJ: gate columns of the consuming layer (same hidden size)
+    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(R.Wg);
+    uint4 wreg[NJ][KB];
+    float bias_v[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int col = HEAD ? 16 * wave + lr : wave * Hp + 32 * p + 16 * jj + lr;
+        const bf16_t* wrow = Wg + (size_t)col * Hp + 8 * kq;
+#pragma unroll
+        for (int n = 0; n < KB; ++n) { wreg[jj][n] = gld<uint4>(wrow + 32 * n); pin(wreg[jj][n]); }
+        bias_v[jj] = R.bias ? gld<float>(R.bias + col) : 0.f;
+    }
+    const size_t slabH = (size_t)Bp * Hp;
+    const bf16_t* __restrict__ Hsrc = static_cast<const bf16_t*>(R.src_h);
+    const int out_dim = R.out_dim;
+    float* const out_bm = R.out_bm;
+    void* const out_ptr = R.out;
+    // A fragment of k-step n (32 columns = tile n): rows lr and 16 + lr (same permutation: (row >> 2) & 3 agrees), chunk kq
+    const unsigned char* const a0 = img + lr * 64 + ((kq ^ img_swz<true>(lr)) * 16);
+    const unsigned char* const a1 = a0 + 16 * 64;
+
+    int c = 0, t = 0;
+    bool ready = false;
+    for (;;) {
+        const int g = set * RC + c;
+        int cn = c + 1, tn = t;
+        if (cn == Ca) { cn = 0; tn = t + 1; }
+        const bool has_next = tn < T;
+        const int gn = set * RC + cn;
+
+        if (!ready) {
+            const FlagPoll s0 = step_flags(a, WT_, g, t, p);
+            if (!flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
+        }
+        dma_image<P, ROWB, true>(Hsrc + (size_t)t * slabH, g, Bp, img_lds, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        FlagPoll pn{nullptr, 0, nullptr, 0, nullptr, 0};
+        if (has_next) pn = step_flags(a, WT_, gn, tn, p);
+        int pv = 1;
+        const bool poll_here = wave == 0 && has_next;
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x4 acc[2][NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            uint4 f0[PF], f1[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < KB) {
+                    f0[i] = *reinterpret_cast<const uint4*>(a0 + i * 2048);
+                    f1[i] = *reinterpret_cast<const uint4*>(a1 + i * 2048);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < KB; ++n) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[n % PF]), __builtin_bit_cast(bf16x8, wreg[jj][n]), acc[0][jj], 0, 0, 0);
+                    acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[n % PF]), __builtin_bit_cast(bf16x8, wreg[jj][n]), acc[1][jj], 0, 0, 0);
+                }
+                if (n + PF < KB) {
+                    f0[n % PF] = *reinterpret_cast<const uint4*>(a0 + (n + PF) * 2048);
+                    f1[n % PF] = *reinterpret_cast<const uint4*>(a1 + (n + PF) * 2048);
+                }
+                if (n == KB / 2 && poll_here) pv = poll_load(pn, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wave == 0) {   // the answer is read behind the barrier of the output staging
+            const bool rdy = has_next && __all(pv != 0);
+            if (lane == 0) lflag[0] = rdy ? 1 : 0;
+        }
+
+        // epilogue: D[row 16 i + 4 kq + r][column 16 jj + lr (of this wave's columns)]
+        if constexpr (!HEAD) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<bf16_t*>(ost + (16 * i + 4 * kq + r) * ORS + (32 * wave + 16 * jj + lr) * 2) = (bf16_t)(acc[i][jj][r] + bias_v[jj]);
+            __syncthreads();
+            ready = lflag[0] != 0;
+            bf16_t* Gout = static_cast<bf16_t*>(out_ptr);
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(Gout + (size_t)t * Bp * G4, (unsigned)((size_t)Bp * G4 * 2));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                const int rb = 32 * g + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(ost + row * ORS + (32 * gate + 8 * q4) * 2);
+                st16_sc1(ro, rb < Bp ? (unsigned)(((size_t)rb * G4 + gate * Hp + 32 * p + 8 * q4) * 2) : kOob, v);
+            }
+            raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);
+        } else {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[4 * i + r] = acc[i][0][r] + bias_v[0];
+            if ((t & 1) == 0) {   // even frame: kept for its partner
+                yb[(c * 256 + tid) * 2] = make_float4(y[0], y[1], y[2], y[3]);
+                yb[(c * 256 + tid) * 2 + 1] = make_float4(y[4], y[5], y[6], y[7]);
+                __syncthreads();   // the image is rewritten at the top of the next chain-step
+                ready = lflag[0] != 0;
+            } else {
+                const float4 e0 = yb[(c * 256 + tid) * 2], e1 = yb[(c * 256 + tid) * 2 + 1];
+                const float ye[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                const int tp = t >> 1, Tp = T >> 1, col = 16 * wave + lr;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * kq + r, bb = 32 * g + row;
+                        const bool live = bb < a.B && col < out_dim;
+                        const float v = live ? 0.5f * (ye[4 * i + r] + y[4 * i + r]) : 0.f;
+                        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(out_bm, (unsigned)((size_t)a.B * Tp * out_dim * 4));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rb_, live ? (unsigned)((((size_t)bb * Tp + tp) * out_dim + col) * 4) : kOob, 0, 0);
+                        *reinterpret_cast<bf16_t*>(ost + row * ORS + col * 2) = (bf16_t)v;
+                    }
+                __syncthreads();
+                ready = lflag[0] != 0;
+                {   // pooled frame, time-major activation [tp][Bp][64]: the input of the embedder's first layer (hand-off)
+                    const int row = tid >> 3, q8 = tid & 7, rb = 32 * g + row;
+                    bf16_t* Mout = static_cast<bf16_t*>(out_ptr);
+                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(Mout + (size_t)tp * Bp * 64, (unsigned)((size_t)Bp * 64 * 2));
+                    const uint4 v = *reinterpret_cast<const uint4*>(ost + row * ORS + q8 * 16);
+                    st16_sc1(ro, rb < Bp ? (unsigned)((rb * 64 + 8 * q8) * 2) : kOob, v);
+                }
+                raise_flag<0>(rflags + ((size_t)g * Tp + tp) * a.flag_stride);
+            }
+        }
+        if (!has_next) break;
+        c = cn;
+        t = tn;
+    }
+}
+
+template <int KS>
+constexpr int fused_fwd2_lds_bytes() {
+    int m = LstmFwd2Lds<KS, 0>::BYTES;
+    m = m > LstmFwd2Lds<KS, 2>::BYTES ? m : LstmFwd2Lds<KS, 2>::BYTES;
+    m = m > LstmFwd2Lds<KS, 4>::BYTES ? m : LstmFwd2Lds<KS, 4>::BYTES;
+    m = m > GemmFwd2Lds<KS>::BYTES ? m : GemmFwd2Lds<KS>::BYTES;
+    return (m + 15) / 16 * 16;
+}
+
+template <int KS>
+__device__ __forceinline__ void fused_fwd2_role(const FusedArgs& a, const FusedRole& R, int set, int p, unsigned char* lds) {
+    switch (R.type) {
+        case FR_LSTM_FWD:
+            if (R.ksx == 2) fused_lstm_fwd2<KS, 2>(a, R, set, p, lds);
+            else if (R.ksx == 4) fused_lstm_fwd2<KS, 4>(a, R, set, p, lds);
+            else fused_lstm_fwd2<KS, 0>(a, R, set, p, lds);
+            break;
+        case FR_PROJ_FWD: fused_gemm_fwd2<KS, false>(a, R, set, p, lds); break;
+        case FR_HEAD_FWD: fused_gemm_fwd2<KS, true>(a, R, set, p, lds); break;
+        default: break;
+    }
+}
+
+template <int KSP, int KSE>
+__global__ __launch_bounds__(256, 2) void fused_fwd2_kernel(FusedArgs a) {
+    constexpr int kLds = fused_fwd2_lds_bytes<KSP>() > fused_fwd2_lds_bytes<KSE>() ? fused_fwd2_lds_bytes<KSP>() : fused_fwd2_lds_bytes<KSE>();
+    static_assert(kLds <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    if ((int)blockIdx.x >= a.grid) return;
+    const PL_GLOBAL short* bt = (const PL_GLOBAL short*)(a.block_tab + 4 * blockIdx.x);
+    const int role = __builtin_amdgcn_readfirstlane((int)bt[0]), set = __builtin_amdgcn_readfirstlane((int)bt[1]),
+              p = __builtin_amdgcn_readfirstlane((int)bt[2]);
+    if (role < 0 || role >= a.n_roles) return;
+    if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    const FusedRole R = uniform_role(a.roles[role]);
+    const int set_step = a.gpp > 0 ? uni(a.gpp / R.C) : 0;   // passes: as in fused_fwd_kernel
+    for (int s2 = set;; s2 += set_step) {
+        if constexpr (KSP == KSE) {
+            fused_fwd2_role<KSE>(a, R, s2, p, lds);
+        } else {
+            if (R.wide) fused_fwd2_role<KSE>(a, R, s2, p, lds);
+            else fused_fwd2_role<KSP>(a, R, s2, p, lds);
+        }
+        if (set_step <= 0 || (s2 + set_step) * R.C >= a.n_groups) break;
+        __syncthreads();
+        if (uni(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+    }
+}
+
+}  // namespace
+
+#define PL_FUSED_FWD2_PAIRS(X) X(46, 46)
+
+bool fused_fwd2_supported(int Hp_pred, int Hp_emb) {
+#define PL_CASE(KP, KE) if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) return true;
+    PL_FUSED_FWD2_PAIRS(PL_CASE)
+#undef PL_CASE
+    return false;
+}
+
+void launch_fused_fwd2(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a) {
+#define PL_CASE(KP, KE)                                                                               \
+    if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) {                                                    \
+        hipLaunchKernelGGL((fused_fwd2_kernel<KP, KE>), dim3(a.grid), dim3(256), 0, stream, a);       \
+        return;                                                                                       \
+    }
+    PL_FUSED_FWD2_PAIRS(PL_CASE)
+#undef PL_CASE
+}
+
+}  // namespace pl

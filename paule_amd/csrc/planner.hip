@@ -256,6 +256,8 @@ struct pl_handle {
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
     int fused_grid_fwd = 0;
     bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
+    int fused_occ2 = 0;          // PAULE_HIP_FUSED_OCC2: the forward launch at two workgroups per CU (lstm_fused2.hip) where the shape has it
+    bool fused_fwd2 = false;     // ... and the plan took it: the role table holds up to 2 n_cu workgroups
     bool fused_rows16 = false;  // batches of up to 16 rows: the LSTM roles of both launches run on 16-row tiles (lstm_fused16.h)
     void* fused_hx[kFusedMaxRoles] = {};        // rows16: the forward LSTM roles' own copies of their h hand-off [2][16][Hp]
     void* fused_dh_pred[4] = {};                // stacked predictor in the backward launch: dL/dh rows of layer l < L - 1 (written by the product role of layer l + 1)
@@ -1339,6 +1341,7 @@ std::vector<short> fused_block_table(int n_cu, const std::vector<FusedSet>& sets
 // chain-step keeps a workgroup busy ~2.1 us, a group's own step-to-step latency is ~4.2 us; the embedder has half the steps.
 int plan_fused(pl_handle* h) {
     h->fused_fwd_ok = h->fused_bwd_ok = false;
+    h->fused_fwd2 = false;
     // bit 0: fused forward launch, bit 1: fused backward launch.  Measured (profiles/r02_ab_fused_range.txt): up to 128 rows both
     // win (B = 64: 4.53 -> 3.33 ms per iteration, T = 2000: 30.4 -> 21.3; one or two chains per workgroup, the roles overlap and the
     // step latency hides); from 129 rows on the backward launch needs 2 - 4 chains per workgroup, its chain-step is bound by the
@@ -1392,6 +1395,9 @@ int plan_fused(pl_handle* h) {
         if (lstm_f + prod_f > h->n_cu) return PL_OK;   // forward and backward launch have the same counts
         best_cp = best_ce = 1;
     }
+    // forward launch at two workgroups per CU (lstm_fused2.hip): twice the workgroup slots, one or two chains a workgroup
+    const bool occ2 = h->fused_occ2 && !rows16 && (mode & 1) && fwd_shape && fused_fwd2_supported(p.Hp, e.Hp);
+    const int fwd_slots = occ2 ? 2 * h->n_cu : h->n_cu;
     int ngf = ng;   // groups the role table is planned for
     // PAULE_HIP_FUSED_GPP=n: the forward launch in PASSES of n groups (lstm_fused.hip: fused_fwd_kernel walks every role over its sets pass
     // after pass) -- built in round 4 for batches of more groups than the roles hold at once (VERDICT r3 missing #5: cfg4's 2048 rows on one
@@ -1410,14 +1416,17 @@ int plan_fused(pl_handle* h) {
         const int cmax = ((mode & 2) && h->bwd_mode == 1) ? 4 : kFusedMaxChains;   // the backward roles have LDS for 4 chains (lstm_fused.hip)
         for (int cp = 1; cp <= cmax; ++cp)
             for (int ce = 1; ce <= cmax; ++ce) {
+                if (occ2 && (cp > 2 || ce > 2)) continue;   // kFused2MaxChains
                 if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
                 if (ngf != ng && (ngf % cp || ngf % ce)) continue;   // passes: whole sets only
                 const int sp = (ngf + cp - 1) / cp, se = (ngf + ce - 1) / ce;
                 // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward: the
                 // predictor's roles, the embedder's, one head workgroup per embedder set
-                if ((mode & 1) && sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > h->n_cu) continue;
+                if ((mode & 1) && sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > fwd_slots) continue;
                 if ((mode & 2) && sp * Pp * n_pred_roles + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
-                const double tp = std::max(cp * 2.1, 4.2), te = std::max(ce * 2.1, 4.2) / 2.0;
+                // two per CU: nothing of a chain-step hides behind the workgroup's other chain (the CU's other workgroup covers it): a
+                // group's step takes the whole chain-step of every chain
+                const double tp = occ2 ? cp * 5.0 : std::max(cp * 2.1, 4.2), te = (occ2 ? ce * 5.0 : std::max(ce * 2.1, 4.2)) / 2.0;
                 const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
                 if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
             }
@@ -1442,9 +1451,10 @@ int plan_fused(pl_handle* h) {
             for (int s = 0; s < se; ++s) sets.push_back({fr_emb_proj(p.L, l), s, Pe, false});
         for (int s = 0; s < sp; ++s) sets.push_back({fr_head(p.L), s, 1, false});
         int grid = 0;
-        std::vector<short> tab = fused_block_table(h->n_cu, sets, &grid);
-        if (grid > 0 && grid <= h->n_cu) {
-            if ((rc = dev_alloc(h, &h->fused_tab_fwd, (size_t)h->n_cu * 4))) return rc;
+        std::vector<short> tab = fused_block_table(fwd_slots, sets, &grid);
+        if (grid > 0 && grid <= fwd_slots) {
+            h->fused_fwd2 = occ2;
+            if ((rc = dev_alloc(h, &h->fused_tab_fwd, (size_t)fwd_slots * 4))) return rc;
             PL_HIP(hipMemcpyAsync(h->fused_tab_fwd, tab.data(), sizeof(short) * (size_t)grid * 4, hipMemcpyHostToDevice, h->stream));
             PL_HIP(hipStreamSynchronize(h->stream));   // tab is a local
             h->fused_grid_fwd = grid;
@@ -1712,6 +1722,7 @@ bool fused_acoustic_forward(pl_handle* h, hipStream_t st) {
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_fwd, h->fused_tab_fwd, h->fused_roles_fwd, false);
     if (h->fused_rows16) launch_fused_fwd16(st, h->pred.Hp, h->emb.Hp, a);
+    else if (h->fused_fwd2) launch_fused_fwd2(st, h->pred.Hp, h->emb.Hp, a);
     else launch_fused_fwd(st, h->pred.Hp, h->emb.Hp, a);
     return true;
 }
@@ -2143,6 +2154,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_XCD")) h->fused_xcd = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_FUSED_OCC2")) h->fused_occ2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;

@@ -513,6 +513,27 @@ def test_fused_forward_in_passes_is_bit_identical(HipPlanner, monkeypatch, shape
     monkeypatch.delenv("PAULE_HIP_FUSED_GPP")
 
 
+@pytest.mark.parametrize("shape", [dict(B=256, T=300, graph=True), dict(B=144, T=61, graph=False),
+                                   dict(B=80, T=33, graph=True, chains=dict(PAULE_HIP_FUSED_CP="2", PAULE_HIP_FUSED_CE="2"))])
+def test_fused_forward_two_per_cu_is_bit_identical(HipPlanner, monkeypatch, shape):
+    """Round 4: the forward launch written for TWO workgroups per CU (lstm_fused2.hip: 256 registers, 80 KB of LDS, the h tile straight
+    into LDS by LDS-DMA in a layout permuted for conflict-free operand reads, role table planned for 2 x n_cu slots) computes what the
+    per-layer sweeps and GEMMs compute, bit for bit: every forward stash, the pooled mel, losses and the plan.  cfg3's shape under a
+    graph, a ragged batch (last group of 16 rows), two chains per workgroup with an odd number of groups."""
+    B, T, H = shape["B"], shape["T"], 720
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    env = dict(PAULE_HIP_FUSED_OCC2="1", **(shape.get("chains") or {}))
+    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, env)
+    for name in FWD_BUFFERS:
+        np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
+    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, shape["graph"], env)
+    np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
+    np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
+    monkeypatch.delenv("PAULE_HIP_FUSED_OCC2")
+
+
 @pytest.mark.parametrize("shape", [dict(B=256, T=60, graph=True), dict(B=70, T=31, graph=False)])
 def test_fused_forward_stacked_predictor_is_bit_identical(HipPlanner, monkeypatch, shape):
     """Round 3: the fused forward launch takes the class-default STACKED predictor (4 x 180, paule/models.py:335-339) in front of
