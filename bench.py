@@ -451,7 +451,7 @@ def main():
                          "fwd_kernel_avg_launch_us": ms_f * 1e3,
                          "fwd_kernel_achieved": fl_f / (ms_f * 1e-3) / 1e12,
                          "fused_fwd_kernel": None if fused is None else {
-                             "kernel": "fused_fwd16_kernel" if plan.get("fused_rows") == 16 else "fused_fwd_kernel",
+                             "kernel": "fused_fwd16_kernel" if plan.get("fused_rows") == 16 else ("fused_fwd2_kernel" if plan.get("fwd_per_cu") == 2 else "fused_fwd_kernel"),
                              "avg_launch_us": fused[0] * 1e3, "flops_per_launch": fused[1],
                              "achieved": fused[1] / (fused[0] * 1e-3) / 1e12, "frac": fused[1] / (fused[0] * 1e-3) / 1e12 / peak}},
         }

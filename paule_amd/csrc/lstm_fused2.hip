@@ -126,7 +126,9 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
         const int ar = lane & 31;
         const bf16_t* wrow = W + (size_t)((ar >> 3) * Hp + 32 * p + 8 * wave + (ar & 7)) * Hp + 8 * (lane >> 5);
 #pragma unroll
-        for (int ks = NWT; ks < KS; ++ks) { wreg[ks] = gld<uint4>(wrow + 16 * ks); pin(wreg[ks]); }
+        for (int ks = NWT; ks < KS; ++ks) wreg[ks] = gld<uint4>(wrow + 16 * ks);
+#pragma unroll
+        for (int ks = NWT; ks < KS; ++ks) pin(wreg[ks]);   // pinned after ALL loads are out: load + pin in one loop waited for every load by itself
     }
     const int bl = lane & 31, hh = lane >> 5;
     // the input projection's weight fragments are fetched per chain-step as well, half way through the MFMA chain (they multiply last):
@@ -436,9 +438,13 @@ __device__ __forceinline__ void fused_gemm_fwd2(const FusedArgs& a, const FusedR
         const int col = HEAD ? 16 * wave + lr : wave * Hp + 32 * p + 16 * jj + lr;
         const bf16_t* wrow = Wg + (size_t)col * Hp + 8 * kq;
 #pragma unroll
-        for (int n = 0; n < KB; ++n) { wreg[jj][n] = gld<uint4>(wrow + 32 * n); pin(wreg[jj][n]); }
+        for (int n = 0; n < KB; ++n) wreg[jj][n] = gld<uint4>(wrow + 32 * n);
         bias_v[jj] = R.bias ? gld<float>(R.bias + col) : 0.f;
     }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int n = 0; n < KB; ++n) pin(wreg[jj][n]);
     const size_t slabH = (size_t)Bp * Hp;
     const bf16_t* __restrict__ Hsrc = static_cast<const bf16_t*>(R.src_h);
     const int out_dim = R.out_dim;
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd2_kernel(FusedArgs a) {
 
 }  // namespace
 
-#define PL_FUSED_FWD2_PAIRS(X) X(46, 46)
+#define PL_FUSED_FWD2_PAIRS(X) X(6, 6) X(46, 46) X(12, 46)
 
 bool fused_fwd2_supported(int Hp_pred, int Hp_emb) {
 #define PL_CASE(KP, KE) if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) return true;

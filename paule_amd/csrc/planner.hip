@@ -256,7 +256,7 @@ struct pl_handle {
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
     int fused_grid_fwd = 0;
     bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
-    int fused_occ2 = 0;          // PAULE_HIP_FUSED_OCC2: the forward launch at two workgroups per CU (lstm_fused2.hip) where the shape has it
+    int fused_occ2 = -1;         // PAULE_HIP_FUSED_OCC2: the forward launch at two workgroups per CU (lstm_fused2.hip): 1 wherever the shape has it, 0 never, -1 (default) where it wins (plan_fused)
     bool fused_fwd2 = false;     // ... and the plan took it: the role table holds up to 2 n_cu workgroups
     bool fused_rows16 = false;  // batches of up to 16 rows: the LSTM roles of both launches run on 16-row tiles (lstm_fused16.h)
     void* fused_hx[kFusedMaxRoles] = {};        // rows16: the forward LSTM roles' own copies of their h hand-off [2][16][Hp]
@@ -1386,7 +1386,6 @@ int plan_fused(pl_handle* h) {
     int forced_p = 0, forced_e = 0;
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CP")) forced_p = std::atoi(z);
     if (const char* z = std::getenv("PAULE_HIP_FUSED_CE")) forced_e = std::atoi(z);
-    double best_cost = 1e30;
     int best_cp = 0, best_ce = 0;
     const int ng16 = h->Bp / 16;
     const int ng_all = ng;
@@ -1395,9 +1394,8 @@ int plan_fused(pl_handle* h) {
         if (lstm_f + prod_f > h->n_cu) return PL_OK;   // forward and backward launch have the same counts
         best_cp = best_ce = 1;
     }
-    // forward launch at two workgroups per CU (lstm_fused2.hip): twice the workgroup slots, one or two chains a workgroup
-    const bool occ2 = h->fused_occ2 && !rows16 && (mode & 1) && fwd_shape && fused_fwd2_supported(p.Hp, e.Hp);
-    const int fwd_slots = occ2 ? 2 * h->n_cu : h->n_cu;
+    bool occ2 = false;           // the forward launch at two workgroups per CU (lstm_fused2.hip): decided below
+    int fwd_slots = h->n_cu;
     int ngf = ng;   // groups the role table is planned for
     // PAULE_HIP_FUSED_GPP=n: the forward launch in PASSES of n groups (lstm_fused.hip: fused_fwd_kernel walks every role over its sets pass
     // after pass) -- built in round 4 for batches of more groups than the roles hold at once (VERDICT r3 missing #5: cfg4's 2048 rows on one
@@ -1408,28 +1406,46 @@ int plan_fused(pl_handle* h) {
         const int gf = std::atoi(z);
         if (gf > 0 && gf < ng && !rows16 && (mode & 1)) { ngf = gf; mode &= ~2; }
     }
-    for (int attempt = 0; attempt < 2 && !best_cp; ++attempt) {
-        if (attempt == 1) {   // both launches do not fit the chip at this batch: the forward launch alone (unless the mode was asked for)
-            if (mode_forced || rows16 || (mode & 3) != 3) break;
-            mode &= ~2;
-        }
+    // chain counts for `slots` forward workgroup slots; o2: the two-per-CU forward launch (one or two chains a workgroup)
+    auto search = [&](bool o2, int slots, int& bcp, int& bce) {
+        double bcost = 1e30;
+        bcp = bce = 0;
         const int cmax = ((mode & 2) && h->bwd_mode == 1) ? 4 : kFusedMaxChains;   // the backward roles have LDS for 4 chains (lstm_fused.hip)
         for (int cp = 1; cp <= cmax; ++cp)
             for (int ce = 1; ce <= cmax; ++ce) {
-                if (occ2 && (cp > 2 || ce > 2)) continue;   // kFused2MaxChains
+                if (o2 && (cp > 2 || ce > 2)) continue;   // kFused2MaxChains (lstm_fused2.hip)
                 if ((forced_p && cp != forced_p) || (forced_e && ce != forced_e)) continue;
                 if (ngf != ng && (ngf % cp || ngf % ce)) continue;   // passes: whole sets only
                 const int sp = (ngf + cp - 1) / cp, se = (ngf + ce - 1) / ce;
                 // forward: the predictor's roles + one head workgroup per predictor set + the embedder's roles; backward: the
                 // predictor's roles, the embedder's, one head workgroup per embedder set
-                if ((mode & 1) && sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > fwd_slots) continue;
+                if ((mode & 1) && sp * (Pp * n_pred_roles + 1) + se * Pe * n_emb_roles > slots) continue;
                 if ((mode & 2) && sp * Pp * n_pred_roles + se * (1 + Pe * n_emb_roles) > h->n_cu) continue;
                 // two per CU: nothing of a chain-step hides behind the workgroup's other chain (the CU's other workgroup covers it): a
                 // group's step takes the whole chain-step of every chain
-                const double tp = occ2 ? cp * 5.0 : std::max(cp * 2.1, 4.2), te = (occ2 ? ce * 5.0 : std::max(ce * 2.1, 4.2)) / 2.0;
+                const double tp = o2 ? cp * 5.0 : std::max(cp * 2.1, 4.2), te = (o2 ? ce * 5.0 : std::max(ce * 2.1, 4.2)) / 2.0;
                 const double cost = std::max(tp, te) + 1e-3 * (cp + ce);
-                if (cost < best_cost) { best_cost = cost; best_cp = cp; best_ce = ce; }
+                if (cost < bcost) { bcost = cost; bcp = cp; bce = ce; }
             }
+    };
+    for (int attempt = 0; attempt < 2 && !best_cp; ++attempt) {
+        if (attempt == 1) {   // both launches do not fit the chip at this batch: the forward launch alone (unless the mode was asked for)
+            if (mode_forced || rows16 || (mode & 3) != 3) break;
+            mode &= ~2;
+        }
+        search(false, h->n_cu, best_cp, best_ce);
+    }
+    // Two workgroups per CU for the forward launch (lstm_fused2.hip; PAULE_HIP_FUSED_OCC2 = 1 / 0 forces / forbids).  By itself only where it
+    // was measured to win: a forward launch alone (129 rows and more, equal widths), seven groups and more, the predictor on ONE chain per
+    // workgroup -- 224 / 240 / 256 rows x 300 frames: 5.14 -> 5.01, 5.15 -> 5.01, 5.22 -> 5.04 ms per iteration; 160 / 192 rows, where the
+    // one-per-CU plan already has one or two chains: 4.57 -> 4.61, 4.65 -> 4.70; with the backward launch in the plan (up to 128 rows, model
+    // set B) the two launches share their chain counts, and two chains at most cost the backward launch more than the forward one gains
+    // (profiles/r04_ab_fused_occ2.txt)
+    if (!rows16 && (mode & 1) && fwd_shape && fused_fwd2_supported(p.Hp, e.Hp) &&
+        (h->fused_occ2 > 0 || (h->fused_occ2 < 0 && !(mode & 2) && ngf == ng && ng >= 7))) {
+        int cp2 = 0, ce2 = 0;
+        search(true, 2 * h->n_cu, cp2, ce2);
+        if (cp2 && (h->fused_occ2 > 0 || cp2 == 1)) { occ2 = true; fwd_slots = 2 * h->n_cu; best_cp = cp2; best_ce = ce2; }
     }
     if (!best_cp) return PL_OK;
     h->fused_gpp = ngf != ng_all ? ngf : 0;
@@ -3111,6 +3127,7 @@ int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
         h->n_cu,
         g_retained_branched_execs.load(std::memory_order_relaxed),
         h->fused_rows16 ? 16 : ((h->fused_fwd_ok || h->fused_bwd_ok) ? 32 : 0),
+        h->fused_fwd_ok ? (h->fused_fwd2 ? 2 : 1) : 0,
     };
     for (int i = 0; i < n && i < PL_PLAN_COUNT; ++i) out[i] = v[i];
     for (int i = PL_PLAN_COUNT; i < n; ++i) out[i] = 0;

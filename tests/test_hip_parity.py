@@ -477,8 +477,10 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     rows, fewer groups than chains), odd T, a one-group-per-workgroup table."""
     B, T, H = shape["B"], shape["T"], shape["H"]
     wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    monkeypatch.setenv("PAULE_HIP_FUSED_OCC2", "0")   # this test is lstm_fused.hip's (one workgroup per CU); the two-per-CU launch has its own below
     monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, shape.get("chains"))
+    assert e["1"].plan_info()["fwd_per_cu"] == 1
     for name in FWD_BUFFERS:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
     monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
@@ -513,19 +515,28 @@ def test_fused_forward_in_passes_is_bit_identical(HipPlanner, monkeypatch, shape
     monkeypatch.delenv("PAULE_HIP_FUSED_GPP")
 
 
-@pytest.mark.parametrize("shape", [dict(B=256, T=300, graph=True), dict(B=144, T=61, graph=False),
-                                   dict(B=80, T=33, graph=True, chains=dict(PAULE_HIP_FUSED_CP="2", PAULE_HIP_FUSED_CE="2"))])
+@pytest.mark.parametrize("shape", [dict(B=256, T=300, H=720, graph=True), dict(B=144, T=61, H=720, graph=False),
+                                   dict(B=80, T=33, H=720, graph=True, chains=dict(PAULE_HIP_FUSED_CP="2", PAULE_HIP_FUSED_CE="2")),
+                                   dict(B=40, T=50, H=96, graph=False), dict(B=256, T=60, set_b=True, graph=True), dict(B=70, T=31, set_b=True, graph=False)])
 def test_fused_forward_two_per_cu_is_bit_identical(HipPlanner, monkeypatch, shape):
     """Round 4: the forward launch written for TWO workgroups per CU (lstm_fused2.hip: 256 registers, 80 KB of LDS, the h tile straight
-    into LDS by LDS-DMA in a layout permuted for conflict-free operand reads, role table planned for 2 x n_cu slots) computes what the
-    per-layer sweeps and GEMMs compute, bit for bit: every forward stash, the pooled mel, losses and the plan.  cfg3's shape under a
-    graph, a ragged batch (last group of 16 rows), two chains per workgroup with an odd number of groups."""
-    B, T, H = shape["B"], shape["T"], 720
-    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    into LDS by LDS-DMA in a layout permuted for conflict-free operand reads, weight fragments partly re-fetched per chain-step, role
+    table planned for 2 x n_cu slots) computes what the per-layer sweeps and GEMMs compute, bit for bit: every forward stash, the pooled
+    mel, losses and the plan.  cfg3's shape under a graph, a ragged batch (last group of 16 rows), two chains per workgroup with an odd
+    number of groups, a narrow model, the stacked two-width predictor of model set B (full and ragged)."""
+    B, T = shape["B"], shape["T"]
+    if shape.get("set_b"):
+        wl = synthetic.make_workload(B, T, "B")
+        bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
+    else:
+        H = shape["H"]
+        wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+        bufs = FWD_BUFFERS
     env = dict(PAULE_HIP_FUSED_OCC2="1", **(shape.get("chains") or {}))
     monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, env)
-    for name in FWD_BUFFERS:
+    assert e["1"].plan_info()["fwd_per_cu"] == 2, e["1"].plan_info()
+    for name in bufs:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
     monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, shape["graph"], env)

@@ -1,7 +1,9 @@
 #!/bin/bash
 set -o pipefail
-mkdir -p gpurun_out
-timeout -k 10 500 python3 -m pytest tests/test_hip_parity.py -x -q -m gpu -k "two_per_cu" > gpurun_out/occ2_test.log 2>&1
-echo "test rc=$?"; tail -n 15 gpurun_out/occ2_test.log | cut -c1-300
-timeout -k 10 300 python3 tools/ab_bench.py PAULE_HIP_FUSED_OCC2=0,1 6 10 > gpurun_out/occ2_ab.log 2>&1
-echo "ab rc=$?"; tail -n 5 gpurun_out/occ2_ab.log | cut -c1-300
+D=$PWD/paule_amd/csrc
+for r in 1 2 3 4; do
+for v in c p n; do
+  echo "=== core_$v"
+  PAULE_HIP_LIB=$D/libpaule_hip_core_$v.so timeout -k 10 200 python3 tools/occ2_probe.py "PAULE_HIP_FUSED_OCC2=1" 2>&1 | tail -n 1
+done
+done

@@ -35,7 +35,7 @@ def main():
     out_path = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, write = per_kernel(dfetch, "FETCH_SIZE"), per_kernel(dwrite, "WRITE_SIZE")
     res = {}
-    for kname, key in (("fused_fwd_kernel", "fused_fwd_kernel"), ("fused_bwd_kernel", "fused_bwd_kernel"),
+    for kname, key in (("fused_fwd_kernel", "fused_fwd_kernel"), ("fused_fwd2_kernel", "fused_fwd2_kernel"), ("fused_bwd_kernel", "fused_bwd_kernel"),
                        ("fused_fwd16_kernel", "fused_fwd16_kernel"), ("fused_bwd16_kernel", "fused_bwd16_kernel"),
                        ("fused_bwd_kernel2", "fused_bwd_kernel2"), ("fused_bwd16_kernel2", "fused_bwd16_kernel2"),
                        ("lstm_bwd16_rs_sweep_kernel", "lstm_bwd16_rs_sweep_kernel"), ("lstm_fwd16_sweep_kernel", "lstm_fwd16_sweep_kernel"),
