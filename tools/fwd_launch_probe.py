@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Forward launch alone (pl_bench_kernel) under a list of environment variants.  usage: occ2_probe.py "A=1,B=2/A=0" [B] [T]"""
+"""Forward launch alone (pl_bench_kernel) under a list of environment variants.  usage: fwd_launch_probe.py "A=1,B=2/A=0" [B] [T]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -6,6 +6,18 @@ tag=$1; shift
 parts=${@:-bench stats pmc}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+# gpurun_out/ does not travel to the box: entries of an earlier call of this session live in profiles/traffic.json (copied there by hand);
+# start from them when they were taken on these kernel sources, so that pmc and pmc_others may run in separate calls
+python3 - "$tag" <<'PYEOF'
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+src, dst = "profiles/traffic.json", f"gpurun_out/{sys.argv[1]}_traffic.json"
+if os.path.exists(src) and not os.path.exists(dst):
+    t = json.load(open(src))
+    if t.get("source_digest") == bench.source_digest():
+        json.dump(t, open(dst, "w"), indent=1, sort_keys=True)
+PYEOF
 run() {  # name, timeout, command...
   local name=$1 tmo=$2; shift 2
   echo "=== $name"
