@@ -284,7 +284,7 @@ int pl_bench_kernel(pl_handle *h, int kernel, int model_id, int reps, float *avg
 enum { PL_PLAN_FUSED_FWD = 0,      /* 1: role-fused forward launch, 0: per-layer forward sweeps / pipelines */
        PL_PLAN_FUSED_BWD = 1,      /* 1: role-fused backward launch */
        PL_PLAN_FWD_CHAINS_PRED = 2, PL_PLAN_FWD_CHAINS_EMB = 3,   /* batch groups per workgroup of the forward roles */
-       PL_PLAN_BWD_CHAINS_PRED = 4, PL_PLAN_BWD_CHAINS_EMB = 5,
+       PL_PLAN_BWD_CHAINS_PRED = 4, PL_PLAN_BWD_CHAINS_EMB = 5,   /* ... of the backward roles (their own counts since round 4) */
        PL_PLAN_FWD_WORKGROUPS = 6, PL_PLAN_BWD_WORKGROUPS = 7,    /* role-bearing workgroups of the fused launches */
        PL_PLAN_BWD_WAVES = 8,      /* waves per workgroup of the per-layer reduce-scatter backward sweep (4 or 8) */
        PL_PLAN_N_CU = 9,

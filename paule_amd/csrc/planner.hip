@@ -248,7 +248,8 @@ struct pl_handle {
     unsigned long long* sweep_stamps = nullptr;   // -DPL_STAMPS builds: [2 (fwd/bwd)][256 blocks][8]
     // fused acoustic sweeps (lstm_fused.hip): one persistent launch per direction, workgroups take roles from these tables
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
-    int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles
+    int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
+    int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
     bool fused_xcd = true;            // PAULE_HIP_FUSED_XCD: the 32-row fused backward roles' own exchange through the shared L2 when a set sits on one XCD
@@ -1407,7 +1408,7 @@ int plan_fused(pl_handle* h) {
         if (gf > 0 && gf < ng && !rows16 && (mode & 1)) { ngf = gf; mode &= ~2; }
     }
     // chain counts for `slots` forward workgroup slots; o2: the two-per-CU forward launch (one or two chains a workgroup)
-    auto search = [&](bool o2, int slots, int& bcp, int& bce) {
+    auto search = [&](bool o2, int slots, int mode, int& bcp, int& bce) {   // mode: which launches the counts have to fit
         double bcost = 1e30;
         bcp = bce = 0;
         const int cmax = ((mode & 2) && h->bwd_mode == 1) ? 4 : kFusedMaxChains;   // the backward roles have LDS for 4 chains (lstm_fused.hip)
@@ -1433,25 +1434,34 @@ int plan_fused(pl_handle* h) {
             if (mode_forced || rows16 || (mode & 3) != 3) break;
             mode &= ~2;
         }
-        search(false, h->n_cu, best_cp, best_ce);
+        search(false, h->n_cu, mode, best_cp, best_ce);
     }
-    // Two workgroups per CU for the forward launch (lstm_fused2.hip; PAULE_HIP_FUSED_OCC2 = 1 / 0 forces / forbids).  By itself only where it
-    // was measured to win: a forward launch alone (129 rows and more, equal widths), seven groups and more, the predictor on ONE chain per
-    // workgroup -- 224 / 240 / 256 rows x 300 frames: 5.14 -> 5.01, 5.15 -> 5.01, 5.22 -> 5.04 ms per iteration; 160 / 192 rows, where the
-    // one-per-CU plan already has one or two chains: 4.57 -> 4.61, 4.65 -> 4.70; with the backward launch in the plan (up to 128 rows, model
-    // set B) the two launches share their chain counts, and two chains at most cost the backward launch more than the forward one gains
-    // (profiles/r04_ab_fused_occ2.txt)
+    int cp_b = best_cp, ce_b = best_ce;   // the backward launch keeps the shared counts
+    // Two workgroups per CU for the forward launch (lstm_fused2.hip; PAULE_HIP_FUSED_OCC2 = 1 / 0 forces / forbids) -- with chain counts of
+    // its own: the backward launch keeps the counts found above.  By itself only where it was measured to win
+    // (profiles/r04_ab_fused_occ2.txt, interleaved A/B, ms per iteration at 300 frames):
+    //  * a STACKED predictor of another width in front of the embedder (model set B: four narrow recurrences + three projection roles a
+    //    group -- the roles that overlap worst on one wave per SIMD): every batch size of the 32-row roles -- 49 rows 2.48 -> 2.31, 64 2.49 ->
+    //    2.31, 96 2.59 -> 2.37, 128 3.10 -> 2.92, 160 4.22 -> 3.38, 192 4.27 -> 3.50, 224 4.60 -> 3.84, 256 (cfg3_setB) 4.64 -> 4.17;
+    //  * equal widths (set A): seven groups and more, and the predictor's role comes down to ONE chain per workgroup from more -- 224 /
+    //    240 / 256 rows: 5.14 -> 5.01, 5.15 -> 5.01, 5.22 -> 5.04.  Not where the one-per-CU plan already has one or two chains: 128 rows
+    //    3.51 -> 3.85, 160 4.57 -> 4.61, 192 4.65 -> 4.70, 128 x 2000 frames 22.6 -> 23.0.
     if (!rows16 && (mode & 1) && fwd_shape && fused_fwd2_supported(p.Hp, e.Hp) &&
-        (h->fused_occ2 > 0 || (h->fused_occ2 < 0 && !(mode & 2) && ngf == ng && ng >= 7))) {
+        (h->fused_occ2 > 0 || (h->fused_occ2 < 0 && ngf == ng && (p.Hp < e.Hp || ng >= 7)))) {
         int cp2 = 0, ce2 = 0;
-        search(true, 2 * h->n_cu, cp2, ce2);
-        if (cp2 && (h->fused_occ2 > 0 || cp2 == 1)) { occ2 = true; fwd_slots = 2 * h->n_cu; best_cp = cp2; best_ce = ce2; }
+        search(true, 2 * h->n_cu, 1, cp2, ce2);
+        if (cp2 && (h->fused_occ2 > 0 || p.Hp < e.Hp || (cp2 == 1 && best_cp > 1))) { occ2 = true; fwd_slots = 2 * h->n_cu; best_cp = cp2; best_ce = ce2; }
+        if (occ2 && !cp_b) mode &= ~2;   // (forced, and nothing fitted one workgroup per CU: forward launch only)
     }
     if (!best_cp) return PL_OK;
+    if (!cp_b) { cp_b = best_cp; ce_b = best_ce; }
     h->fused_gpp = ngf != ng_all ? ngf : 0;
     const int sp = (ngf + best_cp - 1) / best_cp, se = (ngf + best_ce - 1) / best_ce;
     const int sp_l = rows16 ? ng16 : sp, se_l = rows16 ? ng16 : se;   // sets of the LSTM roles
     h->fused_Cp = best_cp; h->fused_Ce = best_ce;
+    h->fused_Cp_bwd = cp_b; h->fused_Ce_bwd = ce_b;
+    const int sp_b = (ng + cp_b - 1) / cp_b, se_b = (ng + ce_b - 1) / ce_b;   // sets of the backward launch's roles
+    const int sp_bl = rows16 ? ng16 : sp_b, se_bl = rows16 ? ng16 : se_b;
     h->fused_n_roles = fused_roles_count(p.L, e.L);
     int rc;
     if (mode & 1) {
@@ -1485,14 +1495,14 @@ int plan_fused(pl_handle* h) {
         // predictor layer that is 0 predictor, 1 head, 2 embedder layer 1, 3 + 2 (l - 1) / 4 + 2 (l - 1) product / recurrence of layer l
         std::vector<FusedSet> sets;
         for (int l = 0; l < p.L; ++l)
-            for (int s = 0; s < sp_l; ++s) sets.push_back({fr_pred(l), s, Pp, true});
+            for (int s = 0; s < sp_bl; ++s) sets.push_back({fr_pred(l), s, Pp, true});
         for (int l = 0; l < e.L; ++l)
-            for (int s = 0; s < se_l; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
+            for (int s = 0; s < se_bl; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
         for (int l = 1; l < p.L; ++l)
-            for (int s = 0; s < sp; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
+            for (int s = 0; s < sp_b; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
         for (int l = 1; l < e.L; ++l)
-            for (int s = 0; s < se; ++s) sets.push_back({fr_emb_proj(p.L, l), s, Pe, false});
-        for (int s = 0; s < se; ++s) sets.push_back({fr_head(p.L), s, 1, false});
+            for (int s = 0; s < se_b; ++s) sets.push_back({fr_emb_proj(p.L, l), s, Pe, false});
+        for (int s = 0; s < se_b; ++s) sets.push_back({fr_head(p.L), s, 1, false});
         int grid = 0;
         std::vector<short> tab = fused_block_table(h->n_cu, sets, &grid);
         if (grid > 0 && grid <= h->n_cu) {
@@ -1664,7 +1674,7 @@ int build_fused_roles(pl_handle* h) {
             const int rl = fr_pred(l);
             const bool top = l == pL - 1;
             FusedRole& R = roles[rl];
-            R.type = FR_LSTM_BWD; R.wide = 0; R.C = h->fused_Cp; R.T = T; R.flags = fl[rl];
+            R.type = FR_LSTM_BWD; R.wide = 0; R.C = h->fused_Cp_bwd; R.T = T; R.flags = fl[rl];
             R.wait[0] = FusedWait{fl[rl], T, Pp, 0, 0, 1};
             R.src_sc1 = 1;
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
@@ -1681,7 +1691,7 @@ int build_fused_roles(pl_handle* h) {
                 R.dA_sc1 = 1;
                 const int rdx = fr_pred_proj(l);
                 FusedRole& D = roles[rdx];
-                D.type = FR_DX_BWD; D.wide = 0; D.C = h->fused_Cp; D.T = T; D.flags = fl[rdx];
+                D.type = FR_DX_BWD; D.wide = 0; D.C = h->fused_Cp_bwd; D.T = T; D.flags = fl[rdx];
                 D.flags2 = flags2_pred(l);
                 D.wait[0] = FusedWait{D.flags2, T, Pp, 0, 0, kFusedRing};
                 D.wait[2] = FusedWait{fl[rl], T, 1, 1, 0, 0};
@@ -1690,7 +1700,7 @@ int build_fused_roles(pl_handle* h) {
         }
         {   // backward mel head: input-gradient tiles of the embedder's first layer in, dL/dh rows of the predictor's top layer out
             FusedRole& R = roles[r_head];
-            R.type = FR_HEAD_BWD; R.wide = 0; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[r_head];
+            R.type = FR_HEAD_BWD; R.wide = 0; R.C = h->fused_Ce_bwd; R.T = Tp; R.flags = fl[r_head];
             R.wait[0] = FusedWait{fl[r_emb0], Tp, Pe, 0, 0, 0};
             R.Wg = p.WlinT; R.out = p.dh_ext; R.dh_ext = h->Y; R.out_dim = h->M; R.out_p = h->Mp; R.xchg_mel = h->fused_xchg_mel;
         }
@@ -1699,7 +1709,7 @@ int build_fused_roles(pl_handle* h) {
             const int rl = fr_emb(pL, l);
             const bool top = l == e.L - 1;
             FusedRole& R = roles[rl];
-            R.type = FR_LSTM_BWD; R.wide = 1; R.C = h->fused_Ce; R.T = Tp; R.flags = fl[rl];
+            R.type = FR_LSTM_BWD; R.wide = 1; R.C = h->fused_Ce_bwd; R.T = Tp; R.flags = fl[rl];
             R.wait[0] = FusedWait{fl[rl], Tp, Pe, 0, 0, 1};
             R.G = ly.G; R.W = ly.WhhT; R.c = ly.c; R.xchg = h->fused_xchg[rl];
             fused16_fields(h, R, fl[rl], nullptr);
@@ -1716,7 +1726,7 @@ int build_fused_roles(pl_handle* h) {
                 R.dA_sc1 = 1;
                 const int rdx = fr_emb_proj(pL, l);
                 FusedRole& D = roles[rdx];
-                D.type = FR_DX_BWD; D.wide = 1; D.C = h->fused_Ce; D.T = Tp; D.flags = fl[rdx];
+                D.type = FR_DX_BWD; D.wide = 1; D.C = h->fused_Ce_bwd; D.T = Tp; D.flags = fl[rdx];
                 D.flags2 = flags2_emb(l);
                 // a ring slot of partial tiles is free once every workgroup of the set has reduced the step that used it
                 D.wait[0] = FusedWait{D.flags2, Tp, Pe, 0, 0, kFusedRing};
@@ -3119,8 +3129,8 @@ int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
         h->fused_bwd_ok ? 1 : 0,
         h->fused_fwd_ok ? h->fused_Cp : 0,
         h->fused_fwd_ok ? h->fused_Ce : 0,
-        h->fused_bwd_ok ? h->fused_Cp : 0,
-        h->fused_bwd_ok ? h->fused_Ce : 0,
+        h->fused_bwd_ok ? h->fused_Cp_bwd : 0,
+        h->fused_bwd_ok ? h->fused_Ce_bwd : 0,
         h->fused_fwd_ok ? h->fused_active_fwd : 0,
         h->fused_bwd_ok ? h->fused_active_bwd : 0,
         h->bwd_waves,

@@ -545,6 +545,33 @@ def test_fused_forward_two_per_cu_is_bit_identical(HipPlanner, monkeypatch, shap
     monkeypatch.delenv("PAULE_HIP_FUSED_OCC2")
 
 
+def test_two_per_cu_forward_beside_the_fused_backward_launch(HipPlanner, monkeypatch):
+    """Round 4: the two-per-CU forward launch has chain counts of its own, so it can sit in front of the (one-per-CU) fused BACKWARD launch:
+    model set B at 256 rows -- the planner takes it by itself (predictor roles 2 -> 1 chains), the backward launch keeps its plan, and six
+    iterations equal the one-per-CU schedule bit for bit (losses, dL/dCP, CP)."""
+    B, T = 256, 40
+    wl = synthetic.make_workload(B, T, "B")
+    out = {}
+    for occ2 in ("0", None):
+        if occ2 is None:
+            monkeypatch.delenv("PAULE_HIP_FUSED_OCC2", raising=False)
+        else:
+            monkeypatch.setenv("PAULE_HIP_FUSED_OCC2", occ2)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=True)
+        plan = eng.plan_info()
+        assert plan["fused_fwd"] == 1 and plan["fused_bwd"] == 1, plan
+        assert plan["fwd_per_cu"] == (1 if occ2 == "0" else 2), plan
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        losses = _n(eng.step(6))
+        eng.synchronize()
+        out[occ2] = (plan, losses, _n(eng.get_cp()), _n(eng.get_grad()) if hasattr(eng, "get_grad") else None)
+    assert out[None][0]["bwd_chains_pred"] == out["0"][0]["bwd_chains_pred"] and out[None][0]["bwd_chains_emb"] == out["0"][0]["bwd_chains_emb"]
+    assert out[None][0]["fwd_chains_pred"] == 1 < out["0"][0]["fwd_chains_pred"], (out[None][0], out["0"][0])
+    np.testing.assert_array_equal(out[None][1], out["0"][1])
+    np.testing.assert_array_equal(out[None][2], out["0"][2])
+
+
 @pytest.mark.parametrize("shape", [dict(B=256, T=60, graph=True), dict(B=70, T=31, graph=False)])
 def test_fused_forward_stacked_predictor_is_bit_identical(HipPlanner, monkeypatch, shape):
     """Round 3: the fused forward launch takes the class-default STACKED predictor (4 x 180, paule/models.py:335-339) in front of
@@ -555,8 +582,10 @@ def test_fused_forward_stacked_predictor_is_bit_identical(HipPlanner, monkeypatc
     B, T = shape["B"], shape["T"]
     wl = synthetic.make_workload(B, T, "B")
     bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
+    monkeypatch.setenv("PAULE_HIP_FUSED_OCC2", "0")   # lstm_fused.hip's launch (since round 4 the planner's choice for set B is the two-per-CU one: its own test above)
     monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False)
+    assert e["1"].plan_info()["fwd_per_cu"] == 1
     for name in bufs:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
     monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
