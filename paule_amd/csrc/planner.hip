@@ -1436,7 +1436,8 @@ int plan_fused(pl_handle* h) {
         }
         search(false, h->n_cu, mode, best_cp, best_ce);
     }
-    int cp_b = best_cp, ce_b = best_ce;   // the backward launch keeps the shared counts
+    int cp_b = best_cp, ce_b = best_ce;   // the backward launch keeps the shared counts (a one-per-CU forward launch too: counts of its own
+                                          // changed nothing there -- set B at 64 ... 256 rows, set A at 64 / 128 were planned the same)
     // Two workgroups per CU for the forward launch (lstm_fused2.hip; PAULE_HIP_FUSED_OCC2 = 1 / 0 forces / forbids) -- with chain counts of
     // its own: the backward launch keeps the counts found above.  By itself only where it was measured to win
     // (profiles/r04_ab_fused_occ2.txt, interleaved A/B, ms per iteration at 300 frames):
