@@ -312,27 +312,37 @@ __device__ __forceinline__ void fused_lstm_fwd(const FusedArgs& a, const FusedRo
             const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
             st16_sc1(ro, rb < Bp ? (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2) : kOob, hvv);
         }
-        asm volatile("" ::: "memory");   // keep the stash stores behind it
+        // One chain per workgroup: the five stash arrays leave BEHIND the flag (nobody inside the launch waits for them, and nothing else of
+        // this workgroup hides their issue: B = 64 3.30 -> 3.25 ms per iteration, 128 x 2000 frames 22.49 -> 22.35); with more chains the
+        // next chain's operands are already waiting, and stores in front of its MFMAs cost more than they save behind this chain's flag
+        // (B = 192, chains 2 / 3: 4.65 -> 4.73): there they stay in front (profiles/r04_ab_fused_occ2.txt, item 11)
+        const bool stash_late = RC == 1;
+        auto stash_stores = [&]() {
+            asm volatile("" ::: "memory");   // keep the stash stores behind the hand-off store
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int e = tid + 256 * i;   // piece: array e / 128, row (e % 128) / 4, quarter e % 4
-            if (i < 2 || wave < 2) {   // 640 pieces: all threads twice, waves 0 and 1 a third time
-                const int arr = e >> 7, row = (e & 127) >> 2, qt = e & 3, rb = 32 * g + row;
-                const uint4 sv = *reinterpret_cast<const uint4*>(hst + (arr + 1) * 32 * HRS + row * HRS + qt * 16);
-                u32x4 d;
-                d[0] = sv.x; d[1] = sv.y; d[2] = sv.z; d[3] = sv.w;
-                if (i < 2) {   // pieces 0 .. 511: the four gate arrays (128 pieces = 2 waves each); 512 .. 639: c
-                    const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
-                    __builtin_amdgcn_raw_buffer_store_b128(d, rg, rb < Bp ? (unsigned)(((size_t)rb * G4 + arr * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
-                } else {
-                    const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)t * slabH, (unsigned)(slabH * 2));
-                    __builtin_amdgcn_raw_buffer_store_b128(d, rc, rb < Bp ? (unsigned)(((size_t)rb * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+            for (int i = 0; i < 3; ++i) {
+                const int e = tid + 256 * i;   // piece: array e / 128, row (e % 128) / 4, quarter e % 4
+                if (i < 2 || wave < 2) {   // 640 pieces: all threads twice, waves 0 and 1 a third time
+                    const int arr = e >> 7, row = (e & 127) >> 2, qt = e & 3, rb = 32 * g + row;
+                    const uint4 sv = *reinterpret_cast<const uint4*>(hst + (arr + 1) * 32 * HRS + row * HRS + qt * 16);
+                    u32x4 d;
+                    d[0] = sv.x; d[1] = sv.y; d[2] = sv.z; d[3] = sv.w;
+                    if (i < 2) {   // pieces 0 .. 511: the four gate arrays (128 pieces = 2 waves each); 512 .. 639: c
+                        const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rg, rb < Bp ? (unsigned)(((size_t)rb * G4 + arr * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+                    } else {
+                        const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rc, rb < Bp ? (unsigned)(((size_t)rb * Hp + 32 * p + 8 * qt) * 2) : kOob, 0, 0);
+                    }
                 }
             }
-        }
+        };
+        if (!stash_late) stash_stores();
         PL_ST(3);   // cell + store issue
-        raise_flag<3>(rflags + ((size_t)g * T + t) * a.flag_stride + p);   // the hand-off store is older than the (at most 3) stash stores
+        if (stash_late) raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);   // only the hand-off is in flight
+        else raise_flag<3>(rflags + ((size_t)g * T + t) * a.flag_stride + p);   // the hand-off store is older than the (at most 3) stash stores
         PL_ST(4);   // drain + barrier + flag
+        if (stash_late) stash_stores();
 
         if (!has_next) break;
         // H. the next chain-step was not ready at the first look (always so with one chain: it waits for the flag just raised)
