@@ -195,6 +195,10 @@ void launch_fused_bwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedAr
 // the forward launch at TWO workgroups per CU (lstm_fused2.hip, round 4): the same role table, planned for 2 x n_cu workgroup slots
 bool fused_fwd2_supported(int Hp_pred, int Hp_emb);
 void launch_fused_fwd2(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
+// the two-per-CU recurrence role alone as a per-layer forward sweep (32-row groups, whole sequence; more groups than one pass of the
+// one-per-CU sweep holds): sets = groups served at once
+bool lstm_fwd2_sweep_supported(int Hp);
+void launch_lstm_fwd2_sweep(hipStream_t stream, int Hp, int sets, const LstmSweepArgs& s);
 // the same role tables with the LSTM roles on 16 batch rows (v_mfma_f32_16x16x32_bf16, one chain): batches of up to 16 rows
 void launch_fused_fwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 void launch_fused_bwd16(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);

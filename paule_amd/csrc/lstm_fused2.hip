@@ -626,7 +626,55 @@ __global__ __launch_bounds__(256, 2) void fused_fwd2_kernel(FusedArgs a) {
     }
 }
 
+// ---- the recurrence role alone as a per-layer forward sweep (batches of more groups than one pass of lstm_fwd_sweep_kernel holds) ------
+// lstm_persist.hip's forward sweep runs one workgroup per CU: 11 groups of 23 workgroups a pass at H = 720, 64 groups (cfg4's 2048 rows on
+// one GPU) in 6 passes of 300 x 4.2 us.  The two-per-CU role holds 22 groups a pass at 5.9 us a step: 3 passes.  Workgroup b serves slice
+// b % P of the groups b / P, b / P + sets, ... one after the other; groups are independent, every group's own flags [T][flag_stride] are
+// the sweep's `counters`, and the role function is the fused launch's (one chain, no waits on other roles): same bits in G, h, c.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void lstm_fwd2_sweep_kernel(LstmSweepArgs s, int sets) {
+    constexpr int P = 16 * KS / 32;
+    constexpr int kLds = fused_fwd2_lds_bytes<KS>();
+    static_assert(kLds <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    const int set = uni((int)blockIdx.x / P), p = uni((int)blockIdx.x % P);
+    if (set >= sets) return;
+    FusedArgs a{};
+    a.Bp = s.Bp; a.B = s.Bp; a.n_groups = (s.Bp + 31) / 32; a.flag_stride = s.flag_stride;
+    a.status = s.status; a.spin_ticks = s.spin_ticks; a.poll_mask = s.poll_mask; a.stamps = s.stamps;
+    FusedRole R{};
+    R.type = FR_LSTM_FWD; R.C = 1; R.T = s.T; R.flags = s.counters;
+    R.wait[0] = FusedWait{s.counters, s.T, P, 0, 0, -1};
+    R.G = s.G; R.W = s.W; R.h = s.h; R.c = s.c;
+    R.ksx = s.x_in ? s.in_p / 16 : 0; R.x_in = s.x_in; R.Wih = s.Wih; R.bias = s.bias;
+    for (int g = set; g < a.n_groups; g += sets) {
+        if (R.ksx == 2) fused_lstm_fwd2<KS, 2>(a, R, g, p, lds);
+        else if (R.ksx == 4) fused_lstm_fwd2<KS, 4>(a, R, g, p, lds);
+        else fused_lstm_fwd2<KS, 0>(a, R, g, p, lds);
+        __syncthreads();   // nobody starts the next group's LDS images while a wave still reads this one's
+        if (uni(__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;   // a wait gave up: everybody leaves
+    }
+}
+
 }  // namespace
+
+#define PL_FUSED_FWD2_KS(X) X(6) X(12) X(46)
+bool lstm_fwd2_sweep_supported(int Hp) {
+#define PL_CASE(K) if (Hp == 16 * K) return true;
+    PL_FUSED_FWD2_KS(PL_CASE)
+#undef PL_CASE
+    return false;
+}
+// sets: groups served at once (<= 2 n_cu / P); the grid is sets x P workgroups
+void launch_lstm_fwd2_sweep(hipStream_t stream, int Hp, int sets, const LstmSweepArgs& s) {
+#define PL_CASE(K)                                                                                              \
+    if (Hp == 16 * K) {                                                                                         \
+        hipLaunchKernelGGL(lstm_fwd2_sweep_kernel<K>, dim3(sets * (16 * K / 32)), dim3(256), 0, stream, s, sets); \
+        return;                                                                                                 \
+    }
+    PL_FUSED_FWD2_KS(PL_CASE)
+#undef PL_CASE
+}
 
 #define PL_FUSED_FWD2_PAIRS(X) X(6, 6) X(46, 46) X(12, 46)
 

@@ -257,6 +257,7 @@ struct pl_handle {
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
     int fused_grid_fwd = 0;
     bool fused_bwd_ok = false;  // PAULE_HIP_FUSED bit 1
+    int sweep2 = -1;             // PAULE_HIP_SWEEP2: per-layer forward sweeps of batches beyond one pass on the two-per-CU role (1 always, 0 never, -1 auto)
     int fused_occ2 = -1;         // PAULE_HIP_FUSED_OCC2: the forward launch at two workgroups per CU (lstm_fused2.hip): 1 wherever the shape has it, 0 never, -1 (default) where it wins (plan_fused)
     bool fused_fwd2 = false;     // ... and the plan took it: the role table holds up to 2 n_cu workgroups
     bool fused_rows16 = false;  // batches of up to 16 rows: the LSTM roles of both launches run on 16-row tiles (lstm_fused16.h)
@@ -444,6 +445,15 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
             s8.xchg = h->sweep_xchg_tok;
         }
         launch_lstm_bwd_rs_sweep(st, Hp, grid, s8);
+    }
+    else if (!bwd && h->dt == BF16 && h->sweep2 != 0 && s.group_rows == 32 && s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T) &&
+             lstm_fwd2_sweep_supported(Hp) && (h->sweep2 > 0 || (s.Bp + 31) / 32 > h->n_cu / (Hp / 32))) {
+        // more 32-row groups than one pass of the one-per-CU forward sweep holds (cfg4's 2048 rows on one GPU: 64 groups in 6 passes of
+        // 11): the two-per-CU recurrence role (lstm_fused2.hip) holds twice as many a pass at 1.4 x the step time
+        const int P = Hp / 32, ng = (s.Bp + 31) / 32, fit = 2 * h->n_cu / P;
+        // equal passes: 64 groups on 22 sets would be 22 + 22 + 20 -- the same three passes on 22 + 21 + 21 keep fewer workgroups per CU pair
+        const int passes = (ng + fit - 1) / fit, sets = (ng + passes - 1) / passes;
+        launch_lstm_fwd2_sweep(st, Hp, sets, s);
     }
     else
         launch_lstm_sweep(st, bwd, Hp, grid, s);
@@ -2182,6 +2192,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_XCD")) h->fused_xcd = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_OCC2")) h->fused_occ2 = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_SWEEP2")) h->sweep2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;

@@ -545,6 +545,41 @@ def test_fused_forward_two_per_cu_is_bit_identical(HipPlanner, monkeypatch, shap
     monkeypatch.delenv("PAULE_HIP_FUSED_OCC2")
 
 
+@pytest.mark.parametrize("shape", [dict(B=800, T=14, H=720), dict(B=403, T=15, H=720, force="1"), dict(B=130, T=20, H=96, force="1")])
+def test_two_per_cu_forward_sweep_is_bit_identical(HipPlanner, monkeypatch, shape):
+    """Round 4: per-layer forward sweeps of batches with more 32-row groups than one pass of the one-per-CU sweep holds run the two-per-CU
+    recurrence role (lstm_fused2.hip: lstm_fwd2_sweep_kernel; 25 groups at H = 720 = two passes of 13 / 12 sets where the old sweep takes
+    three of 11): every forward stash of every layer (fused input projection and precomputed one), the pooled mel, losses and the plan equal
+    the one-per-CU sweeps' bit for bit; ragged last groups; forced at smaller batches and a narrow model."""
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    monkeypatch.setenv("PAULE_HIP_FUSED", "0")
+    monkeypatch.setenv("PAULE_HIP_SWEEP16", "0")
+    out = {}
+    for v in ("0", shape.get("force", "-1")):
+        monkeypatch.setenv("PAULE_HIP_SWEEP2", v)
+        monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
+        assert eng.plan_info()["fused_fwd"] == 0
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        eng.step(1)
+        eng.synchronize()
+        bufs = {name: _n(eng.debug_read(name)) for name in FWD_BUFFERS}
+        monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+        eng2 = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=True)
+        eng2.set_targets(wl.target_mel, wl.target_semvec)
+        eng2.set_cp(wl.cp0)
+        losses = _n(eng2.step(3))
+        eng2.synchronize()
+        out[v] = (bufs, losses, _n(eng2.get_cp()))
+    a, b = out["0"], out[shape.get("force", "-1")]
+    for name in FWD_BUFFERS:
+        np.testing.assert_array_equal(b[0][name], a[0][name], err_msg=name)
+    np.testing.assert_array_equal(b[1], a[1])
+    np.testing.assert_array_equal(b[2], a[2])
+
+
 def test_two_per_cu_forward_beside_the_fused_backward_launch(HipPlanner, monkeypatch):
     """Round 4: the two-per-CU forward launch has chain counts of its own, so it can sit in front of the (one-per-CU) fused BACKWARD launch:
     model set B at 256 rows -- the planner takes it by itself (predictor roles 2 -> 1 chains), the backward launch keeps its plan, and six
