@@ -577,6 +577,268 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
     PL_ST_DUMP(a.stamps);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained form of the streamed reduce-scatter (round 5): a workgroup serves C batch groups ("chains") with ONE copy of its W_hh^T slice
+// and takes a step of each in turn -- t, chain 0; t, chain 1; ...; t - 1, chain 0; ...  A group's step is a latency chain (tiles out,
+// acknowledge, flag, poll, tiles in: ~2.5 of the 4.05 us of lstm_bwd_rs_stream_kernel's step, during which the CU idles); with the other
+// chains' steps in between, a chain finds its tiles in place when its turn comes again, and a sweep needs groups / C x P workgroups
+// instead of groups x P -- what lets several layers' recurrences run side by side on the chip.  Per (group, step) everything is the
+// streamed kernel's: the same tiles from the same 8 MFMAs in the same rotated order, the same per-tile flags and exchange buffer
+// (indexed by the group), the same fixed-order sum, the same-XCD form per group -- results are bit-identical
+// (tests/test_hip_parity.py::test_backward_sweep_forms_are_bit_identical).  The running dL/dc of the chains lives in LDS.
+// Grid: n_slots x P with set = blockIdx % n_slots (8 slots: a set's workgroups share blockIdx % 8, one XCD under the observed dealing --
+// speed only, verified at run time like every same-XCD choice); sets beyond ceil(groups / C) leave at once.
+constexpr int kRsMaxChains = 4;
+template <int KS, int XT>
+__global__ __launch_bounds__(512, 1) void lstm_bwd_rs_chain_kernel(LstmSweepArgs a) {
+    constexpr int Hp = 16 * KS;
+    constexpr int P = Hp / 32;
+    constexpr int NW = 8;
+    constexpr int NT = (P + NW - 1) / NW;
+    constexpr int DRS = 128 * 2 + 16;
+    constexpr int ORS = Hp * 2 + 16;
+    static_assert(P <= 32, "one flag word per source in a 32-int row");
+    static_assert(!XT || NW * NT > P, "the ride-along tile needs a free tile slot in the last wave");
+    __shared__ __attribute__((aligned(16))) unsigned char da_img[2][32 * DRS];
+    __shared__ __attribute__((aligned(16))) unsigned char out_img[32 * ORS];
+    __shared__ float4 dcs[kRsMaxChains][256];
+    __shared__ int lds_flag, lds_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool cellw = wave < 4;
+    const int n_slots = gridDim.x / P;
+    const int set = blockIdx.x % n_slots, p = blockIdx.x / n_slots;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int gs = a.group_rows;
+    const int n_groups = (Bp + gs - 1) / gs;
+    const int C = a.chains < 1 ? 1 : (a.chains > kRsMaxChains ? kRsMaxChains : a.chains);
+    const int g0 = set * C;
+    if (g0 >= n_groups) return;
+    const int Ca = n_groups - g0 < C ? n_groups - g0 : C;
+    const bf16_t* __restrict__ WT = static_cast<const bf16_t*>(a.W);   // Whh^T packed [Hp][4*Hp]
+
+    uint4 wreg[NT][8];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int k = wave + NW * i;
+        const int nt = k < P ? (p + 1 + k) % P : 0;
+        const int n = 32 * nt + (lane & 31);
+        const bf16_t* wsrc = (XT && i == NT - 1 && wave == NW - 1) ? static_cast<const bf16_t*>(a.WihT) + (size_t)(lane & 31) * G4 : WT + (size_t)n * G4;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            wreg[i][ks] = *reinterpret_cast<const uint4*>(wsrc + (ks >> 1) * Hp + 32 * p + 16 * (ks & 1) + 8 * (lane >> 5));
+    }
+
+    const int erow = (tid & 255) >> 3, jq = tid & 7;
+    const int j = 32 * p + 4 * jq;
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    bf16_t* __restrict__ G = static_cast<bf16_t*>(a.G);
+    const bf16_t* __restrict__ Cs = static_cast<const bf16_t*>(a.c);
+    const bf16_t* __restrict__ dhe = static_cast<const bf16_t*>(a.dh_ext);
+    const bf16_t* __restrict__ dhl = static_cast<const bf16_t*>(a.dh_last);
+    bf16_t* __restrict__ X = static_cast<bf16_t*>(a.xchg);
+    constexpr size_t TILE = 32 * 32;
+    const size_t grp_stride = (size_t)P * P * TILE;
+    const size_t slot_stride = (size_t)n_groups * grp_stride;
+    int* const tf = a.tflags;
+    if (tid == 0) lds_abort = 0;
+    __syncthreads();
+
+    unsigned plain_mask = 0;   // bit c: chain c's group verified that it sits on one XCD (a scalar)
+    int kpar = 0;              // parity of the chain-step: which dA image it writes
+    for (int t = T - 1; t >= 0; --t) {
+        for (int c = 0; c < Ca; ++c) {
+            const int g = g0 + c;
+            const int b = gs * g + erow;
+            const bool ok = erow < gs && b < Bp;
+            const int bc = ok ? b : Bp - 1;
+            int* xtab = a.xcc_tab + (size_t)g * 64;
+            const bool plain_handoff = ((plain_mask >> c) & 1u) != 0;
+            uint2 sg[4] = {}, sc = make_uint2(0u, 0u), scp = make_uint2(0u, 0u), sdh = make_uint2(0u, 0u);
+            if (cellw) {
+                const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
+                sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+                if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
+                if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
+                else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
+            }
+            float dh[4];
+            unpack_bf16x4(sdh, dh);
+            PL_ST(0);
+            if (t + 1 < T) {
+                if (cellw) {
+                    const int token = t + 2;
+                    const int* frow = tf + ((size_t)((t + 1) & 1) * n_groups + g) * P * 32 + (size_t)p * 32;
+                    const __amdgpu_buffer_rsrc_t rf = make_rsrc(frow, (unsigned)(P * 4));
+                    const bf16_t* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 2));
+                    const unsigned o0 = (unsigned)((erow * 32 + 4 * jq) * 2);
+                    constexpr unsigned full = P == 32 ? 0xffffffffu : ((1u << P) - 1u);
+                    unsigned issued = 0;
+                    u32x2 pv[P];
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 1;; ++spin) {
+                        int v = 0;
+                        if (lane < P)
+                            v = plain_handoff ? (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxNt)
+                                              : (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
+                        const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(v == token) & full;
+                        const unsigned newly = (unsigned)__builtin_amdgcn_readfirstlane((int)(mask & ~issued));
+#pragma unroll
+                        for (int s = 0; s < P; ++s)
+                            if ((newly >> s) & 1u)
+                                pv[s] = plain_handoff ? __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxNt)
+                                                      : __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + (unsigned)(s * TILE * 2), 0, kAuxSc1);
+                        issued |= newly;
+                        if (issued == full) break;
+                        if ((spin & a.poll_mask) == 0 &&
+                            (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0 ||
+                             __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks)) {
+                            if (lane == 0) {
+                                __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                lds_abort = 1;
+                            }
+#pragma unroll
+                            for (int s = 0; s < P; ++s)
+                                if (!((issued >> s) & 1u)) pv[s] = u32x2{0u, 0u};
+                            break;
+                        }
+                    }
+                    PL_ST(1);   // polls + tile loads issued
+#pragma unroll
+                    for (int s = 0; s < P; ++s) {
+                        float f[4];
+                        unpack_bf16x4(make_uint2(pv[s][0], pv[s][1]), f);
+                        dh[0] += f[0]; dh[1] += f[1]; dh[2] += f[2]; dh[3] += f[3];
+                    }
+                }
+                if (t == T - 2 && a.xcd_fast) {
+                    if (group_on_one_xcd(xtab, P, &lds_flag)) plain_mask |= 1u << c;
+                }
+            }
+            PL_ST(2);   // tiles landed + sums
+
+            unsigned char* const dimg = da_img[kpar];
+            if (cellw) {
+                float gi[4], gf[4], gg[4], go[4], cv[4], cp[4];
+                unpack_bf16x4(sg[0], gi);
+                unpack_bf16x4(sg[1], gf);
+                unpack_bf16x4(sg[2], gg);
+                unpack_bf16x4(sg[3], go);
+                unpack_bf16x4(sc, cv);
+                unpack_bf16x4(scp, cp);
+                float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t + 1 < T) dcv = dcs[c][tid];
+                float dc_next[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+                float dai[4], daf[4], dag[4], dao[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], cv[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
+                dcs[c][tid] = make_float4(dc_next[0], dc_next[1], dc_next[2], dc_next[3]);
+                const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
+                const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
+                if (ok && !(XT && a.skip_dA)) {
+                    bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                    *reinterpret_cast<uint2*>(go_) = pi;
+                    *reinterpret_cast<uint2*>(go_ + Hp) = pf;
+                    *reinterpret_cast<uint2*>(go_ + 2 * Hp) = pg;
+                    *reinterpret_cast<uint2*>(go_ + 3 * Hp) = po;
+                }
+                if (t > 0 || XT) {
+                    unsigned char* drow = dimg + erow * DRS + jq * 8;
+                    *reinterpret_cast<uint2*>(drow) = pi;
+                    *reinterpret_cast<uint2*>(drow + 64) = pf;
+                    *reinterpret_cast<uint2*>(drow + 128) = pg;
+                    *reinterpret_cast<uint2*>(drow + 192) = po;
+                }
+            }
+            if (t == 0 && !XT) continue;   // nobody consumes the partials of step 0 (uniform: no barrier is skipped by part of the workgroup)
+            if (t == T - 1 && tid == 0) {
+                __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(lds_abort) != 0) return;
+            kpar ^= 1;
+            PL_ST(3);   // cell + stash stores + dA image + barrier
+            uint4 bfr[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                bfr[ks] = *reinterpret_cast<const uint4*>(dimg + (lane & 31) * DRS + ks * 32 + (lane >> 5) * 16);
+            bf16_t* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 2));
+            int* const fcol = tf + ((size_t)(t & 1) * n_groups + g) * P * 32 + p;   // + 32 * destination
+            const __amdgpu_buffer_rsrc_t rfl = make_rsrc(fcol, (unsigned)(((P - 1) * 32 + 1) * 4));
+            auto raise = [&](int nt) {
+                if (lane == 0) {
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), rfl, (unsigned)(nt * 32 * 4), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), rfl, (unsigned)(nt * 32 * 4), 0, kAuxSc1);
+                }
+            };
+            int nt_prev = -1;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int k = wave + NW * i;
+                if (XT && t == 0) break;
+                if (NW * i + NW - 1 >= P && k >= P) break;   // in front of a tile's MFMAs, behind the previous tile's epilogue (tools/isa_mfma_hazard_scan.py)
+                const int nt = (p + 1 + k) % P;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+                unsigned char* orow = out_img + (lane & 31) * ORS + (32 * nt + 4 * (lane >> 5)) * 2;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<uint2*>(orow + rg * 16) = pack_bf16x4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cidx = lane + 64 * q, r = cidx >> 2, c4 = cidx & 3;
+                    const uint4 v = *reinterpret_cast<const uint4*>(out_img + r * ORS + (32 * nt + 8 * c4) * 2);
+                    u32x4 d;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    const unsigned off = (unsigned)(((size_t)nt * P * TILE + cidx * 8) * 2);
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(d, ro, off, 0, kAuxSc1);
+                }
+                if (nt_prev >= 0) {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    raise(nt_prev);
+                }
+                nt_prev = nt;
+            }
+            if (nt_prev >= 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise(nt_prev);
+            }
+            if (XT && wave == NW - 1) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[NT - 1][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[ks]), acc, 0, 0, 0);
+                float* xp = a.xpart + (((size_t)t * n_groups + g) * P + p) * 1024;
+                const __amdgpu_buffer_rsrc_t rp = make_rsrc(xp, 4096u);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float f0 = acc[4 * rg], f1 = acc[4 * rg + 1], f2 = acc[4 * rg + 2], f3 = acc[4 * rg + 3];
+                    u32x4 d;
+                    d[0] = __float_as_uint(f0); d[1] = __float_as_uint(f1); d[2] = __float_as_uint(f2); d[3] = __float_as_uint(f3);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rp, (unsigned)(rg * 1024 + lane * 16), 0, 0);
+                }
+            }
+            PL_ST(4);   // tiles + flags
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
 #ifdef PL_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------
 // Token form of the reduce-scatter (round 4; EXPERIMENT, compiled with -DPL_EXPERIMENTS only: measured slower than the flag form,
@@ -1009,7 +1271,11 @@ void launch_lstm_bwd_rs_sweep(hipStream_t stream, int Hp, int grid, const LstmSw
 #define PL_CASE(K)                                                                                        \
     if (Hp == 16 * K) {                                                                                   \
         PL_CASE_EXPERIMENTS(K)                                                                            \
-        if (a.tflags && a.bwd_waves != 4 && K == 46 && a.xpart)                                           \
+        if (a.tflags && a.bwd_waves != 4 && K == 46 && a.chains > 0 && a.xpart)                           \
+            hipLaunchKernelGGL((lstm_bwd_rs_chain_kernel<46, 1>), dim3(grid), dim3(512), 0, stream, a);   \
+        else if (a.tflags && a.bwd_waves != 4 && K == 46 && a.chains > 0)                                 \
+            hipLaunchKernelGGL((lstm_bwd_rs_chain_kernel<46, 0>), dim3(grid), dim3(512), 0, stream, a);   \
+        else if (a.tflags && a.bwd_waves != 4 && K == 46 && a.xpart)                                      \
             hipLaunchKernelGGL((lstm_bwd_rs_stream_kernel<46, 0, 1>), dim3(grid), dim3(512), 0, stream, a);   \
         else if (a.tflags && a.bwd_waves != 4 && K <= 64)                                                 \
             hipLaunchKernelGGL((lstm_bwd_rs_stream_kernel<(K <= 64 ? K : 2), 0>), dim3(grid), dim3(512), 0, stream, a); \

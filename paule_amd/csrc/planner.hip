@@ -250,6 +250,7 @@ struct pl_handle {
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
     int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
+    int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
     bool fused_xcd = true;            // PAULE_HIP_FUSED_XCD: the 32-row fused backward roles' own exchange through the shared L2 when a set sits on one XCD
@@ -443,6 +444,12 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
         if (h->bwd_stream == 2 && whole && h->sweep_xchg_tok && h->bwd_waves != 4 && s.xchg == h->sweep_xchg) {
             s8.token_handoff = h->token_early ? 1 : 2;   // 2: diagnostic, no early tile loads (PAULE_HIP_TOKEN_EARLY=0)
             s8.xchg = h->sweep_xchg_tok;
+        }
+        // PAULE_HIP_BWD_CHAINS=C (round 5, probe): the chained form -- a workgroup serves C groups in turn, ceil(groups / C) sets on 8 slots
+        if (h->bwd_chains > 0 && s8.tflags && !s8.token_handoff && h->bwd_waves != 4 && Hp == 736 && s.group_rows == 32 &&
+            ((s.Bp + 31) / 32 + h->bwd_chains - 1) / h->bwd_chains <= 8 && h->n_cu >= 8 * (Hp / 32)) {
+            s8.chains = h->bwd_chains;
+            grid = 8 * (Hp / 32);
         }
         launch_lstm_bwd_rs_sweep(st, Hp, grid, s8);
     }
@@ -2194,6 +2201,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_FUSED_OCC2")) h->fused_occ2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_SWEEP2")) h->sweep2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_BWD_CHAINS")) h->bwd_chains = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;
         if (const char* z = std::getenv("PAULE_HIP_TOKEN_EARLY")) h->token_early = std::atoi(z) != 0;

@@ -31,7 +31,9 @@ for d, name, steps, labels in (
          (["stash loads issued", "tile loads issued + landed", "sums", "cell+stash+dA image+barrier", "tiles", "token checks", "-", "stash loads landed (diagnostic wait)"]
           if "stamps2" in os.environ.get("PL_STAMP_LIB", "") else
           ["step top/stash loads", "tile loads + token checks", "sums", "cell+stash+dA image+barrier", "tiles", "SWEEPS per step (count)",
-           "TILE LOADS per step (count)"] if os.environ.get("PAULE_HIP_BWD_STREAM", "2") == "2" else
+           "TILE LOADS per step (count)"] if os.environ.get("PAULE_HIP_BWD_STREAM", "1") == "2" else
+          ["step top/stash loads issued", "polls + tile loads issued", "tiles landed + sums", "cell+stash+dA image+barrier", "tiles + flags"]
+          if os.environ.get("PAULE_HIP_BWD_STREAM", "1") == "1" and os.environ.get("PAULE_HIP_BWD_WAVES", "8") != "4" else
           ["step top/prefetch", "wait arrivals", "partial ingest", "cell+stash+dA image", "MFMA+partial image", "hand-off store issue",
            "drain+barrier+add"]) if os.environ.get("PAULE_HIP_BWD_MODE", "1") == "1" else
          ["step top/prefetch", "wait arrivals", "dA loads+LDS+MFMA", "partial reduce", "cell+store issue", "store drain", "barrier+add"])):
@@ -39,8 +41,9 @@ for d, name, steps, labels in (
     used = blk[blk.sum(axis=1) > 0]
     print(f"--- {name}: {len(used)} workgroups; per-step phase time (us), median / max over workgroups")
     tot = 0.0
+    chains = max(1, int(os.environ.get("PAULE_HIP_BWD_CHAINS", "0"))) if d == 1 else 1   # chained form: a workgroup's stamps cover steps x chains chain-steps
     for i, lab in enumerate(labels):
-        v = used[:, i] / steps
+        v = used[:, i] / steps / chains
         tot += np.median(v)
         print(f"  {lab:24s} {np.median(v):6.2f} {v.max():6.2f}")
     print(f"  {'sum':24s} {tot:6.2f}")
