@@ -80,6 +80,11 @@ struct LstmSweepArgs {
     const void* WihT;      // [in_p = 32][4*Hp] packed like Whh^T
     float* xpart;
     int skip_dA;           // with xpart: 1 = dA_t is NOT written to the stash (nothing reads the predictor's dA in a planning iteration)
+    // lstm_persist_rs.hip, streamed form (round 5): n_pf extra workgroups behind the sweep's own are PREFETCHERS -- they follow the groups' tile
+    // flags and read the stash rows (gates, c, dL/dh from above) of step t - pf_dist of their group, one dword per 128-byte line, so that the
+    // lines sit in the XCD's L2 when the cell waves load them: a cell wave's loads return in order, and its first flag poll of a step queues
+    // behind the step's stash loads -- from HBM ~2 us, from L2 ~0.3.  Speed only: no result depends on a prefetcher.  0 = none
+    int n_pf, pf_dist;
     int token_handoff;     // lstm_persist_rs.hip, token form (round 4): 1 = the tiles carry their own step token, no flags, no drains; xchg
                            // is then a buffer ONLY this form uses (zero at the start of every launch: the kernel leaves it retired)
 };

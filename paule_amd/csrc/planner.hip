@@ -250,6 +250,7 @@ struct pl_handle {
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
     int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
+    int bwd_pf = 0, bwd_pf_dist = 3;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf)
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
@@ -444,6 +445,15 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
         if (h->bwd_stream == 2 && whole && h->sweep_xchg_tok && h->bwd_waves != 4 && s.xchg == h->sweep_xchg) {
             s8.token_handoff = h->token_early ? 1 : 2;   // 2: diagnostic, no early tile loads (PAULE_HIP_TOKEN_EARLY=0)
             s8.xchg = h->sweep_xchg_tok;
+        }
+        // prefetcher workgroups on the CUs the sweep leaves idle (PAULE_HIP_BWD_PF = workgroups per resident group, 0 off; _PF_DIST steps ahead)
+        s8.n_pf = 0;
+        if (h->bwd_pf > 0 && s8.tflags && !s8.token_handoff && h->bwd_waves != 4 && !((s8.stash_via_lds >> 3) & 3)) {
+            const int n_res = grid / (Hp / 32);
+            int per = h->bwd_pf;
+            while (per > 0 && grid + per * n_res > h->n_cu) --per;
+            s8.n_pf = per * n_res;
+            s8.pf_dist = h->bwd_pf_dist;
         }
         // PAULE_HIP_BWD_CHAINS=C (round 5, probe): the chained form -- a workgroup serves C groups in turn, ceil(groups / C) sets on 8 slots
         if (h->bwd_chains > 0 && s8.tflags && !s8.token_handoff && h->bwd_waves != 4 && Hp == 736 && s.group_rows == 32 &&
@@ -2202,6 +2212,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_SWEEP2")) h->sweep2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_CHAINS")) h->bwd_chains = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_BWD_PF")) h->bwd_pf = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_BWD_PF_DIST")) h->bwd_pf_dist = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;
         if (const char* z = std::getenv("PAULE_HIP_TOKEN_EARLY")) h->token_early = std::atoi(z) != 0;
