@@ -292,7 +292,9 @@ enum { PL_PLAN_FUSED_FWD = 0,      /* 1: role-fused forward launch, 0: per-layer
                                     * memory; the HIP runtime crashes at a later branched launch once such execs are destroyed) */
        PL_PLAN_FUSED_ROWS = 11,     /* batch rows of the fused launches' LSTM roles: 32, 16 (batches of up to 16 rows), 0 = no fused launch */
        PL_PLAN_FWD_PER_CU = 12,     /* workgroups per CU the fused forward launch is written for: 1, 2 (lstm_fused2.hip) or 0 = no fused forward launch */
-       PL_PLAN_COUNT = 13 };
+       PL_PLAN_BWD_PREFETCHERS = 13, /* prefetcher workgroups beside the predictor's streamed per-layer backward sweep (round 5: they warm the XCD's L2 with
+                                     * the stash rows ahead of the cell waves; speed only), 0 = none / another kernel carries the backward pass */
+       PL_PLAN_COUNT = 14 };
 int pl_plan_info(const pl_handle *h, int32_t *out /* host */, int n);
 
 /* Bytes of device memory held by the handle. */

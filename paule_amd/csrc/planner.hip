@@ -250,7 +250,7 @@ struct pl_handle {
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
     int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
-    int bwd_pf = 0, bwd_pf_dist = 3;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf)
+    int bwd_pf = -1, bwd_pf_dist = 4;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf): -1 auto, 0 off
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
@@ -421,6 +421,18 @@ int sweep_group_rows_for(pl_handle* h, int Hp, bool bwd = false) {
     if (h->dt == F32 || use_sweep16(h, Hp, bwd)) return 16;
     return lstm_sweep_group_rows(Hp, h->Bp, h->n_cu);
 }
+// Prefetcher workgroups beside a streamed 32-row backward sweep of `grid` workgroups (round 5): as many per resident group as the idle CUs
+// hold, at most 8 (cfg3: 8 groups x 23 workgroups leave 72 CUs; 4 per group bring 4.99 -> 4.70 ms per iteration, 8 -> 4.66, 9 no more:
+// profiles/r05_ab_prefetchers.txt).  PAULE_HIP_BWD_PF: -1 auto, 0 off, n per group at most.
+int bwd_prefetchers_for(const pl_handle* h, int Hp, int grid) {
+    const int P = Hp / 32;
+    if (h->bwd_pf == 0 || P < 1 || grid < P) return 0;
+    const int n_res = grid / P;
+    int per = h->bwd_pf > 0 ? h->bwd_pf : 8;
+    while (per > 0 && grid + per * n_res > h->n_cu) --per;
+    return per * n_res;
+}
+
 void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, const LstmSweepArgs& s) {
     if (h->dt == F32) {
         int cgrid = 0;
@@ -446,13 +458,10 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
             s8.token_handoff = h->token_early ? 1 : 2;   // 2: diagnostic, no early tile loads (PAULE_HIP_TOKEN_EARLY=0)
             s8.xchg = h->sweep_xchg_tok;
         }
-        // prefetcher workgroups on the CUs the sweep leaves idle (PAULE_HIP_BWD_PF = workgroups per resident group, 0 off; _PF_DIST steps ahead)
+        // prefetcher workgroups on the CUs the sweep leaves idle (lstm_persist_rs.hip: rs_prefetch_role)
         s8.n_pf = 0;
-        if (h->bwd_pf > 0 && s8.tflags && !s8.token_handoff && h->bwd_waves != 4 && !((s8.stash_via_lds >> 3) & 3)) {
-            const int n_res = grid / (Hp / 32);
-            int per = h->bwd_pf;
-            while (per > 0 && grid + per * n_res > h->n_cu) --per;
-            s8.n_pf = per * n_res;
+        if (s8.tflags && !s8.token_handoff && h->bwd_waves != 4 && !((s8.stash_via_lds >> 3) & 3)) {
+            s8.n_pf = bwd_prefetchers_for(h, Hp, grid);
             s8.pf_dist = h->bwd_pf_dist;
         }
         // PAULE_HIP_BWD_CHAINS=C (round 5, probe): the chained form -- a workgroup serves C groups in turn, ceil(groups / C) sets on 8 slots
@@ -3154,6 +3163,16 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
 
 int64_t pl_device_bytes(const pl_handle* h) { return h ? (int64_t)h->bytes : 0; }
 
+// prefetcher workgroups beside the predictor's whole-sequence backward sweep (0: another kernel carries it, or none fit)
+static int bwd_prefetchers_planned(const pl_handle* h) {
+    pl_handle* hm = const_cast<pl_handle*>(h);
+    if (h->dt != BF16 || !h->use_sweep || h->fused_bwd_ok || h->bwd_mode != 1 || !h->sweep_xchg || h->bwd_stream != 1 || h->bwd_waves == 4 ||
+        h->bwd_dma != 0 || h->bwd_chains > 0 || use_sweep16(hm, h->pred.Hp, true))
+        return 0;
+    const int grid = sweep_grid_for(hm, h->pred.Hp, true);
+    return grid > 0 ? bwd_prefetchers_for(h, h->pred.Hp, grid) : 0;
+}
+
 int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
     if (!h || !out || n < 0) return fail(PL_ERR_INVALID, "pl_plan_info: null handle / output");
     const int32_t v[PL_PLAN_COUNT] = {
@@ -3170,6 +3189,7 @@ int pl_plan_info(const pl_handle* h, int32_t* out, int n) {
         g_retained_branched_execs.load(std::memory_order_relaxed),
         h->fused_rows16 ? 16 : ((h->fused_fwd_ok || h->fused_bwd_ok) ? 32 : 0),
         h->fused_fwd_ok ? (h->fused_fwd2 ? 2 : 1) : 0,
+        bwd_prefetchers_planned(h),
     };
     for (int i = 0; i < n && i < PL_PLAN_COUNT; ++i) out[i] = v[i];
     for (int i = PL_PLAN_COUNT; i < n; ++i) out[i] = 0;

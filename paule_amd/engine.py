@@ -512,13 +512,14 @@ class HipPlanner:
         return ms.value, fl.value
 
     PLAN_FIELDS = ("fused_fwd", "fused_bwd", "fwd_chains_pred", "fwd_chains_emb", "bwd_chains_pred", "bwd_chains_emb",
-                   "fwd_workgroups", "bwd_workgroups", "bwd_waves", "n_cu", "retained_execs", "fused_rows", "fwd_per_cu")
+                   "fwd_workgroups", "bwd_workgroups", "bwd_waves", "n_cu", "retained_execs", "fused_rows", "fwd_per_cu", "bwd_prefetchers")
 
     def plan_info(self):
         """The launch schedule the library planned for this handle (include/paule_hip.h: pl_plan_info) as a dict:
         fused_fwd / fused_bwd 0 or 1 (the role-fused launches of lstm_fused.hip), their chain counts and workgroups, ...,
         fused_rows 32 / 16 (batch rows of their LSTM roles: 16 for batches of up to 16 rows, lstm_fused16.h) or 0, fwd_per_cu 1 / 2
-        (workgroups per CU the forward launch is written for: 2 = lstm_fused2.hip) or 0."""
+        (workgroups per CU the forward launch is written for: 2 = lstm_fused2.hip) or 0, bwd_prefetchers = prefetcher workgroups beside the
+        predictor's streamed backward sweep (round 5) or 0."""
         buf = (C.c_int32 * len(self.PLAN_FIELDS))()
         self._call(self.lib.pl_plan_info, buf, len(self.PLAN_FIELDS))
         return dict(zip(self.PLAN_FIELDS, (int(v) for v in buf)))
