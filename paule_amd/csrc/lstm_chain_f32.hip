@@ -274,7 +274,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_chain_f32_kernel(LstmSweepArg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Bp = a.Bp, T = a.T, C = a.chains;
     const int n_groups = Bp / 16, n_sets = (n_groups + C - 1) / C;
-    const int sets_res = gridDim.x / P;
+    const int n_main = (int)gridDim.x - a.n_pf;
+    const int sets_res = n_main / P;
+    if ((int)blockIdx.x >= n_main) {   // prefetcher workgroups (sweep_common.h: speed only): a set's (step, chain) pairs in the sweep's order
+        stash_prefetch_walk(a, Hp, 4, (int)blockIdx.x - n_main, sets_res, T - 1, 0, PfPaceCounters{a.counters, T, a.flag_stride}, C);
+        return;
+    }
     const int set_first = blockIdx.x % sets_res, p = blockIdx.x / sets_res;
     const float* __restrict__ WT = static_cast<const float*>(a.W);
     const int kq = lane >> 4;
@@ -477,7 +482,7 @@ void launch_lstm_chain_f32(hipStream_t stream, bool backward, int Hp, int grid, 
     const int ksx = (!backward && a.x_in) ? a.in_p / 16 : 0;
 #define PL_CASE(K)                                                                                                              \
     if (Hp == 16 * K) {                                                                                                         \
-        if (backward) hipLaunchKernelGGL((lstm_bwd_chain_f32_kernel<K>), dim3(grid), dim3(256), 0, stream, a);                  \
+        if (backward) hipLaunchKernelGGL((lstm_bwd_chain_f32_kernel<K>), dim3(grid + a.n_pf), dim3(256), 0, stream, a);         \
         else if (ksx == 2) hipLaunchKernelGGL((lstm_fwd_chain_f32_kernel<K, 2>), dim3(grid), dim3(256), 0, stream, a);          \
         else if (ksx == 4) hipLaunchKernelGGL((lstm_fwd_chain_f32_kernel<K, 4>), dim3(grid), dim3(256), 0, stream, a);          \
         else hipLaunchKernelGGL((lstm_fwd_chain_f32_kernel<K, 0>), dim3(grid), dim3(256), 0, stream, a);                        \

@@ -262,59 +262,26 @@ typedef __attribute__((address_space(3))) unsigned char* rs_lds_ptr_t;
 // tile of 8 MFMAs, produced behind the wave's exchange tiles and stored as f32 straight from the accumulators (no flag, nobody waits
 // for it in the launch).  launch_dx_reduce sums the P partials afterwards; the batched product, which re-read the whole dA stash,
 // is gone (cfg3: 107 us -> ~45 us).  The recurrence itself is untouched: every dA and every exchange tile keep their bits.
-// Prefetcher workgroups of the streamed sweeps (LstmSweepArgs::n_pf, round 5).  A cell wave's vector-memory operations return in order, and
-// the first flag poll of a step is issued behind the step's stash loads (gates, c_t, c_{t-1}, dL/dh from above: written by the forward
-// launch milliseconds ago, so they come from HBM): the poll's answer -- and with it every tile load -- waits ~2 us for them however early
-// the tiles were there (profiles/r05_chain_stamps.txt: a workgroup that serves two groups in turn still spends 2.6 us per chain-step in
-// "polls + tile loads").  Moving the stash loads to other waves of the workgroup moves the delay to those waves' tile flags (round 4, A.9).
-// Workgroups on the CUs the sweep leaves idle do it instead: workgroup q follows the groups of slot q % n_res -- the groups its
-// blockIdx % 8 shares an XCD with under the observed dealing -- pf_dist steps ahead of their tile flags and reads one dword of every
-// 128-byte line of the stash rows, so that the lines sit in that XCD's L2 when the cell waves ask for them.  Speed only: nothing waits
-// for a prefetcher, and a prefetcher waits for nobody longer than 20 us.
+// Prefetcher workgroups of the streamed sweeps (LstmSweepArgs::n_pf; sweep_common.h: stash_prefetch_walk), paced on the per-tile flags:
+// the row of destination 0 holds step tokens u + 1 of the steps with u's parity, and later steps overwrite them with smaller ones
 template <int KS>
 __device__ __forceinline__ void rs_prefetch_role(const LstmSweepArgs& a, const int q, const int n_res) {
-    constexpr int Hp = 16 * KS, P = Hp / 32, G4 = 4 * Hp;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int Bp = a.Bp, T = a.T, gs = a.group_rows, n_groups = (Bp + gs - 1) / gs;
-    const int per = a.n_pf / n_res;           // prefetchers per group slot: each takes an interleaved share of the lines
-    const int g_first = q % n_res, part = q / n_res;
-    if (per < 1 || part >= per) return;
-    const int D = a.pf_dist > 0 ? a.pf_dist : 4;
-    const size_t slabG = (size_t)Bp * G4 * 2, slabH = (size_t)Bp * Hp * 2;   // bytes
-    const unsigned char* G = static_cast<const unsigned char*>(a.G);
-    const unsigned char* Cs = static_cast<const unsigned char*>(a.c);
-    const unsigned char* dhe = static_cast<const unsigned char*>(a.dh_ext);
-    unsigned acc = 0;
-    for (int g = g_first; g < n_groups; g += n_res) {
-        const int r0 = gs * g, nr = (r0 + gs <= Bp ? gs : Bp - r0);
-        const unsigned bytesG = (unsigned)((size_t)nr * G4 * 2), bytesH = (unsigned)((size_t)nr * Hp * 2);
-        const unsigned linesG = (bytesG + 127) / 128, linesH = (bytesH + 127) / 128;
-        const unsigned n_lines = linesG + linesH + (dhe ? linesH : 0u);
-        for (int t = T - 1; t >= 0; --t) {
-            const int u = t + D;
-            if (u <= T - 1 && u >= 1 && a.tflags) {   // pace: the group has handed over the tiles of step u (destination 0's row of flags)
-                const int* frow = a.tflags + ((size_t)(u & 1) * n_groups + g) * P * 32;
-                const __amdgpu_buffer_rsrc_t rf = make_rsrc(frow, (unsigned)(P * 4));
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    int v = 1;
-                    if (lane < P) v = (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
-                    if (__all(v != 0 && v <= u + 1)) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 2000ull) break;   // 20 us without news (plain flags of a group on another XCD, an abandoned sweep): go on unpaced
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG + (size_t)r0 * G4 * 2, bytesG);
-            const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)t * slabH + (size_t)r0 * Hp * 2, bytesH);
-            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dhe ? dhe + (size_t)t * slabH + (size_t)r0 * Hp * 2 : Cs, dhe ? bytesH : 0u);
-            for (unsigned l = (unsigned)(part * 512 + tid); l < n_lines; l += (unsigned)(per * 512)) {
-                if (l < linesG) acc ^= __builtin_amdgcn_raw_buffer_load_b32(rg, l * 128u, 0, 0);
-                else if (l < linesG + linesH) acc ^= __builtin_amdgcn_raw_buffer_load_b32(rc, (l - linesG) * 128u, 0, 0);
-                else acc ^= __builtin_amdgcn_raw_buffer_load_b32(rd, (l - linesG - linesH) * 128u, 0, 0);
-            }
+    constexpr int Hp = 16 * KS, P = Hp / 32;
+    const int gs = a.group_rows, n_groups = (a.Bp + gs - 1) / gs;
+    const int lane = threadIdx.x & 63;
+    stash_prefetch_walk(a, Hp, 2, q, n_res, a.T - 1, 0, [&](int g, int u) {
+        if (u < 1 || !a.tflags) return;
+        const int* frow = a.tflags + ((size_t)(u & 1) * n_groups + g) * P * 32;
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(frow, (unsigned)(P * 4));
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            int v = 1;
+            if (lane < P) v = (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
+            if (__all(v != 0 && v <= u + 1)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000ull) break;   // 20 us without news: go on unpaced
+            __builtin_amdgcn_s_sleep(16);
         }
-    }
-    if (acc == 0x7fc01234u && a.status) __hip_atomic_fetch_or(a.status, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // keeps the loads alive, changes nothing
+    });
 }
 
 template <int KS, int DMAV, int XT = 0>   // DMAV bit 0: stash rows by LDS-DMA a step ahead; bit 1: dA_t stored by waves 4 .. 7 from the image

@@ -424,8 +424,8 @@ int sweep_group_rows_for(pl_handle* h, int Hp, bool bwd = false) {
 // Prefetcher workgroups beside a streamed 32-row backward sweep of `grid` workgroups (round 5): as many per resident group as the idle CUs
 // hold, at most 8 (cfg3: 8 groups x 23 workgroups leave 72 CUs; 4 per group bring 4.99 -> 4.70 ms per iteration, 8 -> 4.66, 9 no more:
 // profiles/r05_ab_prefetchers.txt).  PAULE_HIP_BWD_PF: -1 auto, 0 off, n per group at most.
-int bwd_prefetchers_for(const pl_handle* h, int Hp, int grid) {
-    const int P = Hp / 32;
+int bwd_prefetchers_for(const pl_handle* h, int Hp, int grid, int slice = 32) {   // slice: hidden units per workgroup (32 bf16, 16 f32)
+    const int P = Hp / slice;
     if (h->bwd_pf == 0 || P < 1 || grid < P) return 0;
     const int n_res = grid / P;
     int per = h->bwd_pf > 0 ? h->bwd_pf : 8;
@@ -440,8 +440,11 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
         if (C > 0 && s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T)) {
             LstmSweepArgs sc = s;
             sc.chains = C;
+            if (bwd) { sc.n_pf = bwd_prefetchers_for(h, Hp, cgrid, 16); sc.pf_dist = h->bwd_pf_dist; }
             launch_lstm_chain_f32(st, bwd, Hp, cgrid, sc);
         } else {
+            // (no prefetchers beside the one-chain f32 sweeps: their step is MFMA issue, 3.1 of 6.0 us, and the flag wait 0.8 -- cfg2 3.88 ms
+            // per iteration with and without, profiles/r05_ab_prefetchers.txt; the chains kernel above gains 4 %)
             launch_lstm_sweep_f32(st, bwd, Hp, grid, s);
         }
     }

@@ -143,6 +143,77 @@ __device__ __forceinline__ void cell_bwd(float dh, float dc_in, float gi, float 
     dc_out = dc * gf;
 }
 
+// ---- stash prefetchers (round 5) -----------------------------------------------------------------------------------------
+// A cell-owning wave's vector-memory operations return in order, and the first flag poll of a backward step is issued behind the step's
+// stash loads (gates, c_t, c_{t-1}, dL/dh from above: written by the forward pass milliseconds ago, so they come from HBM): the poll's
+// answer -- and with it every load of handed-over bytes -- waits ~2 us for them however early the hand-off was there
+// (profiles/r05_chain_stamps.txt: a workgroup that serves two groups in turn still spends 2.6 us per chain-step in "polls + tile loads").
+// Moving the stash loads to other waves of the workgroup moves the delay to those waves' hand-off flags (round 4, A.9; round 5's
+// in-workgroup touches: profiles/r05_ab_prefetchers.txt).  PREFETCHER workgroups on the CUs a sweep leaves idle do it instead: appended
+// to the sweep's grid, workgroup q follows the groups of slot q % n_res -- the groups its blockIdx % 8 shares an XCD with under the
+// observed dealing -- `dist` steps ahead of their hand-off flags and reads one dword of every 128-byte line of the stash rows of that
+// step, so that the lines sit in that XCD's L2 when the cell waves ask for them.  Speed only: nothing waits for a prefetcher, a
+// prefetcher waits for nobody longer than 20 us, and a launch without them computes the same bits.
+// pace(g, u): returns once group g has handed over step u (bounded).  elt: bytes per stash element (2 bf16, 4 f32).
+// chains: groups a workgroup of the sweep serves in turn per step (1: a workgroup takes its groups one after the other); a slot's
+// prefetchers walk the (step, chain) pairs in the sweep's order.  When the slots of one group sit on 8 / n_res XCDs (n_res divides 8:
+// blocks b, b + n_res, ... of the slot), the prefetchers of each of those XCDs share ALL lines among themselves.
+template <typename Pace>
+__device__ __forceinline__ void stash_prefetch_walk(const LstmSweepArgs& a, int Hp, int elt, int q, int n_res, int t_hi, int t_lo, Pace pace,
+                                                    int chains = 1) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int Bp = a.Bp, gs = a.group_rows, n_groups = (Bp + gs - 1) / gs;
+    const int C = chains < 1 ? 1 : chains, n_sets = (n_groups + C - 1) / C;
+    int per = a.n_pf / n_res;                 // prefetchers per slot
+    const int s_first = q % n_res;
+    int part = q / n_res;
+    if (per < 1 || part >= per) return;
+    const int xs = (n_res <= 8 && 8 % n_res == 0 && per % (8 / n_res) == 0) ? 8 / n_res : 1;   // XCDs a slot's workgroups sit on (observed dealing)
+    part /= xs;
+    per /= xs;
+    const int D = a.pf_dist > 0 ? a.pf_dist : 4;
+    const size_t rowG = (size_t)4 * Hp * elt, rowH = (size_t)Hp * elt;
+    const size_t slabG = (size_t)Bp * rowG, slabH = (size_t)Bp * rowH;
+    const unsigned char* G = static_cast<const unsigned char*>(a.G);
+    const unsigned char* Cs = static_cast<const unsigned char*>(a.c);
+    const unsigned char* dhe = static_cast<const unsigned char*>(a.dh_ext);
+    unsigned acc = 0;
+    for (int set = s_first; set < n_sets; set += n_res) {
+        for (int t = t_hi; t >= t_lo; --t) {
+            for (int c = 0; c < C; ++c) {
+                const int g = set * C + c;
+                if (g >= n_groups) break;
+                const int r0 = gs * g, nr = (r0 + gs <= Bp ? gs : Bp - r0);
+                const unsigned bytesG = (unsigned)(nr * rowG), bytesH = (unsigned)(nr * rowH);
+                const unsigned linesG = (bytesG + 127) / 128, linesH = (bytesH + 127) / 128;
+                const unsigned n_lines = linesG + linesH + (dhe ? linesH : 0u);
+                if (t + D <= t_hi) pace(g, t + D);
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG + (size_t)r0 * rowG, bytesG);
+                const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)t * slabH + (size_t)r0 * rowH, bytesH);
+                const __amdgpu_buffer_rsrc_t rd = make_rsrc(dhe ? dhe + (size_t)t * slabH + (size_t)r0 * rowH : Cs, dhe ? bytesH : 0u);
+                for (unsigned l = (unsigned)(part * nth + tid); l < n_lines; l += (unsigned)(per * nth)) {
+                    if (l < linesG) acc ^= __builtin_amdgcn_raw_buffer_load_b32(rg, l * 128u, 0, 0);
+                    else if (l < linesG + linesH) acc ^= __builtin_amdgcn_raw_buffer_load_b32(rc, (l - linesG) * 128u, 0, 0);
+                    else acc ^= __builtin_amdgcn_raw_buffer_load_b32(rd, (l - linesG - linesH) * 128u, 0, 0);
+                }
+            }
+        }
+    }
+    if (acc == 0x7fc01234u && a.status) __hip_atomic_fetch_or(a.status, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // keeps the loads alive, changes nothing
+}
+// pace on the per-workgroup arrival flags of the whole-workgroup hand-off (counters [group][step][flag_stride]): slice 0's flag of step u
+struct PfPaceCounters {
+    const int* counters; int T, flag_stride;
+    __device__ __forceinline__ void operator()(int g, int u) const {
+        const int* f = counters + ((size_t)g * T + u) * flag_stride;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000ull) break;   // 20 us without news (plain flags of a group on another XCD, an abandoned sweep): unpaced
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+};
+
 #ifdef PL_STAMPS
 #define PL_ST(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
 #define PL_ST_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
