@@ -3172,6 +3172,7 @@ static int bwd_prefetchers_planned(const pl_handle* h) {
     if (h->dt != BF16 || !h->use_sweep || h->fused_bwd_ok || h->bwd_mode != 1 || !h->sweep_xchg || h->bwd_stream != 1 || h->bwd_waves == 4 ||
         h->bwd_dma != 0 || h->bwd_chains > 0 || use_sweep16(hm, h->pred.Hp, true))
         return 0;
+    if (h->pred.L > 1 && (h->wf_dirs & 2) && wavefront_chunks(hm, h->pred, h->pred.Tl, 0) > 0) return 0;   // time chunks keep the whole-workgroup hand-off: no prefetchers
     const int grid = sweep_grid_for(hm, h->pred.Hp, true);
     return grid > 0 ? bwd_prefetchers_for(h, h->pred.Hp, grid) : 0;
 }

@@ -360,21 +360,28 @@ def test_backward_sweep_forms_are_bit_identical(HipPlanner, monkeypatch, shape):
     monkeypatch.setenv("PAULE_HIP_FUSED", "1")   # fused forward launch + per-layer backward sweeps, as cfg3 runs
     monkeypatch.setenv("PAULE_HIP_BWD_XT", "0")  # dL/dCP by the batched product in all three forms (round 4's ride-along tile sums it in another order)
     out = {}
+    # round 5: the streamed form without its prefetcher workgroups (they only warm the L2: speed, never bits), and the chained form -- a
+    # workgroup serves two / three groups in turn with one copy of its weights (PAULE_HIP_BWD_CHAINS; a probe, lstm_bwd_rs_chain_kernel)
     for form, env in (("w4", dict(PAULE_HIP_BWD_WAVES="4")), ("w8", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="0")),
-                      ("stream", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1"))):
-        for k in ("PAULE_HIP_BWD_WAVES", "PAULE_HIP_BWD_STREAM"):
+                      ("stream", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1")),
+                      ("stream_nopf", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1", PAULE_HIP_BWD_PF="0")),
+                      ("chain2", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1", PAULE_HIP_BWD_CHAINS="2")),
+                      ("chain3", dict(PAULE_HIP_BWD_WAVES="8", PAULE_HIP_BWD_STREAM="1", PAULE_HIP_BWD_CHAINS="3"))):
+        for k in ("PAULE_HIP_BWD_WAVES", "PAULE_HIP_BWD_STREAM", "PAULE_HIP_BWD_PF", "PAULE_HIP_BWD_CHAINS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
         assert eng.plan_info()["bwd_waves"] == (4 if form == "w4" else 8)
+        if shape["set"] == "A":   # the predictor's own sweep: prefetchers beside the streamed form only (every shape here leaves CUs idle)
+            assert (eng.plan_info()["bwd_prefetchers"] > 0) == (form == "stream"), (form, eng.plan_info())
         eng.set_targets(wl.target_mel, wl.target_semvec)
         eng.set_cp(wl.cp0)
         loss = _n(eng.step(3))
         eng.synchronize()
         out[form] = dict(loss=loss, cp=_n(eng.get_cp()), dX=_n(eng.debug_read("dX")), G=_n(eng.debug_read("emb.G0")))
         eng.close()
-    for form in ("w8", "stream"):
+    for form in ("w8", "stream", "stream_nopf", "chain2", "chain3"):
         for k in ("loss", "cp", "dX", "G"):
             np.testing.assert_array_equal(out[form][k], out["w4"][k], err_msg=f"{form}: {k}")
 
@@ -1876,6 +1883,9 @@ def test_full_size_cfg3_bf16_against_oracle_rows(HipPlanner, B):
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
     plan = eng.plan_info()   # the schedule this test says it covers is the one the library planned
     assert plan["fused_fwd"] == 1 and plan["fused_bwd"] == (0 if B == 256 else 1) and plan["bwd_waves"] == 8, plan
+    # ... down to the forward launch's form (256 rows: two workgroups per CU, lstm_fused2.hip) and the prefetcher workgroups beside the
+    # backward sweeps (round 5): a declined plan must not pass this test on the older kernels
+    assert plan["fwd_per_cu"] == (2 if B == 256 else 1) and (plan["bwd_prefetchers"] > 0) == (B == 256), plan
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     loss = _n(eng.step(n))
@@ -2088,6 +2098,8 @@ def test_full_size_cfg3_bf16_vs_rounding_emulation(HipPlanner):
     wl = og.workload("cfg3_rows")
     ref = og.get("cfg3_rows")   # oracle/bf16_emul.py on rows 0 and 255: the predictor's h stash (bf16 patterns) and dL/dCP
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    plan = eng.plan_info()   # the headline schedule and nothing older: two-per-CU forward launch, streamed backward sweeps with their prefetchers
+    assert plan["fused_fwd"] == 1 and plan["fwd_per_cu"] == 2 and plan["fused_bwd"] == 0 and plan["bwd_waves"] == 8 and plan["bwd_prefetchers"] > 0, plan
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     eng.step(1, return_loss=False)
