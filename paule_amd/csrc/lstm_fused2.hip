@@ -26,6 +26,9 @@
 #ifndef FUSED2_STREAMED_W
 #define FUSED2_STREAMED_W 4   // W_hh fragments (k-steps) of a recurrence role that are fetched per chain-step instead of staying in registers
 #endif
+#ifndef FUSED2_PF
+#define FUSED2_PF 3           // B fragments read ahead of the MFMA that consumes them (recurrence roles)
+#endif
 #ifndef FUSED2_SPLIT_TILE
 #define FUSED2_SPLIT_TILE 1   // 1: the h tile's landing is waited for in two halves around the MFMA chain (measured: DESIGN.md 4.0d)
 #endif
@@ -93,7 +96,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
     static_assert(KS % 2 == 0, "whole 32-unit tiles");
     constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32;
     constexpr int ROWB = Hp * 2, HRS = L::HRS, XRS = L::XRS;
-    constexpr int PF = 3;                             // B-fragment read-ahead
+    constexpr int PF = FUSED2_PF;                     // B-fragment read-ahead
     constexpr int NP1 = FUSED2_SPLIT_TILE ? (P + 3) / 4 : (P + 1) / 2;   // pieces per wave in the first half of the tile (tiles 0 .. 2 NP1 - 1)
     constexpr int KH = FUSED2_SPLIT_TILE ? 4 * NP1 : KS;                 // ... = k-steps 0 .. KH - 1
     constexpr int PK = KS / 2;                        // k-step of the look at the next chain-step's flags (two chains)
@@ -130,7 +133,6 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
 #pragma unroll
         for (int ks = NWT; ks < KS; ++ks) pin(wreg[ks]);   // pinned after ALL loads are out: load + pin in one loop waited for every load by itself
     }
-    const int bl = lane & 31, hh = lane >> 5;
     // the input projection's weight fragments are fetched per chain-step as well, half way through the MFMA chain (they multiply last):
     // they take the registers the streamed W_hh fragments have left by then
     uint4 wx[KSX ? KSX : 1];
@@ -158,9 +160,8 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
     bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c);
     const bool src_sc1 = R.src_sc1 != 0;   // x / G rows come from a role of this launch: write-through loads
     const bf16_t* const x_in = static_cast<const bf16_t*>(R.x_in);
-    // B fragment of k-step ks: tile ks >> 1, row bl, chunk 2 (ks & 1) + hh
-    const unsigned char* const bsrc0 = himg + bl * 64 + ((hh ^ img_swz<false>(bl)) * 16);
-    const unsigned char* const bsrc1 = himg + bl * 64 + (((2 + hh) ^ img_swz<false>(bl)) * 16);
+    // B fragment of k-step ks: tile ks >> 1, row bl, chunk 2 (ks & 1) + hh (addresses: per chain-step, from the opaque lane index -- held across
+    // the loop they were spilled, and the reload in front of the first MFMA carried an s_waitcnt vmcnt(0) that waited for the WHOLE tile)
 
     // the five stash arrays of a chain-step (gates i f g o, c; nobody inside the launch waits for them) leave LDS BEHIND the flag: issued
     // in front of it they sat on the group's critical path (0.9 us a chain-step; behind the next chain-step's tile requests they delayed
@@ -194,6 +195,8 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int lane_q = tq & 63, bl_q = lane_q & 31, hh_q = lane_q >> 5;
+        const unsigned char* const bsrc0 = himg + bl_q * 64 + ((hh_q ^ img_swz<false>(bl_q)) * 16);
+        const unsigned char* const bsrc1 = himg + bl_q * 64 + (((2 + hh_q) ^ img_swz<false>(bl_q)) * 16);
         const int g = set * RC + c;
         int cn = c + 1, tn = t;
         if (cn == Ca) { cn = 0; tn = t + 1; }
