@@ -72,6 +72,21 @@ __device__ __forceinline__ void dma_image(const void* slab, int g, int Bp, unsig
         if (2 * j + hi < P) glds16_sc1(uni(src + j * 128), voff, (unsigned)uni((int)(dst + (unsigned)(j * 4096))));
 }
 
+// The same image from the role's PRIVATE copy of the hand-off (round 5): tile-major [slice kb][32 rows][64 B] -- a slice is 2 KB contiguous,
+// 16 whole lines stored plainly by the one workgroup that owns it -- fetched through the XCD's L2 (nt).  One wave instruction = one
+// contiguous 1-KB piece; the chunk permutation of the image sits on the global side as before.
+template <int P, bool GEMM>
+__device__ __forceinline__ void dma_image_tiles(const unsigned char* tiles, unsigned img_lds, int wave, int lane) {
+    const int half = wave & 1, hi = wave >> 1;
+    const int row = 16 * half + (lane >> 2);
+    const unsigned voff = (unsigned)(row * 64 + (((lane & 3) ^ img_swz<GEMM>(row)) * 16));
+    const unsigned char* src = tiles + hi * 2048;
+    const unsigned dst = img_lds + (unsigned)(hi * 2048 + half * 1024);
+#pragma unroll
+    for (int j = 0; j < (P + 1) / 2; ++j)
+        if (2 * j + hi < P) glds16_nt(uni(src + j * 4096), voff, (unsigned)uni((int)(dst + (unsigned)(j * 4096))));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward recurrence of one layer (arithmetic of lstm_fwd_sweep_kernel / fused_lstm_fwd)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -90,7 +105,11 @@ struct LstmFwd2Lds {
     static constexpr int BYTES = O_FLAG + 64;
 };
 
-template <int KS, int KSX>
+// SC1: the role's input rows (x / G) are written by a role of this launch: write-through loads, issued behind the flag wait.  A compile-time
+// fact of the instantiation, because the waits differ: rows that nobody in the launch writes are fetched in front of the flag wait and have
+// landed before the tile's pieces go out, and the compiler's s_waitcnt for a load still in flight on ONE path of a run-time choice would sit
+// on both (SC1 = true is correct for any role, only slower for rows that could have come early).
+template <int KS, int KSX, bool SC1>
 __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = LstmFwd2Lds<KS, KSX>;
     static_assert(KS % 2 == 0, "whole 32-unit tiles");
@@ -158,8 +177,22 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
     bf16_t* __restrict__ G = static_cast<bf16_t*>(R.G);
     bf16_t* __restrict__ Hs = static_cast<bf16_t*>(R.h);
     bf16_t* __restrict__ Cs = static_cast<bf16_t*>(R.c);
-    const bool src_sc1 = R.src_sc1 != 0;   // x / G rows come from a role of this launch: write-through loads
+    constexpr bool src_sc1 = SC1;   // x / G rows come from a role of this launch: write-through loads
     const bf16_t* const x_in = static_cast<const bf16_t*>(R.x_in);
+    // The role's OWN exchange through the XCD's L2 (round 5; tools/microbench/allgather_step.hip: 5.9 -> 4.5 us a step at two workgroups per CU):
+    // written through, the h slices drop out of the L2 and all 23 workgroups of a set fetch the same 47 KB from the memory side, 64-byte half
+    // lines at a time.  Every workgroup ALSO stores its slice plainly into a private tile-major copy (R.hx: [2 slots][groups][P][32 rows][64 B],
+    // whole lines) and raises a second, plain flag (R.fast_flags); it publishes its XCD with its first hand-off, the members of a set compare at
+    // chain-step (c = 0, t = 1) -- behind their first completed wait on each other -- and a set that is whole on one XCD reads the private copy
+    // (nt LDS-DMA), polls the plain flags (nt), and moves the write-through h store and flag, which only OTHER roles read, out of its own way:
+    // behind the plain flag, the write-through flag one chain-step late (a wave's stores complete in order: the next drain covers them).
+    // Placement is never assumed, the bits do not change.
+    unsigned char* const hx = static_cast<unsigned char*>(R.hx);
+    int* const xtab = (hx && R.xtab) ? R.xtab + set * 64 : nullptr;
+    const long fdelta = (xtab && R.fast_flags) ? (long)(R.fast_flags - R.flags) : 0;
+    const size_t hx_grp = (size_t)P * 2048, hx_slot = (size_t)a.n_groups * hx_grp;
+    bool fast = false;
+    int wt_g = -1, wt_t = -1;   // fast: the write-through flag of the chain-step before is still to be raised
     // B fragment of k-step ks: tile ks >> 1, row bl, chunk 2 (ks & 1) + hh (addresses: per chain-step, from the opaque lane index -- held across
     // the loop they were spilled, and the reload in front of the first MFMA carried an s_waitcnt vmcnt(0) that waited for the WHOLE tile)
 
@@ -209,28 +242,34 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff + 32u * ks, 0, 0);
             wreg[ks] = make_uint4(v[0], v[1], v[2], v[3]);
         }
+        // Input rows that no role of this launch writes (the predictor's CP frames) do not depend on anybody's flag either: fetched here, they
+        // have landed by the time the flags are up
+        uint4 xv = make_uint4(0, 0, 0, 0);
+        constexpr bool kXEarly = KSX > 0 && !SC1;
+        if constexpr (KSX > 0) {
+            if (!src_sc1 && wave < XC / 2) {   // 32 x XC threads = XC / 2 whole waves: a scalar branch
+                int rb = 32 * g + tq / XC;
+                rb = rb < Bp ? rb : Bp - 1;
+                xv = gld<uint4>(x_in + ((size_t)t * Bp + rb) * INP + (tq % XC) * 8);
+            }
+        }
         // 0. what this chain-step waits for (bounded; the barrier inside also closes the last chain-step's LDS reads)
         if (!ready) {
-            const FlagPoll s0 = step_flags(a, WT_, g, t, p);
+            FlagPoll s0 = step_flags(a, WT_, g, t, p);
+            if (fast && s0.na > 0) { s0.fa += fdelta; s0.fa_nt = 1; }   // the set's own flags of step t - 1: the plain set
             if (!poll_empty(s0) && !flags_wait(s0, a.status, lflag + 1, a.spin_ticks, a.poll_mask)) return;
         }
         PL_ST(0);   // wait for the chain-step's flags
 
         // A. operands: the small x / projection rows into registers, the h tile straight into LDS
-        uint4 xv = make_uint4(0, 0, 0, 0);
         uint2 gxn[4] = {};
         uint4 gv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         if constexpr (KSX > 0) {
-            if (wave < XC / 2) {   // 32 x XC threads = XC / 2 whole waves: a scalar branch
-                const int row = tq / XC, cc = tq % XC;
-                int rb = 32 * g + row;
+            if (src_sc1 && wave < XC / 2) {
+                int rb = 32 * g + tq / XC;
                 rb = rb < Bp ? rb : Bp - 1;
-                if (src_sc1) {
-                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x_in + (size_t)t * Bp * INP, (unsigned)((size_t)Bp * INP * 2));
-                    xv = ld16_sc1(rx, (unsigned)((rb * INP + cc * 8) * 2));
-                } else {
-                    xv = gld<uint4>(x_in + ((size_t)t * Bp + rb) * INP + cc * 8);
-                }
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(x_in + (size_t)t * Bp * INP, (unsigned)((size_t)Bp * INP * 2));
+                xv = ld16_sc1(rx, (unsigned)((rb * INP + (tq % XC) * 8) * 2));
             }
         } else {
             if (src_sc1) {
@@ -249,66 +288,87 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
                 for (int q = 0; q < 4; ++q) gxn[q] = gld<uint2>(g_row + q * Hp);
             }
         }
-        if (t > 0) {
-            dma_image<P, ROWB, false>(Hs + (size_t)(t - 1) * slabH, g, Bp, himg_lds, wave, lane_q);
-            // the tile in two halves: the first KH k-steps' pieces (a wave's first NP1, and everything older) have landed when all but
-            // its youngest pieces have; the second half lands under the first half's MFMAs
-            if (!FUSED2_SPLIT_TILE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P + 1) / 2 - NP1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P / 2 - NP1 > 0 ? P / 2 - NP1 : 0) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if constexpr (KSX > 0) {
-            if (wave < XC / 2) *reinterpret_cast<uint4*>(ximg + (tq / XC) * XRS + (tq % XC) * 16) = xv;
-        } else {
-            if (src_sc1) {
+        // the input rows go to their LDS image where waiting for them costs nothing: rows fetched in front of the flag wait at once, rows a role
+        // of this launch wrote (issued just now, in front of the tile's pieces) behind the SECOND half's landing wait -- the x-projection
+        // multiplies last, and the cell update reads the projection rows after the chain
+        auto stage_x = [&]() {
+            if constexpr (KSX > 0) {
+                if (wave < XC / 2) *reinterpret_cast<uint4*>(ximg + (tq / XC) * XRS + (tq % XC) * 16) = xv;
+            } else {
+                if (src_sc1) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int e = tq + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
-                    *reinterpret_cast<uint4*>(ximg + row * L::GRS + gate * 64 + q4 * 16) = gv[q];
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = tq + 256 * q, row = e >> 4, gate = (e >> 2) & 3, q4 = e & 3;
+                        *reinterpret_cast<uint4*>(ximg + row * L::GRS + gate * 64 + q4 * 16) = gv[q];
+                    }
                 }
             }
-        }
-        __syncthreads();
-        if constexpr (KSX == 0) {
-            if (src_sc1) {
-                const unsigned char* gsrc = ximg + bl_q * L::GRS + (8 * wave + 4 * hh_q) * 2;
+        };
+        auto read_gx = [&]() {
+            if constexpr (KSX == 0) {
+                if (src_sc1) {
+                    const unsigned char* gsrc = ximg + bl_q * L::GRS + (8 * wave + 4 * hh_q) * 2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const uint2*>(gsrc + q * 64);
+                    for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const uint2*>(gsrc + q * 64);
+                }
             }
-        }
-
-        PL_ST(1);   // operands: issue -> landed -> barrier
+        };
+        const bool x_late = t > 0 && src_sc1 && FUSED2_SPLIT_TILE;   // staged at the half-way point of the MFMA chain
+        // Everything the compiler itself has in flight is waited for HERE, in front of the tile's pieces (on every path: a wait the compiler
+        // still owes on ONE path comes out as s_waitcnt vmcnt(0) behind the merge): it does not count the pieces (inline asm), so its wait for
+        // any load it issued earlier came out as s_waitcnt vmcnt(0) somewhere between the first-half wait and the first MFMA -- which waited
+        // for the WHOLE tile, and the split landing never overlapped anything (round 4).  The streamed weight fragments and the
+        // early input rows were fetched in front of the flag wait: they have landed.
+#pragma unroll
+        for (int ks = 0; ks < NWT; ++ks) asm volatile("" ::"v"(wreg[ks].x), "v"(wreg[ks].y), "v"(wreg[ks].z), "v"(wreg[ks].w));
+        if constexpr (kXEarly) asm volatile("" ::"v"(xv.x), "v"(xv.y), "v"(xv.z), "v"(xv.w));
         // B. with a second chain: a look at ITS flags from inside the MFMA chain (with one chain the next chain-step waits for the
         // flag this one raises at its end)
         FlagPoll pn{nullptr, 0, nullptr, 0, nullptr, 0};
         const bool look = has_next && Ca > 1;
         if (look) pn = step_flags(a, WT_, gn, tn, p);
+        if (look && fast && pn.na > 0) { pn.fa += fdelta; pn.fa_nt = 1; }
         int pv = 1;
         const bool poll_here = wave == 0 && look;
-
         // C. gates = W_hh h_{t-1} (+ W_ih x_t + b)
         f32x16 acc;
-        if constexpr (KSX > 0) {
-            const float4* bs = reinterpret_cast<const float4*>(lds + L::O_BIAS) + (wave * 2 + hh_q) * 4;
+        auto acc_init = [&]() {
+            if constexpr (KSX > 0) {
+                const float4* bs = reinterpret_cast<const float4*>(lds + L::O_BIAS) + (wave * 2 + hh_q) * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 bv = bs[i];
-                acc[4 * i] = bv.x; acc[4 * i + 1] = bv.y; acc[4 * i + 2] = bv.z; acc[4 * i + 3] = bv.w;
+                for (int i = 0; i < 4; ++i) {
+                    const float4 bv = bs[i];
+                    acc[4 * i] = bv.x; acc[4 * i + 1] = bv.y; acc[4 * i + 2] = bv.z; acc[4 * i + 3] = bv.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
+        };
+        // (ONE branch on t > 0 for operands and chain together: with two, the loads of the t = 0 path -- x-projection fragments, the look's
+        // poll -- were still owed at the merge in front of the chain, and the compiler put its s_waitcnt vmcnt(0) in front of the first MFMA)
         if (t > 0) {
+            if (fast) dma_image_tiles<P, false>(hx + (size_t)((t - 1) & 1) * hx_slot + (size_t)g * hx_grp, himg_lds, wave, lane_q);
+            else dma_image<P, ROWB, false>(Hs + (size_t)(t - 1) * slabH, g, Bp, himg_lds, wave, lane_q);
+            // the tile in two halves: the first KH k-steps' pieces (a wave's first NP1, and everything older) have landed when all but
+            // its youngest pieces have; the second half lands under the first half's MFMAs
+            if (!FUSED2_SPLIT_TILE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P + 1) / 2 - NP1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P / 2 - NP1 > 0 ? P / 2 - NP1 : 0) : "memory");
+            if (!x_late) stage_x();
+            __syncthreads();
+            if (!x_late) read_gx();
+            PL_ST(1);   // operands: issue -> landed -> barrier
+            acc_init();
             uint4 bq[PF];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 constexpr int K0[2] = {0, KH}, K1[2] = {KH, KS};
-                if (half == 1 && K0[1] < K1[1]) {   // the second half of the tile
+                if (half == 1 && K0[1] < K1[1]) {   // the second half of the tile (and, with it, input rows that a role of this launch wrote)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (x_late) stage_x();
                     __syncthreads();
+                    if (x_late) read_gx();
                 }
                 if (half == 1) fetch_wx();
 #pragma unroll
@@ -325,6 +385,12 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
                 }
             }
         } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage_x();
+            __syncthreads();
+            read_gx();
+            PL_ST(1);
+            acc_init();
             fetch_wx();
             if (poll_here) pv = poll_load(pn, lane);
         }
@@ -374,18 +440,55 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
             }
             cst[c * 256 + tq] = make_float4(c_state[0], c_state[1], c_state[2], c_state[3]);
         }
+        if (xtab && c == 0 && t == 1 && wave == 1) {   // every member's XCD id is in place (stored and drained in front of its first flag)
+            const int mine = xcc_id_plus1();
+            int v = mine;
+            if (lane_q < P) v = flag_load(xtab + lane_q);
+            const bool same = __all(v == mine);
+            if (lane_q == 0) lflag[2] = same ? 1 : 0;
+        }
         __syncthreads();
         PL_ST(3);   // cell update, staging, barrier
         ready = lflag[0] != 0;
+        if (xtab && c == 0 && t == 1) fast = uni(lflag[2]) != 0;
+        int* const wflag = rflags + ((size_t)g * T + t) * a.flag_stride + p;
         if (wave < 2) {
             const int row = tq >> 2, qt = tq & 3;
             const int rb = 32 * g + row;
             const uint4 hvv = *reinterpret_cast<const uint4*>(hst + row * HRS + qt * 16);
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
-            st16_sc1(ro, rb < Bp ? (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2) : kOob, hvv);
+            if (hx) {   // the private tile-major copy, plain: what the set itself reads once it has found itself on one XCD
+                u32x4 d;
+                d[0] = hvv.x; d[1] = hvv.y; d[2] = hvv.z; d[3] = hvv.w;
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(hx + (size_t)(t & 1) * hx_slot + (size_t)g * hx_grp + (size_t)p * 2048, 2048u);
+                __builtin_amdgcn_raw_buffer_store_b128(d, rx, (unsigned)(row * 64 + qt * 16), 0, 0);
+            }
+            if (!fast) {
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                st16_sc1(ro, rb < Bp ? (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2) : kOob, hvv);
+            }
         }
+        if (xtab && c == 0 && t == 0 && tq == 0) flag_store(xtab + p, xcc_id_plus1());   // with the first hand-off: drained before its flag
         PL_ST(4);   // hand-off store issue
-        raise_flag<0>(rflags + ((size_t)g * T + t) * a.flag_stride + p);   // only the hand-off is in flight: the stash stores follow the flag
+        if (!fast) {
+            raise_flag<0>(wflag);   // only the hand-off is in flight: the stash stores follow the flag
+            if (fdelta != 0 && wave == 0 && lane_q == 0) flag_store_plain(wflag + fdelta, 1);   // the plain set holds every step: the set may switch to it
+        } else {
+            // drained here: this step's private slice and everything older -- the write-through h and stash stores of the chain-step before
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave == 0 && lane_q == 0) {
+                flag_store_plain(wflag + fdelta, 1);
+                if (wt_g >= 0) flag_store(rflags + ((size_t)wt_g * T + wt_t) * a.flag_stride + p, 1);
+            }
+            wt_g = g; wt_t = t;
+            if (wave < 2) {   // the write-through copy for the roles that read this layer's h (mel head, projection of the layer above)
+                const int row = tq >> 2, qt = tq & 3;
+                const int rb = 32 * g + row;
+                const uint4 hvv = *reinterpret_cast<const uint4*>(hst + row * HRS + qt * 16);
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(Hs + (size_t)t * slabH, (unsigned)(slabH * 2));
+                st16_sc1(ro, rb < Bp ? (unsigned)((rb * Hp + 32 * p + 8 * qt) * 2) : kOob, hvv);
+            }
+        }
         PL_ST(5);   // drain + barrier + flag
         stash_stores(g, t, tq);
         PL_ST(6);   // stash store issue (behind the flag: they drain under the next wait)
@@ -393,6 +496,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
         c = cn;
         t = tn;
     }
+    if (wt_g >= 0) raise_flag<0>(rflags + ((size_t)wt_g * T + wt_t) * a.flag_stride + p);   // the last chain-step's write-through flag
     PL_ST_DUMP(a.stamps);
 }
 
@@ -591,10 +695,11 @@ constexpr int fused_fwd2_lds_bytes() {
 template <int KS>
 __device__ __forceinline__ void fused_fwd2_role(const FusedArgs& a, const FusedRole& R, int set, int p, unsigned char* lds) {
     switch (R.type) {
-        case FR_LSTM_FWD:
-            if (R.ksx == 2) fused_lstm_fwd2<KS, 2>(a, R, set, p, lds);
-            else if (R.ksx == 4) fused_lstm_fwd2<KS, 4>(a, R, set, p, lds);
-            else fused_lstm_fwd2<KS, 0>(a, R, set, p, lds);
+        case FR_LSTM_FWD:   // (the role tables give the CP-fed layer rows nobody in the launch writes, every other layer rows of a role)
+            if (R.ksx == 2 && !R.src_sc1) fused_lstm_fwd2<KS, 2, false>(a, R, set, p, lds);
+            else if (R.ksx == 2) fused_lstm_fwd2<KS, 2, true>(a, R, set, p, lds);
+            else if (R.ksx == 4) fused_lstm_fwd2<KS, 4, true>(a, R, set, p, lds);
+            else fused_lstm_fwd2<KS, 0, true>(a, R, set, p, lds);
             break;
         case FR_PROJ_FWD: fused_gemm_fwd2<KS, false>(a, R, set, p, lds); break;
         case FR_HEAD_FWD: fused_gemm_fwd2<KS, true>(a, R, set, p, lds); break;
@@ -651,9 +756,9 @@ __global__ __launch_bounds__(256, 2) void lstm_fwd2_sweep_kernel(LstmSweepArgs s
     R.G = s.G; R.W = s.W; R.h = s.h; R.c = s.c;
     R.ksx = s.x_in ? s.in_p / 16 : 0; R.x_in = s.x_in; R.Wih = s.Wih; R.bias = s.bias;
     for (int g = set; g < a.n_groups; g += sets) {
-        if (R.ksx == 2) fused_lstm_fwd2<KS, 2>(a, R, g, p, lds);
-        else if (R.ksx == 4) fused_lstm_fwd2<KS, 4>(a, R, g, p, lds);
-        else fused_lstm_fwd2<KS, 0>(a, R, g, p, lds);
+        if (R.ksx == 2) fused_lstm_fwd2<KS, 2, false>(a, R, g, p, lds);
+        else if (R.ksx == 4) fused_lstm_fwd2<KS, 4, false>(a, R, g, p, lds);
+        else fused_lstm_fwd2<KS, 0, false>(a, R, g, p, lds);
         __syncthreads();   // nobody starts the next group's LDS images while a wave still reads this one's
         if (uni(__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;   // a wait gave up: everybody leaves
     }

@@ -254,6 +254,7 @@ struct pl_handle {
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
+    bool fused2_xcd = true;           // PAULE_HIP_FUSED2_XCD: the two-per-CU forward roles' own exchange through the XCD's L2 from a private tile-major copy (round 5)
     bool fused_xcd = true;            // PAULE_HIP_FUSED_XCD: the 32-row fused backward roles' own exchange through the shared L2 when a set sits on one XCD
     int fused_gpp = 0;                // forward launch in passes: groups per pass (0: every group has its own set, one pass)
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
@@ -1520,6 +1521,12 @@ int plan_fused(pl_handle* h) {
         std::vector<short> tab = fused_block_table(fwd_slots, sets, &grid);
         if (grid > 0 && grid <= fwd_slots) {
             h->fused_fwd2 = occ2;
+            if (occ2 && h->fused2_xcd) {   // private tile-major copies of the recurrence roles' hand-off: [2 slots][groups][P][32 rows][64 B]
+                for (int l = 0; l < p.L; ++l)
+                    if ((rc = raw_alloc(h, &h->fused_hx[fr_pred(l)], (size_t)2 * ng * Pp * 2048))) return rc;
+                for (int l = 0; l < e.L; ++l)
+                    if ((rc = raw_alloc(h, &h->fused_hx[fr_emb(p.L, l)], (size_t)2 * ng * Pe * 2048))) return rc;
+            }
             if ((rc = dev_alloc(h, &h->fused_tab_fwd, (size_t)fwd_slots * 4))) return rc;
             PL_HIP(hipMemcpyAsync(h->fused_tab_fwd, tab.data(), sizeof(short) * (size_t)grid * 4, hipMemcpyHostToDevice, h->stream));
             PL_HIP(hipStreamSynchronize(h->stream));   // tab is a local
@@ -1627,6 +1634,15 @@ void fused32_xcd_fields(pl_handle* h, FusedRole& R, int* slice) {
     R.fast_flags = slice + (size_t)((h->Bp + 31) / 32) * h->T * h->flag_stride;
 }
 
+// two-per-CU forward recurrence roles (lstm_fused2.hip, round 5): XCD-id table (one row of 64 per set), the plain flag set of the own exchange
+// (second quarter of the slice, as for the 32-row backward roles) and the private tile-major copy of the hand-off
+void fused2_fwd_xcd_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
+    if (h->fused_rows16 || !h->fused_fwd2 || !h->fused2_xcd || !hx) return;
+    R.xtab = slice + (size_t)((h->Bp + 7) / 8) * h->T * h->flag_stride;
+    R.fast_flags = slice + (size_t)((h->Bp + 31) / 32) * h->T * h->flag_stride;
+    R.hx = hx;
+}
+
 void fused16_fields(pl_handle* h, FusedRole& R, int* slice, void* hx) {
     if (!h->fused_rows16) return;
     if (!h->xcd_fast || !h->xcd_fast16) return;   // PAULE_HIP_XCD_FAST=0 / PAULE_HIP_XCD_FAST16=0: the write-through exchange everywhere (A/B, counter passes)
@@ -1654,6 +1670,7 @@ int build_fused_roles(pl_handle* h) {
             R.wait[0] = FusedWait{fl[fr_pred(l)], T, Pp, 0, 0, -1};
             R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c;
             fused16_fields(h, R, fl[fr_pred(l)], h->fused_hx[fr_pred(l)]);
+            fused2_fwd_xcd_fields(h, R, fl[fr_pred(l)], h->fused_hx[fr_pred(l)]);
             if (l == 0) {
                 R.ksx = ly.in_p / 16; R.x_in = h->X0; R.Wih = ly.Wih; R.bias = ly.bias;
             } else {
@@ -1680,6 +1697,7 @@ int build_fused_roles(pl_handle* h) {
             R.src_sc1 = 1;
             R.G = ly.G; R.W = ly.Whh; R.h = ly.h; R.c = ly.c; R.x_in = h->mel_tm; R.Wih = ly.Wih; R.bias = ly.bias;
             fused16_fields(h, R, fl[fr_emb(pL, 0)], h->fused_hx[fr_emb(pL, 0)]);
+            fused2_fwd_xcd_fields(h, R, fl[fr_emb(pL, 0)], h->fused_hx[fr_emb(pL, 0)]);
         }
         for (int l = 1; l < e.L; ++l) {
             LstmLayer& ly = e.layers[l];
@@ -1695,6 +1713,7 @@ int build_fused_roles(pl_handle* h) {
             Rl.src_sc1 = 1;
             Rl.G = ly.G; Rl.W = ly.Whh; Rl.h = ly.h; Rl.c = ly.c;
             fused16_fields(h, Rl, fl[rl], h->fused_hx[rl]);
+            fused2_fwd_xcd_fields(h, Rl, fl[rl], h->fused_hx[rl]);
         }
         if ((rc = dev_alloc(h, &h->fused_roles_fwd, (size_t)n_roles))) return rc;
         PL_HIP(hipMemcpyAsync(h->fused_roles_fwd, roles.data(), sizeof(FusedRole) * n_roles, hipMemcpyHostToDevice, h->stream));
@@ -2220,6 +2239,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_XCD")) h->fused_xcd = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_FUSED2_XCD")) h->fused2_xcd = std::atoi(z) != 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_OCC2")) h->fused_occ2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_SWEEP2")) h->sweep2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
