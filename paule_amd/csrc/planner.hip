@@ -254,7 +254,9 @@ struct pl_handle {
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
-    bool fused2_xcd = true;           // PAULE_HIP_FUSED2_XCD: the two-per-CU forward roles' own exchange through the XCD's L2 from a private tile-major copy (round 5)
+    bool fused2_xcd = false;          // PAULE_HIP_FUSED2_XCD=1: the two-per-CU forward roles' own exchange through the XCD's L2 from a private tile-major copy (round 5:
+                                      // bit-identical; the predictor's chain-step 5.3 -> 5.1 us, the embedder's roles -- the launch's longest -- unchanged, the iteration
+                                      // 4.35 -> 4.39 ms: opt-in, profiles/r05_ab_fused2_forward.txt)
     bool fused_xcd = true;            // PAULE_HIP_FUSED_XCD: the 32-row fused backward roles' own exchange through the shared L2 when a set sits on one XCD
     int fused_gpp = 0;                // forward launch in passes: groups per pass (0: every group has its own set, one pass)
     short* fused_tab_fwd = nullptr;   // [n_cu][4] block -> (role, set, slice)
