@@ -732,6 +732,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd2_kernel(FusedArgs a) {
         __syncthreads();
         if (uni(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
     }
+#ifdef PL_STAMPS
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(role + 1) | ((unsigned long long)set << 8) | ((unsigned long long)p << 16);   // who this block was (tools/fused2_stamps.py)
+#endif
 }
 
 // ---- the recurrence role alone as a per-layer forward sweep (batches of more groups than one pass of lstm_fwd_sweep_kernel holds) ------

@@ -19,15 +19,21 @@ eng.set_targets(wl.target_mel, wl.target_semvec)
 eng.set_cp(wl.cp0)
 eng.step(3)
 eng.synchronize()
-raw = np.fromfile(os.environ["PL_STAMP_FILE"] + ".sweep", dtype=np.uint64).reshape(2, 256, 8).astype(np.float64) * 0.01
-labels = ["wait flags", "operands", "MFMA", "cell+staging", "h store issue", "drain+flag", "stash+landing", "-"]
-blk = raw[0]
+raw = np.fromfile(os.environ["PL_STAMP_FILE"] + ".sweep", dtype=np.uint64).reshape(512, 8)   # the forward launch's blocks 0 .. 511 (its stamps run into the backward half: no backward launch here)
+tag = raw[:, 7].astype(np.int64)
+blk = raw[:, :7].astype(np.float64) * 0.01
+labels = ["wait flags", "operands", "MFMA", "cell+staging", "h store issue", "drain+flag", "stash+landing"]
+role, rset = (tag & 255) - 1, (tag >> 8) & 255
 tot = blk.sum(axis=1)
-used = np.flatnonzero(tot > 0)
-print(f"{used.size} stamped workgroups among blocks 0..255; total per workgroup min {tot[used].min():.0f} / median {np.median(tot[used]):.0f} / max {tot[used].max():.0f} us")
-key = np.round(blk[used] / tot[used, None], 1)
-_, inv = np.unique(key, axis=0, return_inverse=True)
-for k in np.unique(inv):
-    sel = used[inv == k]
+names = {0: "predictor recurrence", 1: "mel head", 2: "embedder layer 1", 3: "projection for layer 2", 4: "embedder layer 2"}
+for r in sorted(set(role[role >= 0].tolist())):
+    sel = np.flatnonzero((role == r) & (tot > 0))
+    if sel.size == 0:
+        print(f"role {r} ({names.get(r, '?')}): {int((role == r).sum())} workgroups, no stamps (product role)")
+        continue
     med = np.median(blk[sel], axis=0)
-    print(f"  {sel.size:3d} workgroups (blocks {sel[:6].tolist()}...): " + "  ".join(f"{lab} {v:.0f}" for lab, v in zip(labels, med) if lab != "-") + f"  | sum {med.sum():.0f} us")
+    print(f"role {r} ({names.get(r, '?')}): {sel.size} workgroups, total min {tot[sel].min():.0f} / median {np.median(tot[sel]):.0f} / max {tot[sel].max():.0f} us: " +
+          "  ".join(f"{lab} {v:.0f}" for lab, v in zip(labels, med)))
+    for s_ in sorted(set(rset[sel].tolist())):
+        ss = sel[rset[sel] == s_]
+        print(f"     set {s_}: {ss.size} workgroups, total median {np.median(tot[ss]):.0f} us, wait flags {np.median(blk[ss, 0]):.0f}, operands {np.median(blk[ss, 1]):.0f}, MFMA {np.median(blk[ss, 2]):.0f}")
