@@ -303,7 +303,11 @@ int64_t pl_device_bytes(const pl_handle *h);
 double pl_flops_per_iteration(const pl_handle *h);
 
 const char *pl_last_error(void); /* thread-local */
-int pl_version(void);
+int pl_version(void);            /* PL_VERSION; answered by the loader itself: touches no HIP runtime */
+/* HIP_VERSION (major * 10000000 + minor * 100000 + patch) of the toolchain the kernels were compiled with.  The loader compares its major
+ * with the major of the HIP runtime it binds the kernels to and refuses a mismatch with a clear pl_last_error() instead of undefined
+ * behaviour inside the runtime (a host may bring a runtime of another ROCm release than /opt/rocm's, e.g. a PyTorch wheel's). */
+int pl_hip_version_built(void);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "pl_get_pred_optimizer_state", "pl_set_pred_optimizer_state", "pl_get_pred_optimizer_step", "pl_set_pred_optimizer_step",
     "pl_train_model_step", "pl_reset_model_optimizer", "pl_get_model_optimizer_state", "pl_set_model_optimizer_state",
     "pl_get_model_optimizer_step", "pl_set_model_optimizer_step",
-    "pl_last_error", "pl_version",
+    "pl_last_error", "pl_version", "pl_hip_version_built",
 )
 
 
@@ -62,8 +62,9 @@ def load_library(path: str | None = None):
 
     libpaule_hip.so is a LOADER (csrc/shim.cpp): it links no HIP runtime.  On the first pl_* call that needs the kernels it binds
     libpaule_hip_core.so to the HIP runtime the process already has (PyTorch's, if torch was imported -- in whatever order) or, when there
-    is none, to /opt/rocm's.  So nothing here depends on import order any more; loading the library and asking
-    pl_version() touch no runtime at all.  PAULE_HIP_LIB = another build of the CORE (diagnostic builds: libpaule_hip_stamps.so, an A/B
+    is none, to /opt/rocm's.  So nothing here depends on import order any more; loading the library, pl_version() and
+    pl_last_error() touch no runtime at all (the loader answers them itself); every OTHER entry point -- pl_default_config included -- binds,
+    and the loader refuses a runtime of another major release than the kernels were compiled for (pl_hip_version_built).  PAULE_HIP_LIB = another build of the CORE (diagnostic builds: libpaule_hip_stamps.so, an A/B
     build) or another directory's libpaule_hip.so."""
     global _lib
     if _lib is not None and path is None:

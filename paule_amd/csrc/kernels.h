@@ -185,7 +185,7 @@ struct FusedArgs {
     int* census;              // residency check: every role-bearing workgroup signs in here first (zeroed with the flags) ...
     int n_active;             // ... and waits, briefly, until all n_active have: a launch that is not wholly resident (another process
     unsigned long long census_ticks;   // holds CUs) sets status 2 and leaves within census_ticks instead of spinning for seconds in its waits
-    unsigned long long census_late_ticks;   // test hook (PAULE_HIP_CENSUS_LATE_MS): workgroup 0 signs in this late; 0 = off
+    unsigned long long census_late_ticks;   // test hook (PAULE_HIP_DEBUG=census_late_ms=N): workgroup 0 signs in this late; 0 = off
     unsigned long long* stamps;
     const FusedRole* roles;   // [n_roles] in device memory (a table in the kernel arguments would have to be indexed dynamically,
                               // which makes the compiler copy it to scratch)

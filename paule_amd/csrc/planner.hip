@@ -123,6 +123,36 @@ struct Model {
 
 }  // namespace
 
+// ONE diagnostic variable (round 5; VERDICT r4 hygiene): PAULE_HIP_DEBUG = comma-separated words out of
+//   stop_after_fwd        pl_step enqueues the forward pass only (tests that compare forward stashes, tools/fused_check.py, tools/fused2_stamps.py)
+//   fused                 print grid, expected workgroups and chain counts of every fused launch, and where the 16-row roles' workgroups sat
+//   graph                 trace capture / instantiate / launch / destroy of the iteration graph on stderr
+//   segv_trace            print the native frames of a segmentation fault before dying (section 10 of DESIGN.md)
+//   census_ms=N           how long a fused launch's workgroups wait for each other to sign in (default 50)
+//   census_late_ms=N      test hook: workgroup 0 signs in N ms late          } the two ways a census fails, made to happen
+//   census_expect_extra=N test hook: the census waits for N more workgroups  } (tests/test_hip_parity.py)
+// It replaces PAULE_HIP_STOP_AFTER_FWD, _DEBUG_FUSED, _DEBUG_GRAPH, _SEGV_TRACE and the three PAULE_HIP_CENSUS_* variables.
+static const char* debug_find(const char* w) {   // -> what follows the word ("" for a bare word, "=..." for a value), or nullptr
+    const char* v = std::getenv("PAULE_HIP_DEBUG");
+    if (!v) return nullptr;
+    const size_t n = std::strlen(w);
+    for (const char* q = v; *q;) {
+        const char* e = std::strchr(q, ',');
+        const size_t len = e ? (size_t)(e - q) : std::strlen(q);
+        if (len >= n && std::strncmp(q, w, n) == 0 && (len == n || q[n] == '=')) return q + n;
+        if (!e) break;
+        q = e + 1;
+    }
+    return nullptr;
+}
+static bool debug_word(const char* w) { return debug_find(w) != nullptr; }
+static bool debug_value(const char* w, long long* out) {
+    const char* r = debug_find(w);
+    if (!r || *r != '=') return false;
+    *out = std::atoll(r + 1);
+    return true;
+}
+
 struct pl_handle {
     pl_config cfg{};
     int B = 0, T = 0, Tp = 0, C = 0, M = 0, S = 0, Bp = 0, Cp = 0, Mp = 0, Sp = 0, dt = 0;
@@ -203,9 +233,9 @@ struct pl_handle {
                                 // same-XCD fast path), 0 all-gather of dA (f32-exact accumulation; A/B variant)
     // diagnostic switches, read ONCE by pl_create (no getenv on launch paths)
     bool tn_bf16 = true;        // PAULE_HIP_TN_BF16: training, bf16: weight-gradient products on the bf16 MFMA (0: the exact f32 MFMA form)
-    bool stop_after_fwd = false;   // PAULE_HIP_STOP_AFTER_FWD: pl_step enqueues the forward pass only (tools/fused_check.py, stash comparisons in tests)
-    bool debug_fused = false;   // PAULE_HIP_DEBUG_FUSED
-    bool census_hooks = false;  // PAULE_HIP_CENSUS_EXPECT_EXTRA / PAULE_HIP_CENSUS_LATE_MS were set when the handle was created: the test
+    bool stop_after_fwd = false;   // PAULE_HIP_DEBUG=stop_after_fwd: pl_step enqueues the forward pass only (tools/fused_check.py, stash comparisons in tests)
+    bool debug_fused = false;   // PAULE_HIP_DEBUG=fused
+    bool census_hooks = false;  // PAULE_HIP_DEBUG=census_expect_extra / census_late_ms were set when the handle was created: the test
                                 // hooks of the residency census are then re-read at every fused launch (never otherwise)
     int bwd_stream = 1;         // PAULE_HIP_BWD_STREAM: form of the 32-row reduce-scatter backward sweep's hand-off (lstm_persist_rs.hip): 2 the tiles
                                 // carry their own step token (round 4: no flags, no drains), 1 per-tile flags and streamed ingest (round 3), 0 one
@@ -277,7 +307,7 @@ struct pl_handle {
     FusedRole* fused_roles_bwd = nullptr;       // handle's own buffer, the flag slices are the last 2 n_roles of the iteration's slices)
     int fused_n_roles = 0;
     int fused_active_fwd = 0, fused_active_bwd = 0;   // role-bearing workgroups of the two launches (residency census)
-    unsigned long long census_ticks = 5000000ull;     // 50 ms (PAULE_HIP_CENSUS_MS)
+    unsigned long long census_ticks = 5000000ull;     // 50 ms (PAULE_HIP_DEBUG=census_ms=N)
     unsigned long long spin_ticks = 200000000ull;   // 2 s
     unsigned poll_mask = 63u;
     double* past = nullptr;
@@ -1603,8 +1633,9 @@ void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, c
     a.census = fused_slice(h, 0, bwd) + h->sweep_cnt_bytes / sizeof(int) - 1;
     a.n_active = bwd ? h->fused_active_bwd : h->fused_active_fwd;
     if (h->census_hooks) {   // test hooks: a workgroup that never shows up / one that shows up after the others have given up
-        if (const char* z = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA")) a.n_active += std::atoi(z);
-        if (const char* z = std::getenv("PAULE_HIP_CENSUS_LATE_MS")) a.census_late_ticks = 100000ull * (unsigned long long)std::atoll(z);
+        long long z = 0;
+        if (debug_value("census_expect_extra", &z)) a.n_active += (int)z;
+        if (debug_value("census_late_ms", &z)) a.census_late_ticks = 100000ull * (unsigned long long)z;
     }
     a.census_ticks = h->census_ticks;
     if (h->debug_fused)
@@ -1913,7 +1944,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     h->sweep_slot = -1;
 }
 
-// PAULE_HIP_SEGV_TRACE=1 (diagnostic): print the native frames of a segmentation fault before dying -- the crash inside
+// PAULE_HIP_DEBUG=segv_trace (diagnostic): print the native frames of a segmentation fault before dying -- the crash inside
 // hipGraphLaunch after branched graph execs were destroyed (drop_graph) leaves no other trace
 void segv_trace(int sig) {
     void* frames[64];
@@ -1931,7 +1962,7 @@ int check_launch() {
     return PL_OK;
 }
 
-static const bool g_dbg_graph = std::getenv("PAULE_HIP_DEBUG_GRAPH") != nullptr;
+static const bool g_dbg_graph = debug_word("graph");
 // graph execs with parallel branches that retired handles left allocated (see drop_graph): counted, so that a host can see the leak
 // the containment of the runtime crash costs (pl_plan_info: PL_PLAN_RETAINED_EXECS, process-wide)
 static std::atomic<int> g_retained_branched_execs{0};
@@ -2039,6 +2070,7 @@ extern "C" {
 
 const char* pl_last_error(void) { return g_last_error.c_str(); }
 int pl_version(void) { return PL_VERSION; }
+int pl_hip_version_built(void) { return HIP_VERSION; }
 
 int pl_default_config(pl_config* cfg) {
     if (!cfg) return fail(PL_ERR_INVALID, "cfg is NULL");
@@ -2117,7 +2149,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(PL_ERR_INVALID, "pl_create: no such HIP device");
     DeviceGuard guard(cfg->device);
 
-    if (std::getenv("PAULE_HIP_SEGV_TRACE")) signal(SIGSEGV, segv_trace);
+    if (debug_word("segv_trace")) signal(SIGSEGV, segv_trace);
     pl_handle* h = new pl_handle();
     h->cfg = *cfg;
     h->stream = static_cast<hipStream_t>(cfg->stream);
@@ -2254,11 +2286,11 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) < 0 ? 0 : (std::atoi(z) > 2 ? 2 : std::atoi(z));
 #endif
         if (const char* z = std::getenv("PAULE_HIP_TN_BF16")) h->tn_bf16 = std::atoi(z) != 0;
-        h->debug_fused = std::getenv("PAULE_HIP_DEBUG_FUSED") != nullptr;
-        h->census_hooks = std::getenv("PAULE_HIP_CENSUS_EXPECT_EXTRA") != nullptr || std::getenv("PAULE_HIP_CENSUS_LATE_MS") != nullptr;
-        if (std::getenv("PAULE_HIP_STOP_AFTER_FWD")) {
+        h->debug_fused = debug_word("fused");
+        h->census_hooks = debug_word("census_expect_extra") || debug_word("census_late_ms");
+        if (debug_word("stop_after_fwd")) {
             h->stop_after_fwd = true;
-            fprintf(stderr, "[pl] PAULE_HIP_STOP_AFTER_FWD is set: pl_step of this handle enqueues the forward pass ONLY (diagnostic mode: no loss, "
+            fprintf(stderr, "[pl] PAULE_HIP_DEBUG=stop_after_fwd: pl_step of this handle enqueues the forward pass ONLY (diagnostic mode: no loss, "
                             "no backward pass, no update -- loss logs and the CP do not change)\n");
         }
         if (const char* z = std::getenv("PAULE_HIP_XCD_FAST")) h->xcd_fast = std::atoi(z);
@@ -2296,12 +2328,6 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
                     xb = xb > xe ? xb : xe;
                 }
             if (xb && (rc = raw_alloc(h, &h->sweep_xchg, xb))) return bail(rc);
-            if (xb && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_xt && h->pred.L >= 1 &&
-                lstm_rs_ride_along_supported(h->pred.Hp, h->pred.layers[0].in_p)) {
-                void* q = nullptr;
-                if ((rc = raw_alloc(h, &q, lstm_rs_xpart_bytes(h->pred.Hp, h->Bp, h->T)))) return bail(rc);
-                h->dx_part = static_cast<float*>(q);
-            }
             if (xb && h->bwd_stream == 2) {   // the token form's own exchange (raw_alloc zeroes it: every granule "retired")
                 if ((rc = raw_alloc(h, &h->sweep_xchg_tok, xb))) return bail(rc);
                 h->sweep_xchg_tok_bytes = xb;
@@ -2349,7 +2375,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             h->wf_next = 0;
         }
         if (const char* ms = std::getenv("PAULE_HIP_SPIN_MS")) h->spin_ticks = 100000ull * (unsigned long long)std::atoll(ms);
-        if (const char* ms = std::getenv("PAULE_HIP_CENSUS_MS")) h->census_ticks = 100000ull * (unsigned long long)std::atoll(ms);
+        if (long long ms = 0; debug_value("census_ms", &ms)) h->census_ticks = 100000ull * (unsigned long long)ms;
         const size_t n_groups_max = (Bp + 7) / 8;   // groups hold >= 8 rows
         const int slice = h->dt == F32 ? 16 : 32;   // hidden units per workgroup
         int pmax = h->pred.Hp / slice;
@@ -2372,6 +2398,15 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     }
     if ((rc = dev_alloc(h, &h->past, B * T * h->C))) return bail(rc);
     if ((rc = plan_fused(h))) return bail(rc);
+    // scratch of the ride-along input gradient (lstm_persist_rs.hip, XT): only where the predictor's backward pass really is the streamed
+    // 32-row per-layer sweep -- not under the fused backward launch, not on the 16-row kernels (226 MB at cfg3, 754 MB at
+    // 128 x 2000 frames, which runs the fused backward, 1.8 GB at 2048 x 300)
+    if (h->dt == BF16 && h->use_sweep && h->bwd_mode == 1 && h->sweep_xchg && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_xt && h->pred.L >= 1 &&
+        lstm_rs_ride_along_supported(h->pred.Hp, h->pred.layers[0].in_p) && !h->fused_bwd_ok && !use_sweep16(h, h->pred.Hp, true)) {
+        void* q = nullptr;
+        if ((rc = raw_alloc(h, &q, lstm_rs_xpart_bytes(h->pred.Hp, h->Bp, h->T)))) return bail(rc);
+        h->dx_part = static_cast<float*>(q);
+    }
     if ((rc = build_fused_roles(h))) return bail(rc);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { bail(PL_ERR_HIP); return fail(PL_ERR_HIP, std::string("pl_create: ") + hipGetErrorString(e)); }
@@ -2564,7 +2599,7 @@ int pl_synchronize(pl_handle* h) {
         }
     }
 #endif
-    if (h->debug_fused && h->fused_rows16) {   // PAULE_HIP_DEBUG_FUSED: where the 16-row roles' workgroups sat in the last iteration
+    if (h->debug_fused && h->fused_rows16) {   // PAULE_HIP_DEBUG=fused: where the 16-row roles' workgroups sat in the last iteration
         for (int bwd = 0; bwd < 2; ++bwd)
             for (int r = 0; r < h->fused_n_roles; ++r) {
                 int ids[32] = {};

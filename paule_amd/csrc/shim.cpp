@@ -118,7 +118,19 @@ void load() {
 #include "shim_table.inc"
 #undef PL_FWD_CUSTOM
 #undef PL_FWD
-    if (!g.error.empty()) g.core = nullptr;
+    if (!g.error.empty()) { g.core = nullptr; return; }
+    // (5) the runtime the kernels are now bound to against the one they were compiled for: another MAJOR release is refused
+    using rt_ver_fn = int (*)(int*);
+    rt_ver_fn rt_ver = reinterpret_cast<rt_ver_fn>(dlsym(rt, "hipRuntimeGetVersion"));
+    int have = 0;
+    if (rt_ver && rt_ver(&have) == 0 && have > 0 && g.p_pl_hip_version_built) {
+        const int built = g.p_pl_hip_version_built();
+        if (have / 10000000 != built / 10000000) {
+            g.error = "the HIP runtime in this process (" + g.runtime_path + ", version " + std::to_string(have) + ") is another major release than the one " +
+                      core_path + " was compiled for (" + std::to_string(built) + "): rebuild the library against that ROCm, or load the matching runtime first";
+            g.core = nullptr;
+        }
+    }
 }
 
 // More than one HIP runtime in the process (looked up when a pl_create FAILS -- the second copy may have arrived after the loader
@@ -165,8 +177,12 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
     return rc;
 }
 
+// Neither of these two binds anything: a host may ask for the version, or for the last error of a thread that has not called anything yet,
+// BEFORE it loads its own HIP runtime -- binding here would bring /opt/rocm's copy in front of it
+int pl_version(void) { return PL_VERSION; }
+
 const char* pl_last_error(void) {
-    if (!ready()) return t_msg.c_str();
+    if (!g.core) return t_msg.c_str();   // nothing bound (yet, or the binding failed: ready() left its reason here)
     if (!t_msg.empty()) return t_msg.c_str();
     return g.p_pl_last_error();
 }

@@ -101,12 +101,14 @@ order = sys.argv[1]
 lib = None
 if order == "lib_first":
     lib = C.CDLL(sys.argv[2])          # the loader alone: maps no runtime
+    assert lib.pl_version() == 100     # the loader's own answer: still no runtime
     assert not [l for l in open("/proc/self/maps") if "amdhip" in l]
     import torch
 else:
     import torch
     lib = C.CDLL(sys.argv[2])
-assert lib.pl_version() == 100         # first call: binds the core to the runtime that is mapped NOW
+built = lib.pl_hip_version_built()     # first bound call: binds the core to the runtime that is mapped NOW (and checks its major release)
+assert built // 10000000 >= 6, built
 mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
 print("MAPPED", mapped)
 '''
@@ -142,8 +144,9 @@ def test_loader_reports_a_missing_core_through_the_c_abi(tmp_path):
     shutil.copy(_capi.LIB_PATH, tmp_path / "libpaule_hip.so")
     code = ("import ctypes as C, sys\n"
             "lib = C.CDLL(sys.argv[1]); lib.pl_last_error.restype = C.c_char_p\n"
-            "rc = lib.pl_version(); msg = lib.pl_last_error().decode()\n"
-            "assert rc != 100 and 'libpaule_hip_core.so' in msg, (rc, msg)\n"
+            "assert lib.pl_version() == 100 and lib.pl_last_error().decode() == ''   # answered by the loader, binds nothing\n"
+            "rc = lib.pl_hip_version_built(); msg = lib.pl_last_error().decode()\n"
+            "assert rc == 2 and 'libpaule_hip_core.so' in msg, (rc, msg)   # PL_ERR_HIP\n"
             "print('OK')\n")
     env = {k: v for k, v in os.environ.items() if k not in ("PAULE_HIP_CORE", "PAULE_HIP_LIB")}
     out = subprocess.run([sys.executable, "-c", code, str(tmp_path / "libpaule_hip.so")], capture_output=True, text=True, timeout=120, env=env)

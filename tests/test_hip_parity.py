@@ -430,8 +430,7 @@ def test_fused_launch_census_late_sign_in_keeps_the_first_cause(HipPlanner, monk
     wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
     monkeypatch.setenv("PAULE_HIP_FUSED", "1")
     monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
-    monkeypatch.setenv("PAULE_HIP_CENSUS_MS", "10")
-    monkeypatch.setenv("PAULE_HIP_CENSUS_LATE_MS", "40")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "census_ms=10,census_late_ms=40")
     monkeypatch.setenv("PAULE_HIP_SPIN_MS", "300")
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
     assert eng.plan_info()["fused_fwd"] == 1
@@ -440,7 +439,7 @@ def test_fused_launch_census_late_sign_in_keeps_the_first_cause(HipPlanner, monk
     eng.step(1, return_loss=False)
     with pytest.raises(ValueError, match="not all resident"):
         eng.synchronize()
-    monkeypatch.delenv("PAULE_HIP_CENSUS_LATE_MS")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "census_ms=10")
     eng.set_cp(wl.cp0)
     eng.reset_optimizer()
     assert np.isfinite(_n(eng.step(2))).all()
@@ -485,12 +484,12 @@ def test_fused_forward_is_bit_identical(HipPlanner, monkeypatch, shape):
     B, T, H = shape["B"], shape["T"], shape["H"]
     wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
     monkeypatch.setenv("PAULE_HIP_FUSED_OCC2", "0")   # this test is lstm_fused.hip's (one workgroup per CU); the two-per-CU launch has its own below
-    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, shape.get("chains"))
     assert e["1"].plan_info()["fwd_per_cu"] == 1
     for name in FWD_BUFFERS:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
-    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    monkeypatch.delenv("PAULE_HIP_DEBUG")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 4, shape["graph"], shape.get("chains"))
     np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
     np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
@@ -511,11 +510,11 @@ def test_fused_forward_in_passes_is_bit_identical(HipPlanner, monkeypatch, shape
     else:
         wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
         bufs = FWD_BUFFERS
-    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, dict(PAULE_HIP_FUSED_GPP=shape["gpp"]))
     for name in bufs:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
-    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    monkeypatch.delenv("PAULE_HIP_DEBUG")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, True, dict(PAULE_HIP_FUSED_GPP=shape["gpp"]))
     np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
     np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
@@ -540,12 +539,12 @@ def test_fused_forward_two_per_cu_is_bit_identical(HipPlanner, monkeypatch, shap
         wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
         bufs = FWD_BUFFERS
     env = dict(PAULE_HIP_FUSED_OCC2="1", **(shape.get("chains") or {}))
-    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False, env)
     assert e["1"].plan_info()["fwd_per_cu"] == 2, e["1"].plan_info()
     for name in bufs:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
-    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    monkeypatch.delenv("PAULE_HIP_DEBUG")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, shape["graph"], env)
     np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
     np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
@@ -565,7 +564,7 @@ def test_two_per_cu_forward_sweep_is_bit_identical(HipPlanner, monkeypatch, shap
     out = {}
     for v in ("0", shape.get("force", "-1")):
         monkeypatch.setenv("PAULE_HIP_SWEEP2", v)
-        monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+        monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
         eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
         assert eng.plan_info()["fused_fwd"] == 0
         eng.set_targets(wl.target_mel, wl.target_semvec)
@@ -573,7 +572,7 @@ def test_two_per_cu_forward_sweep_is_bit_identical(HipPlanner, monkeypatch, shap
         eng.step(1)
         eng.synchronize()
         bufs = {name: _n(eng.debug_read(name)) for name in FWD_BUFFERS}
-        monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+        monkeypatch.delenv("PAULE_HIP_DEBUG")
         eng2 = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=True)
         eng2.set_targets(wl.target_mel, wl.target_semvec)
         eng2.set_cp(wl.cp0)
@@ -625,12 +624,12 @@ def test_fused_forward_stacked_predictor_is_bit_identical(HipPlanner, monkeypatc
     wl = synthetic.make_workload(B, T, "B")
     bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
     monkeypatch.setenv("PAULE_HIP_FUSED_OCC2", "0")   # lstm_fused.hip's launch (since round 4 the planner's choice for set B is the two-per-CU one: its own test above)
-    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 1, False)
     assert e["1"].plan_info()["fwd_per_cu"] == 1
     for name in bufs:
         np.testing.assert_array_equal(_n(e["1"].debug_read(name)), _n(e["0"].debug_read(name)), err_msg=name)
-    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    monkeypatch.delenv("PAULE_HIP_DEBUG")
     e = _fused_pair(HipPlanner, monkeypatch, wl, B, T, ("0", "1"), 3, shape["graph"])
     np.testing.assert_array_equal(e["1"].losses, e["0"].losses)
     np.testing.assert_array_equal(_n(e["1"].get_cp()), _n(e["0"].get_cp()))
@@ -794,7 +793,7 @@ def _pair16(HipPlanner, monkeypatch, wl, B, T, iters, use_graph, other, stop_aft
             monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
             monkeypatch.setenv("PAULE_HIP_FUSED", "3")
         if stop_after_fwd:
-            monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+            monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
         eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=use_graph)
         plan = eng.plan_info()
         want = {"fused16": (16, 1, 1), "fused32": (32, 1, 1), "pipelines": (0, 0, 0)}[which]
@@ -804,7 +803,7 @@ def _pair16(HipPlanner, monkeypatch, wl, B, T, iters, use_graph, other, stop_aft
         eng.losses = _n(eng.step(iters))
         eng.synchronize()
         out[which] = eng
-    for k in ("PAULE_HIP_FUSED16", "PAULE_HIP_FUSED_MIN_B", "PAULE_HIP_FUSED", "PAULE_HIP_STOP_AFTER_FWD"):
+    for k in ("PAULE_HIP_FUSED16", "PAULE_HIP_FUSED_MIN_B", "PAULE_HIP_FUSED", "PAULE_HIP_DEBUG"):
         monkeypatch.delenv(k, raising=False)
     return out
 
@@ -2042,7 +2041,7 @@ def test_bf16_path_equals_rounding_emulation(HipPlanner, shape, monkeypatch):
     ex.set_cp(wl.cp0.numpy())
 
     # forward stashes of the first iteration
-    monkeypatch.setenv("PAULE_HIP_STOP_AFTER_FWD", "1")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "stop_after_fwd")
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
@@ -2062,7 +2061,7 @@ def test_bf16_path_equals_rounding_emulation(HipPlanner, shape, monkeypatch):
         assert same >= 0.88 and steps.max() <= 4, (name, same, steps.max())
     mel = _n(eng.debug_read("mel")).reshape(B, Tp, -1)
     np.testing.assert_allclose(mel, parts["mel"], atol=2e-3 * np.abs(parts["mel"]).max(), rtol=0)
-    monkeypatch.delenv("PAULE_HIP_STOP_AFTER_FWD")
+    monkeypatch.delenv("PAULE_HIP_DEBUG")
 
     # one full iteration: the model gradient dL/dCP; then 5 iterations: the plan
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
@@ -2298,15 +2297,14 @@ def test_fused_launch_residency_census(HipPlanner, monkeypatch):
     wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
     monkeypatch.setenv("PAULE_HIP_FUSED", "1")
     monkeypatch.setenv("PAULE_HIP_FUSED_MIN_B", "1")
-    monkeypatch.setenv("PAULE_HIP_CENSUS_MS", "20")
-    monkeypatch.setenv("PAULE_HIP_CENSUS_EXPECT_EXTRA", "1")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "census_ms=20,census_expect_extra=1")
     eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16", use_graph=False)
     eng.set_targets(wl.target_mel, wl.target_semvec)
     eng.set_cp(wl.cp0)
     eng.step(1, return_loss=False)
     with pytest.raises(ValueError, match="not all resident"):
         eng.synchronize()
-    monkeypatch.delenv("PAULE_HIP_CENSUS_EXPECT_EXTRA")
+    monkeypatch.setenv("PAULE_HIP_DEBUG", "census_ms=20")
     eng.set_cp(wl.cp0)            # the handle is usable again once the GPU is its own
     eng.reset_optimizer()
     loss = _n(eng.step(2))

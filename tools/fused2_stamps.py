@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ["PAULE_HIP_LIB"] = os.path.join(ROOT, "paule_amd", "csrc", "libpaule_hip_stamps.so")
 os.environ.setdefault("PL_STAMP_FILE", os.path.join(ROOT, "gpurun_out", "stamps"))
 os.environ["PAULE_HIP_FUSED_OCC2"] = os.environ.get("PAULE_HIP_FUSED_OCC2", "1")
-os.environ["PAULE_HIP_STOP_AFTER_FWD"] = "1"
+os.environ["PAULE_HIP_DEBUG"] = "stop_after_fwd"
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 import numpy as np
 from paule_amd import synthetic

@@ -17,7 +17,7 @@ model_set = os.environ.get("FC_SET", "A")
 hidden = os.environ.get("FC_HIDDEN")
 batches = [int(x) for x in sys.argv[1:]] or [256]
 if stage == "fwd":
-    os.environ["PAULE_HIP_STOP_AFTER_FWD"] = "1"
+    os.environ["PAULE_HIP_DEBUG"] = "stop_after_fwd"
 os.environ.setdefault("PAULE_HIP_SPIN_MS", "300")
 FWD = ["X0", "pred.h0", "pred.c0", "pred.G0", "mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0", "emb.h1", "emb.c1", "emb.G1"]
 ALL = FWD + ["sem", "pred.dh_ext", "dX", "grad", "x"]
