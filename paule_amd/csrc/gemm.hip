@@ -92,13 +92,16 @@ static void launch_typed(hipStream_t stream, const void* A, int lda, const void*
                          int ldc, int M, int N, int K) {
     auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     constexpr long kEnough = 64;
+    // one block column (N <= 64): the product streams A once and is bound by how many CUs pull on HBM, so the large tile needs most of the
+    // chip's worth of workgroups (round 5: cfg2's dL/dCP product ran 256 x 32 tiles on 75 CUs at 1.6 TB/s)
+    constexpr long kEnoughNarrow = 192;
     if (N <= 32) {
-        if (blocks(256, 32) >= kEnough || M <= 64)
+        if (blocks(256, 32) >= kEnoughNarrow || M <= 64)
             launch_cfg<AT, OT, 256, 32, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
         else
             launch_cfg<AT, OT, 64, 32, 16, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
     } else if (N <= 64) {
-        if (blocks(128, 64) >= kEnough || M <= 32)
+        if (blocks(128, 64) >= kEnoughNarrow || M <= 32)
             launch_cfg<AT, OT, 128, 64, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);   // 2 x 2 waves of 64 x 32
         else
             launch_cfg<AT, OT, 32, 64, 16, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);

@@ -2,7 +2,7 @@
 """Interleaved A/B timing of engine variants in ONE process on ONE device (MI355X guide, methodology rule 24).
 usage: ab_bench.py VAR=a,b[,c] [rounds] [iters]      e.g.  ab_bench.py PAULE_HIP_XCD_FAST=0,1 8 10
        ab_bench.py "A=0,B=2/A=1,B=3" [rounds] [iters]  variants separated by "/", each a list of assignments
-env: AB_BATCH (256), AB_FRAMES (300), AB_DTYPE (bf16), AB_GRAPH (1), AB_SET (A)"""
+env: AB_BATCH (256), AB_FRAMES (300), AB_DTYPE (bf16), AB_GRAPH (1), AB_SET (A), AB_OBJECTIVE (acoustic_semvec)"""
 import os
 import sys
 import time
@@ -23,7 +23,7 @@ else:
     variants = [{var: v} for v in vals]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-cfg = dict(batch=int(os.environ.get("AB_BATCH", 256)), frames=int(os.environ.get("AB_FRAMES", 300)), objective="acoustic_semvec", dtype=os.environ.get("AB_DTYPE", "bf16"))
+cfg = dict(batch=int(os.environ.get("AB_BATCH", 256)), frames=int(os.environ.get("AB_FRAMES", 300)), objective=os.environ.get("AB_OBJECTIVE", "acoustic_semvec"), dtype=os.environ.get("AB_DTYPE", "bf16"))
 wl = synthetic.make_workload(cfg["batch"], cfg["frames"], os.environ.get("AB_SET", "A"))
 engines = []
 for v in variants:
