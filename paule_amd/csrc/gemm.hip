@@ -3,6 +3,8 @@
 // Used for: LSTM input projections for all time steps (W_ih x_t + b), post_linear / linear_mapping,
 // and the backward-data products dA * W_ih, dY * W_p, dsem * W_m (weights pre-transposed at upload,
 // so every product is "NT").  M = T * Bp rows of a time-major activation slab.
+#include <atomic>
+
 #include "kernels.h"
 #include "tile_gemm.h"
 
@@ -115,9 +117,18 @@ static void launch_typed(hipStream_t stream, const void* A, int lda, const void*
     }
 }
 
+// gemm_big.hip's 256 x 256 tiles for the large bf16 products: on by default; a handle created with PAULE_HIP_GEMM_BIG=0 switches them off for
+// what it enqueues (enqueue_iteration sets this before it launches anything; the results are bit-identical either way)
+static std::atomic<bool> g_gemm_big{true};
+void gemm_set_big(bool on) { g_gemm_big.store(on, std::memory_order_relaxed); }
+
 void launch_gemm_nt(hipStream_t stream, int dt, bool out_f32, const void* A, int lda, const void* W, int ldw,
                     const float* bias, void* C, int ldc, int M, int N, int K) {
     if (M <= 0 || N <= 0) return;
+    if (dt == BF16 && g_gemm_big.load(std::memory_order_relaxed) && gemm_big_takes(M, N, K)) {
+        launch_gemm_nt_big(stream, out_f32, A, lda, W, ldw, bias, C, ldc, M, N, K);
+        return;
+    }
     if (dt == BF16) {
         if (out_f32)
             launch_typed<bf16_t, float>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);

@@ -12,6 +12,12 @@ inline size_t dtype_size(int dt) { return dt == BF16 ? 2 : 4; }
 // ---- gemm.hip -------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]);  A, W of activation type `dt`; C float if out_f32 else `dt`.
 // lda/ldw/ldc in elements; K % 32 == 0; rows 16-byte aligned.
+// gemm_big.hip: the large bf16 products on 256 x 256 tiles (bit-identical to gemm.hip's tiles); launch_gemm_nt hands them over by itself
+bool gemm_big_takes(int M, int N, int K);
+void gemm_big_init();   // once per process, outside any stream capture (function attribute: 128 KB of LDS)
+void gemm_set_big(bool on);
+void launch_gemm_nt_big(hipStream_t stream, bool out_f32, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                        int M, int N, int K);
 void launch_gemm_nt(hipStream_t stream, int dt, bool out_f32, const void* A, int lda, const void* W, int ldw,
                     const float* bias, void* C, int ldc, int M, int N, int K);
 

@@ -235,6 +235,7 @@ struct pl_handle {
     bool tn_bf16 = true;        // PAULE_HIP_TN_BF16: training, bf16: weight-gradient products on the bf16 MFMA (0: the exact f32 MFMA form)
     bool stop_after_fwd = false;   // PAULE_HIP_DEBUG=stop_after_fwd: pl_step enqueues the forward pass only (tools/fused_check.py, stash comparisons in tests)
     bool debug_fused = false;   // PAULE_HIP_DEBUG=fused
+    bool gemm_big = true;       // PAULE_HIP_GEMM_BIG: the large bf16 products on gemm_big.hip's 256 x 256 tiles (0: gemm.hip's tiles; same bits)
     bool census_hooks = false;  // PAULE_HIP_DEBUG=census_expect_extra / census_late_ms were set when the handle was created: the test
                                 // hooks of the residency census are then re-read at every fused launch (never otherwise)
     int bwd_stream = 1;         // PAULE_HIP_BWD_STREAM: form of the 32-row reduce-scatter backward sweep's hand-off (lstm_persist_rs.hip): 2 the tiles
@@ -1896,6 +1897,7 @@ AdamArgs adam_args(pl_handle* h) {
 
 // one inner iteration: forward, criterion, backward-data, Adam + projection
 void enqueue_iteration(pl_handle* h, hipStream_t st) {
+    gemm_set_big(h->gemm_big);
     const bool with_sem = h->need_emb_in_step();
     h->wf_next = 0;
     h->wf_stream_next = 0;
@@ -2287,6 +2289,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
 #endif
         if (const char* z = std::getenv("PAULE_HIP_TN_BF16")) h->tn_bf16 = std::atoi(z) != 0;
         h->debug_fused = debug_word("fused");
+        if (const char* z = std::getenv("PAULE_HIP_GEMM_BIG")) h->gemm_big = std::atoi(z) != 0;
+        gemm_big_init();
         h->census_hooks = debug_word("census_expect_extra") || debug_word("census_late_ms");
         if (debug_word("stop_after_fwd")) {
             h->stop_after_fwd = true;

@@ -386,6 +386,29 @@ def test_backward_sweep_forms_are_bit_identical(HipPlanner, monkeypatch, shape):
             np.testing.assert_array_equal(out[form][k], out["w4"][k], err_msg=f"{form}: {k}")
 
 
+@pytest.mark.parametrize("shape", [dict(B=256, T=300, fused="1"), dict(B=270, T=120, fused="0")])
+def test_big_gemm_matches_tile_gemm_bit_for_bit(HipPlanner, monkeypatch, shape):
+    """Round 5: the large bf16 products run on gemm_big.hip's 256 x 256 tiles (eight waves, LDS-DMA double buffer).  Same MFMA, same k order,
+    same epilogue arithmetic as gemm.hip's tiles: with PAULE_HIP_GEMM_BIG=0 (every product on gemm.hip) the iteration produces the same
+    bits -- stashes, dL/dCP, losses, final CP.  Shapes: cfg3 (the dL/dh product of embedder layer 1: K = 2944, a partial last N tile);
+    the per-layer path at 270 rows (ragged last M tile; the input projections' K = 736 ends on a HALF stage)."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "A")
+    monkeypatch.setenv("PAULE_HIP_FUSED", shape["fused"])
+    out = {}
+    for big in ("0", "1"):
+        monkeypatch.setenv("PAULE_HIP_GEMM_BIG", big)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        loss = _n(eng.step(3))
+        eng.synchronize()
+        out[big] = dict(loss=loss, cp=_n(eng.get_cp()), dX=_n(eng.debug_read("dX")), G0=_n(eng.debug_read("emb.G0")), G1=_n(eng.debug_read("emb.G1")))
+        eng.close()
+    for k in out["0"]:
+        np.testing.assert_array_equal(out["1"][k], out["0"][k], err_msg=k)
+
+
 @pytest.mark.parametrize("shape", [dict(B=256, T=300), dict(B=144, T=61), dict(B=270, T=17), dict(B=16, T=40)])
 def test_ride_along_input_gradient_equals_the_batched_product(HipPlanner, monkeypatch, shape):
     """Round 4: in the predictor's streamed backward sweep the workgroup's partial dL/dCP = dA_t[its 128 gate rows] W_ih rides along as
