@@ -96,7 +96,9 @@ static void launch_typed(hipStream_t stream, const void* A, int lda, const void*
     constexpr long kEnough = 64;
     // one block column (N <= 64): the product streams A once and is bound by how many CUs pull on HBM, so the large tile needs most of the
     // chip's worth of workgroups (round 5: cfg2's dL/dCP product ran 256 x 32 tiles on 75 CUs at 1.6 TB/s)
-    constexpr long kEnoughNarrow = 192;
+    // ... and more: with one workgroup per CU at a time, 300 large tiles are two rounds, the second on 44 CUs (cfg3's dL/dmel product: 65 us for
+    // 226 MB); from three rounds on the tail no longer matters
+    constexpr long kEnoughNarrow = 768;
     if (N <= 32) {
         if (blocks(256, 32) >= kEnoughNarrow || M <= 64)
             launch_cfg<AT, OT, 256, 32, 64, 32>(stream, A, lda, W, ldw, bias, C, ldc, M, N, K);

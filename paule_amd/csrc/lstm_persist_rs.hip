@@ -1262,9 +1262,17 @@ __global__ __launch_bounds__(256) void dx_reduce_kernel(const float* __restrict_
     const int rg = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4* src = reinterpret_cast<const float4*>(xpart + (size_t)tg * P * 1024) + rg * 64 + lane;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < P; ++p) {
-        const float4 v = src[(size_t)p * 256];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (P == 23) {   // the ride-along's shape: all 23 loads in flight, summed in the same order
+        float4 v[23];
+#pragma unroll
+        for (int p = 0; p < 23; ++p) v[p] = src[(size_t)p * 256];
+#pragma unroll
+        for (int p = 0; p < 23; ++p) { s.x += v[p].x; s.y += v[p].y; s.z += v[p].z; s.w += v[p].w; }
+    } else {
+        for (int p = 0; p < P; ++p) {
+            const float4 v = src[(size_t)p * 256];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
     const int b = 32 * g + (lane & 31), n = 8 * rg + 4 * (lane >> 5);
     if (b < Bp) *reinterpret_cast<float4*>(dX + ((size_t)t * Bp + b) * 32 + n) = s;
