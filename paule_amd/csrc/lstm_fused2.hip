@@ -29,6 +29,12 @@
 #ifndef FUSED2_PF
 #define FUSED2_PF 3           // B fragments read ahead of the MFMA that consumes them (recurrence roles)
 #endif
+#ifndef FUSED2_XCD
+#define FUSED2_XCD 0          // 1: the recurrence roles' own exchange through the XCD's L2 is compiled in (PAULE_HIP_FUSED2_XCD=1 then switches it on)
+#endif
+#ifndef FUSED2_X_LATE_MIN_KS
+#define FUSED2_X_LATE_MIN_KS 16   // narrower recurrences stage their input rows in front of the chain: their tile is six pieces, the half-way stop only costs
+#endif
 #ifndef FUSED2_SPLIT_TILE
 #define FUSED2_SPLIT_TILE 1   // 1: the h tile's landing is waited for in two halves around the MFMA chain (measured: DESIGN.md 4.0d)
 #endif
@@ -187,7 +193,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
     // (nt LDS-DMA), polls the plain flags (nt), and moves the write-through h store and flag, which only OTHER roles read, out of its own way:
     // behind the plain flag, the write-through flag one chain-step late (a wave's stores complete in order: the next drain covers them).
     // Placement is never assumed, the bits do not change.
-    unsigned char* const hx = static_cast<unsigned char*>(R.hx);
+    unsigned char* const hx = FUSED2_XCD ? static_cast<unsigned char*>(R.hx) : nullptr;   // (compiled out by default: see FUSED2_XCD)
     int* const xtab = (hx && R.xtab) ? R.xtab + set * 64 : nullptr;
     const long fdelta = (xtab && R.fast_flags) ? (long)(R.fast_flags - R.flags) : 0;
     const size_t hx_grp = (size_t)P * 2048, hx_slot = (size_t)a.n_groups * hx_grp;
@@ -313,7 +319,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
                 }
             }
         };
-        const bool x_late = t > 0 && src_sc1 && FUSED2_SPLIT_TILE;   // staged at the half-way point of the MFMA chain
+        const bool x_late = t > 0 && src_sc1 && FUSED2_SPLIT_TILE && KS >= FUSED2_X_LATE_MIN_KS;   // staged at the half-way point of the MFMA chain
         // Everything the compiler itself has in flight is waited for HERE, in front of the tile's pieces (on every path: a wait the compiler
         // still owes on ONE path comes out as s_waitcnt vmcnt(0) behind the merge): it does not count the pieces (inline asm), so its wait for
         // any load it issued earlier came out as s_waitcnt vmcnt(0) somewhere between the first-half wait and the first MFMA -- which waited
