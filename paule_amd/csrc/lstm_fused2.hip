@@ -64,6 +64,29 @@ __device__ __forceinline__ int img_swz(int row) {
 // rows 32 g .. 32 g + 31 of a row-major [Bp][Hp] bf16 slab -> image, by LDS-DMA (write-through reads).  Wave w fills the half tiles
 // (kb = 2 j + (w >> 1), rows 16 (w & 1) ...): P tiles x 2 halves, 12 or 11 pieces a wave at Hp = 736.  Rows beyond the batch read row
 // Bp - 1 (their results are never stored: every store's offset goes through the range check).
+// N pieces of one wave in ONE asm statement: piece j reads 128 bytes further along the rows (the instruction's immediate offset, which moves
+// the global AND the LDS address) and lands 4096 bytes further in the image (M0 moves by 4096 - 128 between pieces).  Piece by piece through
+// glds16_sc1, each piece paid a 64-bit address (two v_readlane of the spilled slab pointer, s_add_u32, s_addc_u32), its LDS address and a
+// save / restore of M0: ten scalar instructions beside a DMA whose own issue costs about as much (round 5).
+#define PL_GLDS_FIRST "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\t"
+#define PL_GLDS_NEXT(OFF) "s_add_u32 m0, m0, 3968\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:" #OFF " sc1\n\t"
+#define PL_GLDS_LAST "s_mov_b32 m0, %0"
+#define PL_GLDS_ARGS : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory", "scc"
+template <int N>
+__device__ __forceinline__ void dma_pieces_sc1(const unsigned char* src, unsigned voff, unsigned dst) {
+    unsigned keep;
+    static_assert(N == 1 || N == 2 || N == 3 || N == 11 || N == 12, "piece counts of P = 3, 6, 23");
+    if constexpr (N == 1) asm volatile(PL_GLDS_FIRST PL_GLDS_LAST PL_GLDS_ARGS);
+    if constexpr (N == 2) asm volatile(PL_GLDS_FIRST PL_GLDS_NEXT(128) PL_GLDS_LAST PL_GLDS_ARGS);
+    if constexpr (N == 3) asm volatile(PL_GLDS_FIRST PL_GLDS_NEXT(128) PL_GLDS_NEXT(256) PL_GLDS_LAST PL_GLDS_ARGS);
+    if constexpr (N == 11)
+        asm volatile(PL_GLDS_FIRST PL_GLDS_NEXT(128) PL_GLDS_NEXT(256) PL_GLDS_NEXT(384) PL_GLDS_NEXT(512) PL_GLDS_NEXT(640) PL_GLDS_NEXT(768) PL_GLDS_NEXT(896)
+                     PL_GLDS_NEXT(1024) PL_GLDS_NEXT(1152) PL_GLDS_NEXT(1280) PL_GLDS_LAST PL_GLDS_ARGS);
+    if constexpr (N == 12)
+        asm volatile(PL_GLDS_FIRST PL_GLDS_NEXT(128) PL_GLDS_NEXT(256) PL_GLDS_NEXT(384) PL_GLDS_NEXT(512) PL_GLDS_NEXT(640) PL_GLDS_NEXT(768) PL_GLDS_NEXT(896)
+                     PL_GLDS_NEXT(1024) PL_GLDS_NEXT(1152) PL_GLDS_NEXT(1280) PL_GLDS_NEXT(1408) PL_GLDS_LAST PL_GLDS_ARGS);
+}
+
 template <int P, int ROWB, bool GEMM>
 __device__ __forceinline__ void dma_image(const void* slab, int g, int Bp, unsigned img_lds, int wave, int lane) {
     const int half = wave & 1, hi = wave >> 1;
@@ -71,11 +94,10 @@ __device__ __forceinline__ void dma_image(const void* slab, int g, int Bp, unsig
     int rb = 32 * g + row;
     rb = rb < Bp ? rb : Bp - 1;
     const unsigned voff = (unsigned)(rb * ROWB + (((lane & 3) ^ img_swz<GEMM>(row)) * 16));
-    const unsigned char* src = static_cast<const unsigned char*>(slab) + hi * 64;
-    const unsigned dst = img_lds + (unsigned)(hi * 2048 + half * 1024);
-#pragma unroll
-    for (int j = 0; j < (P + 1) / 2; ++j)
-        if (2 * j + hi < P) glds16_sc1(uni(src + j * 128), voff, (unsigned)uni((int)(dst + (unsigned)(j * 4096))));
+    const unsigned char* src = uni(static_cast<const unsigned char*>(slab) + hi * 64);
+    const unsigned dst = (unsigned)uni((int)(img_lds + (unsigned)(hi * 2048 + half * 1024)));
+    if (hi == 0) dma_pieces_sc1<(P + 1) / 2>(src, voff, dst);   // tiles kb = 2 j + hi < P
+    else dma_pieces_sc1<P / 2>(src, voff, dst);
 }
 
 // The same image from the role's PRIVATE copy of the hand-off (round 5): tile-major [slice kb][32 rows][64 B] -- a slice is 2 KB contiguous,
@@ -795,6 +817,7 @@ void launch_lstm_fwd2_sweep(hipStream_t stream, int Hp, int sets, const LstmSwee
 
 #define PL_FUSED_FWD2_PAIRS(X) X(6, 6) X(46, 46) X(12, 46)
 
+bool fused_fwd2_xcd_compiled() { return FUSED2_XCD != 0; }
 bool fused_fwd2_supported(int Hp_pred, int Hp_emb) {
 #define PL_CASE(KP, KE) if (Hp_pred == 16 * KP && Hp_emb == 16 * KE) return true;
     PL_FUSED_FWD2_PAIRS(PL_CASE)

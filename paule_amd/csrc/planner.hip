@@ -2275,7 +2275,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_WAVES")) h->bwd_waves = std::atoi(z) == 4 ? 4 : 8;
         if (const char* z = std::getenv("PAULE_HIP_BWD_STREAM")) h->bwd_stream = std::atoi(z) != 0 ? 1 : 0;
         if (const char* z = std::getenv("PAULE_HIP_FUSED_XCD")) h->fused_xcd = std::atoi(z) != 0;
-        if (const char* z = std::getenv("PAULE_HIP_FUSED2_XCD")) h->fused2_xcd = std::atoi(z) != 0;
+        if (const char* z = std::getenv("PAULE_HIP_FUSED2_XCD")) h->fused2_xcd = std::atoi(z) != 0 && fused_fwd2_xcd_compiled();
         if (const char* z = std::getenv("PAULE_HIP_FUSED_OCC2")) h->fused_occ2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_SWEEP2")) h->sweep2 = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
