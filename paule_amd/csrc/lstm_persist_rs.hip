@@ -284,6 +284,9 @@ __device__ __forceinline__ void rs_prefetch_role(const LstmSweepArgs& a, const i
     });
 }
 
+#ifndef RS_DA_LATE
+#define RS_DA_LATE 0
+#endif
 template <int KS, int DMAV, int XT = 0>   // DMAV bit 0: stash rows by LDS-DMA a step ahead; bit 1: dA_t stored by waves 4 .. 7 from the image
 __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArgs a) {
     constexpr bool DMA = (DMAV & 1) != 0, DAW = (DMAV & 2) != 0;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
                 for (int u = 0; u < 4; ++u) cell_bwd(dh[u], dc_next[u], gi[u], gf[u], gg[u], go[u], c[u], cp[u], dai[u], daf[u], dag[u], dao[u], dc_next[u]);
                 const uint2 pi = pack_bf16x4(dai[0], dai[1], dai[2], dai[3]), pf = pack_bf16x4(daf[0], daf[1], daf[2], daf[3]);
                 const uint2 pg = pack_bf16x4(dag[0], dag[1], dag[2], dag[3]), po = pack_bf16x4(dao[0], dao[1], dao[2], dao[3]);
-                if (ok && (!DAW || t == 0) && !(XT && a.skip_dA)) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                if (ok && (!DAW || t == 0) && !(XT && a.skip_dA) && (!RS_DA_LATE || t == 0)) {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
                     bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
                     *reinterpret_cast<uint2*>(go_) = pi;
                     *reinterpret_cast<uint2*>(go_ + Hp) = pf;
@@ -583,6 +586,14 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
                 }
             }
             if (XT && t == 0) break;
+            if (RS_DA_LATE && !DAW && cellw && ok && !(XT && a.skip_dA)) {   // experiment: the cell waves' dA stores BEHIND their tiles and flags, read back from the image
+                const unsigned char* drow = dimg + erow * DRS + jq * 8;
+                bf16_t* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                *reinterpret_cast<uint2*>(go_) = *reinterpret_cast<const uint2*>(drow);
+                *reinterpret_cast<uint2*>(go_ + Hp) = *reinterpret_cast<const uint2*>(drow + 64);
+                *reinterpret_cast<uint2*>(go_ + 2 * Hp) = *reinterpret_cast<const uint2*>(drow + 128);
+                *reinterpret_cast<uint2*>(go_ + 3 * Hp) = *reinterpret_cast<const uint2*>(drow + 192);
+            }
             if (DAW && !cellw) {   // dA_t -> the gate stash, from the image (double-buffered: intact until step t - 2), as 16-byte pieces (gate ch >> 2,
                 // units 8 (ch & 3) .. + 7) -- BEHIND the tiles: in front of them the acknowledge of these stores (HBM, ~1 us) sat in the way of every
                 // tile flag's counted wait (tile phase 1.23 -> 2.20 us, profiles/r04_ab_bwd_dma.txt)
