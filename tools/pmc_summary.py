@@ -34,11 +34,15 @@ def instantiation(recorded, kname):
     """The template arguments of a recorded kernel name as text ("<46, 0, 1>", "" for none): launches of different instantiations of one
     kernel are different kernels (the predictor's backward sweep with its ride-along tile, the embedder layers' without) and are
     reported separately (no more "upper third by value" of a mixed population)."""
-    if recorded.startswith("_Z"):
-        m = re.search(r"%d%sI((?:L[a-z]\d+E)+)E" % (len(kname), re.escape(kname)), recorded)
-        return "<" + ", ".join(re.findall(r"L[a-z](\d+)E", m.group(1))) + ">" if m else ""
+    if recorded.startswith("_Z"):   # rocprofv3 leaves some names mangled: builtin types (f, d, DF16b = __bf16) and integer literals (Li46E)
+        m = re.search(r"%d%sI((?:DF16b|f|d|L[a-z]\d+E)+)E" % (len(kname), re.escape(kname)), recorded)
+        if not m:
+            return ""
+        names = {"DF16b": "bf16", "f": "float", "d": "double"}
+        toks = re.findall(r"DF16b|f|d|L[a-z]\d+E", m.group(1))
+        return "<" + ", ".join(names.get(t) or re.sub(r"L[a-z](\d+)E", r"\1", t) for t in toks) + ">"
     m = re.search(r"(?<![A-Za-z0-9_])%s(<[^>]*>)" % re.escape(kname), recorded)
-    return m.group(1) if m else ""
+    return m.group(1).replace("bool _Accum", "bf16") if m else ""   # (the profiler's demangler prints __bf16 as "bool _Accum")
 
 
 def main():
@@ -55,7 +59,8 @@ def main():
                        ("lstm_bwd_rs_sweep_kernel", "lstm_bwd_rs_sweep_kernel"), ("lstm_bwd_sweep_kernel", "lstm_bwd_sweep_kernel"),
                        ("lstm_fwd_sweep_kernel", "lstm_fwd_sweep_kernel"),
                        ("lstm_bwd_step_kernel", "lstm_bwd_step_kernel"), ("lstm_fwd_step_kernel", "lstm_fwd_step_kernel"),
-                       ("gemm_nt_kernel", "gemm_nt_kernel")):
+                       ("lstm_fwd_chain_f32_kernel", "lstm_fwd_chain_f32_kernel"), ("lstm_bwd_chain_f32_kernel", "lstm_bwd_chain_f32_kernel"),
+                       ("gemm_nt_big_kernel", "gemm_nt_big_kernel"), ("dx_reduce_kernel", "dx_reduce_kernel"), ("gemm_nt_kernel", "gemm_nt_kernel")):
         insts = sorted({instantiation(k, kname) for k in list(fetch) + list(write) if is_kernel(k, kname)})
         if not insts:
             continue
