@@ -205,6 +205,7 @@ void launch_fused_fwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedAr
 void launch_fused_bwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 // the forward launch at TWO workgroups per CU (lstm_fused2.hip, round 4): the same role table, planned for 2 x n_cu workgroup slots
 bool fused_fwd2_supported(int Hp_pred, int Hp_emb);
+bool fused_passes_compiled();    // lstm_fused.hip was built with -DFUSED_PASSES=1 (the forward launch in passes, PAULE_HIP_FUSED_GPP)
 bool fused_fwd2_xcd_compiled();   // lstm_fused2.hip was built with -DFUSED2_XCD=1 (the recurrence roles' own exchange through the XCD's L2)
 void launch_fused_fwd2(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedArgs& a);
 // the two-per-CU recurrence role alone as a per-layer forward sweep (32-row groups, whole sequence; more groups than one pass of the

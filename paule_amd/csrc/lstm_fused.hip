@@ -36,6 +36,12 @@
 #define FUSED_POLL_EARLY -1   // wave 0's EARLY look after FUSED_POLL_EARLY / 8 of the MFMA chain: if it finds the flags up, the late look's answer is not waited for (-1: off, the default: measured slower)
 #endif
 
+#ifndef FUSED_PASSES
+#define FUSED_PASSES 0   // 1: fused_fwd_kernel's pass loop is compiled in (PAULE_HIP_FUSED_GPP then switches it on).  Off by default (round 5): the launch in passes
+                         // was measured slower than the per-layer sweeps where it applies (NOTEBOOK.md A.10), and the role descriptor held live across the pass
+                         // loop costs every role of every launch scalar registers (B = 128 x 300: 3.47 -> 3.44 ms, 128 x 2000: 22.29 -> 22.17 without it)
+#endif
+
 namespace pl {
 
 namespace {
@@ -1259,7 +1265,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
     // every role function starts from scratch (weights, cell state at t = 0), flags and stashes are indexed by the absolute group, so a
     // pass is exactly the launch a batch of those groups alone would run (tests: test_full_size_cfg4_one_gpu..., bit-equal rows).  Roles
     // drift apart by passes as they please: a wait is per (group, step) and every role walks the passes in the same order.
-    const int set_step = a.gpp > 0 ? uni(a.gpp / R.C) : 0;
+    const int set_step = (FUSED_PASSES && a.gpp > 0) ? uni(a.gpp / R.C) : 0;
     for (int s2 = set;; s2 += set_step) {
         if constexpr (KSP == KSE) {
             fused_fwd_role<KSE>(a, R, s2, p, lds);
@@ -1267,7 +1273,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedArgs a) {
             if (R.wide) fused_fwd_role<KSE>(a, R, s2, p, lds);
             else fused_fwd_role<KSP>(a, R, s2, p, lds);
         }
-        if (set_step <= 0 || (s2 + set_step) * R.C >= a.n_groups) break;
+        if (!FUSED_PASSES || set_step <= 0 || (s2 + set_step) * R.C >= a.n_groups) break;
         __syncthreads();   // nobody starts the next pass's LDS images while a wave still reads this one's
         if (uni(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;   // a wait gave up: everybody leaves
     }
@@ -1493,5 +1499,7 @@ void launch_fused_bwd(hipStream_t stream, int Hp_pred, int Hp_emb, const FusedAr
     PL_FUSED_BWD16_PAIRS(PL_CASE)
 #undef PL_CASE
 }
+
+bool fused_passes_compiled() { return FUSED_PASSES != 0; }
 
 }  // namespace pl

@@ -1476,7 +1476,7 @@ int plan_fused(pl_handle* h) {
     // GPU).  Bit-identical (test_fused_forward_in_passes_is_bit_identical), and NOT faster there: 43.9 ms per iteration in passes of 8 or
     // 16 groups against 41.4 ms on the per-layer forward sweeps, which at 64 groups already fill the chip (11 groups a pass on 253 CUs)
     // -- what the fused launch wins at 256 rows is the idle time of three half-empty sweeps (profiles/r04_ab_fused_passes.txt).  Opt-in.
-    if (const char* z = std::getenv("PAULE_HIP_FUSED_GPP")) {
+    if (const char* z = fused_passes_compiled() ? std::getenv("PAULE_HIP_FUSED_GPP") : nullptr) {
         const int gf = std::atoi(z);
         if (gf > 0 && gf < ng && !rows16 && (mode & 1)) { ngf = gf; mode &= ~2; }
     }

@@ -4,6 +4,7 @@ Tolerances (written here): f32 engine vs float64 oracle over 20 itera
   CP atol 1e-5, loss curve rtol 1e-5, forward outputs atol 2e-5;
 bf16 engine: loss curve rtol 2e-2, per-term gradient cosine >= 0.999, CP atol 2 * lr * n_iters * 1 %... stated below.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -527,6 +528,8 @@ def test_fused_forward_in_passes_is_bit_identical(HipPlanner, monkeypatch, shape
     ragged last groups, a last pass with fewer sets than roles have; the stacked two-width predictor): every forward stash, the pooled
     mel, losses and the plan equal the per-layer path's bit for bit."""
     B, T, H = shape["B"], shape["T"], shape["H"]
+    if "FUSED_PASSES=1" not in os.environ.get("PAULE_HIP_BUILD_OPTIONS", ""):
+        pytest.skip("the pass loop is a build option since round 5 (make EXTRA=-DFUSED_PASSES=1; set PAULE_HIP_BUILD_OPTIONS=FUSED_PASSES=1 to run this test)")
     if shape.get("set_b"):
         wl = synthetic.make_workload(B, T, "B")
         bufs = [f"pred.{k}{l}" for l in range(4) for k in "hcG"] + ["mel", "mel_tm", "emb.h0", "emb.c0", "emb.G0"]
