@@ -357,16 +357,17 @@ void launch_dsem(hipStream_t stream, int dt, const LossArgs& a, void* dsem, bool
 // dL/dY (pre-pool linear output): each pooled frame's gradient goes half to each of its two frames.
 template <typename AT>
 __global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __restrict__ dY, int tube, int t0, int n_t) {
-    const int64_t n = (int64_t)n_t * a.Bp * a.Mp;   // frames t0 .. t0 + n_t - 1
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one thread per POOLED frame element (tp, b, m): both frames of the pair get the same value (round 5: one thread per frame element
+    // computed everything twice -- an f64 division and three 64-bit index divisions each: 27 us for 20 MB at cfg3)
+    const int tp0 = t0 >> 1, tp1 = (t0 + n_t + 1) >> 1;   // pooled frames touched by frames t0 .. t0 + n_t - 1
+    const unsigned n = (unsigned)(tp1 - tp0) * (unsigned)a.Bp * (unsigned)a.Mp;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    idx += (int64_t)t0 * a.Bp * a.Mp;
-    const int m = (int)(idx % a.Mp);
-    const int b = (int)((idx / a.Mp) % a.Bp);
-    const int t = (int)(idx / ((int64_t)a.Mp * a.Bp));
-    const int tp = t >> 1;
+    const unsigned m = idx % (unsigned)a.Mp, r = idx / (unsigned)a.Mp;
+    const unsigned b = r % (unsigned)a.Bp;
+    const int tp = tp0 + (int)(r / (unsigned)a.Bp);
     float v = 0.f;
-    if (b < a.B && m < a.M && tp < a.Tp) {
+    if ((int)b < a.B && (int)m < a.M && tp < a.Tp) {
         double g = 0.0;
         if (tube) {
             const double rm = a.scal[(size_t)b * 8 + 6];
@@ -384,12 +385,18 @@ __global__ void dy_kernel(LossArgs a, const float* __restrict__ dmel_e, AT* __re
         }
         v = (float)(0.5 * g);
     }
-    dY[idx] = from_f32<AT>(v);
+    const AT o = from_f32<AT>(v);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = 2 * tp + h;
+        if (t >= t0 && t < t0 + n_t) dY[((size_t)t * a.Bp + b) * a.Mp + m] = o;
+    }
 }
 
 void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_e, void* dY, bool tube, int t0, int n_t) {
     if (n_t < 0) { t0 = 0; n_t = a.T; }
-    const int64_t n = (int64_t)n_t * a.Bp * a.Mp;
+    if (n_t <= 0) return;
+    const int64_t n = (int64_t)(((t0 + n_t + 1) >> 1) - (t0 >> 1)) * a.Bp * a.Mp;   // (< 2^31: 2000 frames x 2048 rows x 64 = 1.3e8)
     if (n <= 0) return;
     if (dt == BF16)
         hipLaunchKernelGGL(dy_kernel<bf16_t>, dim3(blocks_for(n)), dim3(256), 0, stream, a, dmel_e, static_cast<bf16_t*>(dY), tube ? 1 : 0, t0, n_t);
