@@ -29,6 +29,10 @@
 #ifndef FUSED2_PF
 #define FUSED2_PF 3           // B fragments read ahead of the MFMA that consumes them (recurrence roles)
 #endif
+#ifndef FUSED2_AHEAD
+#define FUSED2_AHEAD 1        // 1: a two-chain recurrence role requests the OTHER chain's h tile at the end of a chain-step (behind its hand-off store, in front of
+                              // the drain and the flag) when that chain's flags were already seen up: the tile lands under the flag, the stash stores and the loop top
+#endif
 #ifndef FUSED2_XCD
 #define FUSED2_XCD 0          // 1: the recurrence roles' own exchange through the XCD's L2 is compiled in (PAULE_HIP_FUSED2_XCD=1 then switches it on)
 #endif
@@ -137,7 +141,9 @@ struct LstmFwd2Lds {
 // fact of the instantiation, because the waits differ: rows that nobody in the launch writes are fetched in front of the flag wait and have
 // landed before the tile's pieces go out, and the compiler's s_waitcnt for a load still in flight on ONE path of a run-time choice would sit
 // on both (SC1 = true is correct for any role, only slower for rows that could have come early).
-template <int KS, int KSX, bool SC1>
+// AHEAD (with FUSED2_AHEAD): the other chain's h tile is requested at the end of a chain-step (see there).  On in the role-fused launch
+// (cfg3 4.19 -> 4.14 ms, cfg3_setB 4.14 -> 4.05), off in the per-layer sweep kernel, where it measured 0.4 % slower (2048 rows).
+template <int KS, int KSX, bool SC1, bool AHEAD>
 __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = LstmFwd2Lds<KS, KSX>;
     static_assert(KS % 2 == 0, "whole 32-unit tiles");
@@ -249,6 +255,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
     PL_ST_DECL
     int c = 0, t = 0;
     bool ready = false;   // the flags of the coming chain-step were seen up during the last one
+    bool ahead = false;   // ... and its h tile was requested at the end of the last one (FUSED2_AHEAD): the pieces are in flight, older than everything below
     for (;;) {
         // per-lane_q indices of this chain-step, opaque to the optimizer: derived from plain `tid` every address of the x loads, the staging
         // image, the stores ... is loop-invariant (one chain), gets hoisted in front of the loop and held in registers the kernel does not
@@ -376,6 +383,12 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
         // (ONE branch on t > 0 for operands and chain together: with two, the loads of the t = 0 path -- x-projection fragments, the look's
         // poll -- were still owed at the merge in front of the chain, and the compiler put its s_waitcnt vmcnt(0) in front of the first MFMA)
         if (t > 0) {
+            if (ahead) {
+                // requested a chain-step ago: the pieces are older than this chain-step's streamed fragments and write-through input rows (NWT
+                // + NSC of them at most, on every wave) -- all but those have completed means the whole tile has landed
+                constexpr int NSC = (KSX == 0 && SC1) ? 2 : 0;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWT + NSC) : "memory");
+            } else {
             if (fast) dma_image_tiles<P, false>(hx + (size_t)((t - 1) & 1) * hx_slot + (size_t)g * hx_grp, himg_lds, wave, lane_q);
             else dma_image<P, ROWB, false>(Hs + (size_t)(t - 1) * slabH, g, Bp, himg_lds, wave, lane_q);
             // the tile in two halves: the first KH k-steps' pieces (a wave's first NP1, and everything older) have landed when all but
@@ -383,6 +396,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
             if (!FUSED2_SPLIT_TILE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P + 1) / 2 - NP1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P / 2 - NP1 > 0 ? P / 2 - NP1 : 0) : "memory");
+            }
             if (!x_late) stage_x();
             __syncthreads();
             if (!x_late) read_gx();
@@ -497,8 +511,16 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
         }
         if (xtab && c == 0 && t == 0 && tq == 0) flag_store(xtab + p, xcc_id_plus1());   // with the first hand-off: drained before its flag
         PL_ST(4);   // hand-off store issue
+        // FUSED2_AHEAD: the other chain's flags were seen up during this chain-step's MFMAs (ready), and behind the barrier above nobody reads the
+        // h image any more: its next tile goes out NOW, behind this chain-step's hand-off store -- the drain in front of the flag waits for
+        // everything but the pieces (a wave's memory operations complete in order), and the tile lands under the flag, the stash stores and
+        // the next chain-step's top instead of in front of its MFMAs
+        const bool ahead_next = FUSED2_AHEAD && AHEAD && ready && has_next && tn > 0 && !fast;
+        if (ahead_next) dma_image<P, ROWB, false>(Hs + (size_t)(tn - 1) * slabH, gn, Bp, himg_lds, wave, lane_q);
+        ahead = ahead_next;
         if (!fast) {
-            raise_flag<0>(wflag);   // only the hand-off is in flight: the stash stores follow the flag
+            if (ahead_next) raise_flag<(P + 1) / 2>(wflag);   // waves 0 and 1 (the storing ones) requested (P + 1) / 2 pieces each; waves 2, 3 one fewer and stored nothing
+            else raise_flag<0>(wflag);   // only the hand-off is in flight: the stash stores follow the flag
             if (fdelta != 0 && wave == 0 && lane_q == 0) flag_store_plain(wflag + fdelta, 1);   // the plain set holds every step: the set may switch to it
         } else {
             // drained here: this step's private slice and everything older -- the write-through h and stash stores of the chain-step before
@@ -724,10 +746,10 @@ template <int KS>
 __device__ __forceinline__ void fused_fwd2_role(const FusedArgs& a, const FusedRole& R, int set, int p, unsigned char* lds) {
     switch (R.type) {
         case FR_LSTM_FWD:   // (the role tables give the CP-fed layer rows nobody in the launch writes, every other layer rows of a role)
-            if (R.ksx == 2 && !R.src_sc1) fused_lstm_fwd2<KS, 2, false>(a, R, set, p, lds);
-            else if (R.ksx == 2) fused_lstm_fwd2<KS, 2, true>(a, R, set, p, lds);
-            else if (R.ksx == 4) fused_lstm_fwd2<KS, 4, true>(a, R, set, p, lds);
-            else fused_lstm_fwd2<KS, 0, true>(a, R, set, p, lds);
+            if (R.ksx == 2 && !R.src_sc1) fused_lstm_fwd2<KS, 2, false, true>(a, R, set, p, lds);
+            else if (R.ksx == 2) fused_lstm_fwd2<KS, 2, true, true>(a, R, set, p, lds);
+            else if (R.ksx == 4) fused_lstm_fwd2<KS, 4, true, true>(a, R, set, p, lds);
+            else fused_lstm_fwd2<KS, 0, true, true>(a, R, set, p, lds);
             break;
         case FR_PROJ_FWD: fused_gemm_fwd2<KS, false>(a, R, set, p, lds); break;
         case FR_HEAD_FWD: fused_gemm_fwd2<KS, true>(a, R, set, p, lds); break;
@@ -787,9 +809,9 @@ __global__ __launch_bounds__(256, 2) void lstm_fwd2_sweep_kernel(LstmSweepArgs s
     R.G = s.G; R.W = s.W; R.h = s.h; R.c = s.c;
     R.ksx = s.x_in ? s.in_p / 16 : 0; R.x_in = s.x_in; R.Wih = s.Wih; R.bias = s.bias;
     for (int g = set; g < a.n_groups; g += sets) {
-        if (R.ksx == 2) fused_lstm_fwd2<KS, 2, false>(a, R, g, p, lds);
-        else if (R.ksx == 4) fused_lstm_fwd2<KS, 4, false>(a, R, g, p, lds);
-        else fused_lstm_fwd2<KS, 0, false>(a, R, g, p, lds);
+        if (R.ksx == 2) fused_lstm_fwd2<KS, 2, false, false>(a, R, g, p, lds);
+        else if (R.ksx == 4) fused_lstm_fwd2<KS, 4, false, false>(a, R, g, p, lds);
+        else fused_lstm_fwd2<KS, 0, false, false>(a, R, g, p, lds);
         __syncthreads();   // nobody starts the next group's LDS images while a wave still reads this one's
         if (uni(__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;   // a wait gave up: everybody leaves
     }
