@@ -33,6 +33,9 @@
 #define FUSED2_AHEAD 1        // 1: a two-chain recurrence role requests the OTHER chain's h tile at the end of a chain-step (behind its hand-off store, in front of
                               // the drain and the flag) when that chain's flags were already seen up: the tile lands under the flag, the stash stores and the loop top
 #endif
+#ifndef FUSED2_X_AT_END
+#define FUSED2_X_AT_END 1     // with a tile requested ahead: the write-through input rows are waited for behind the whole recurrent chain instead of half way through it
+#endif
 #ifndef FUSED2_XCD
 #define FUSED2_XCD 0          // 1: the recurrence roles' own exchange through the XCD's L2 is compiled in (PAULE_HIP_FUSED2_XCD=1 then switches it on)
 #endif
@@ -406,7 +409,7 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 constexpr int K0[2] = {0, KH}, K1[2] = {KH, KS};
-                if (half == 1 && K0[1] < K1[1]) {   // the second half of the tile (and, with it, input rows that a role of this launch wrote)
+                if (half == 1 && K0[1] < K1[1] && !(FUSED2_X_AT_END && ahead)) {   // the second half of the tile (and, with it, input rows that a role of this launch wrote)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (x_late) stage_x();
                     __syncthreads();
@@ -425,6 +428,12 @@ __device__ __forceinline__ void fused_lstm_fwd2(const FusedArgs& a, const FusedR
                     if (ks == PK && poll_here) pv = poll_load(pn, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (FUSED2_X_AT_END && ahead && x_late) {   // the tile was there from the start (requested a chain-step ago): no half-way stop; the write-through
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // input rows -- issued at this chain-step's top -- are staged behind the whole recurrent chain
+                stage_x();
+                __syncthreads();
+                read_gx();
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

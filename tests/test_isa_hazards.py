@@ -53,6 +53,34 @@ def test_scanner_finds_the_branch_hazard_and_accepts_the_padded_form(tmp_path):
     assert _scan_text(FIXED, tmp_path, "fixed.s") == []
 
 
+# the compiler's merged if / else tails (round 5): each arm sets a flag pair, the code behind the merge branches on it.  From the MFMA's arm the
+# branch is always taken; the fall-through block (the OTHER arm's continuation, which reuses the accumulator's registers) is not reachable
+FLAG_IDIOM = """
+_Z4flagv:
+	v_mfma_f32_32x32x16_bf16 v[2:17], v[182:185], v[202:205], v[2:17]
+	s_mov_b64 s[86:87], 0
+.LBB0_1:
+	v_lshlrev_b32_e32 v195, 4, v215
+	s_and_b64 vcc, exec, s[86:87]
+	s_cbranch_vccz .LBB0_3
+; %bb.2:
+	v_mul_lo_u32 v2, v218, s45
+.LBB0_3:
+	s_nop 7
+	s_nop 7
+	v_add_f32_e32 v20, v2, v3
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_scanner_follows_the_compilers_flag_idiom(tmp_path):
+    assert _scan_text(FLAG_IDIOM, tmp_path, "flag.s") == []
+    # without the flag's value on the path both edges are possible again: the write of v2 four wait states behind the MFMA is reported
+    bad = _scan_text(FLAG_IDIOM.replace("\ts_mov_b64 s[86:87], 0\n", "\ts_nop 0\n"), tmp_path, "noflag.s")
+    assert any("v_mul_lo_u32 v2" in f[4] for f in bad), bad
+
+
 def _makefile_sources():
     """The SRCS of paule_amd/csrc/Makefile: what the shipped library is built from -- a new kernel file is scanned without anybody listing it here."""
     mk = open(os.path.join(ROOT, "paule_amd", "csrc", "Makefile")).read()

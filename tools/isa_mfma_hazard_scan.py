@@ -94,16 +94,20 @@ def scan_function(name, lines):
             findings.append((name, k, t, None, None, "unknown MFMA opcode: add it to REQ"))
             continue
         dst = regs(ops.split(",")[0])
-        # depth-first over paths; state = (instruction index, wait states so far)
+        # depth-first over paths; state = (instruction index, wait states so far, what the path knows about vcc, SGPR pairs the path has seen
+        # set to 0 / -1).  The last two follow ONE idiom of the compiler (round 5): it merges the tails of an if / else by setting a flag pair
+        # (s_mov_b64 s[a:b], 0 | -1) in each arm and branching on `s_and_b64 vcc, exec, s[a:b]` behind the merge -- a path that has seen the
+        # s_mov takes only the edge that flag allows; without this the scan walks from the MFMAs of one arm into the other arm's code
         best = {}
-        stack = [(s, 0) for s in succ(k)]
+        stack = [(s, 0, None, ()) for s in succ(k)]
         while stack:
-            q, ws = stack.pop()
+            q, ws, vcc, pairs = stack.pop()
             if ws >= need or q >= n:
                 continue
-            if q in best and best[q] <= ws:
+            key = (q, vcc, pairs)
+            if key in best and best[key] <= ws:
                 continue
-            best[q] = ws
+            best[key] = ws
             qt, qmn, qops = ins[q]
             touched = regs(qops) & dst
             if touched:
@@ -118,8 +122,23 @@ def scan_function(name, lines):
             step = 1
             if qmn == "s_nop":
                 step = int(qops.strip(), 0) + 1
-            for s in succ(q):
-                stack.append((s, ws + step))
+            o = [x.strip() for x in qops.split(",")] if qops else []
+            nxt = succ(q)
+            if qmn in ("s_cbranch_vccz", "s_cbranch_vccnz") and vcc is not None and len(nxt) == 2:
+                taken = (vcc == 0) == (qmn == "s_cbranch_vccz")
+                nxt = [nxt[1]] if taken else [nxt[0]]
+            pd = dict(pairs)
+            if qmn == "s_mov_b64" and len(o) == 2 and o[0].startswith("s[") and o[1] in ("0", "-1"):
+                pd[o[0]] = 0 if o[1] == "0" else -1
+            elif o and o[0].startswith("s") and o[0] in pd:
+                del pd[o[0]]   # (any other write to a tracked pair; partial writes of its halves are not produced for these flags)
+            if qmn == "s_and_b64" and len(o) == 3 and o[0] == "vcc" and "exec" in o[1:] and any(x in pd for x in o[1:]):
+                vcc = 0 if pd[[x for x in o[1:] if x in pd][0]] == 0 else 1   # exec is not zero on a path that is being executed
+            elif (o and o[0] in ("vcc", "vcc_lo", "vcc_hi")) or (qmn.startswith("v_cmp") and not qmn.endswith("_e64")) or qmn.startswith("v_div_scale") or qmn in ("v_add_co_u32_e32", "v_sub_co_u32_e32", "v_addc_co_u32_e32", "v_subb_co_u32_e32", "v_subrev_co_u32_e32"):
+                vcc = None
+            npairs = tuple(sorted(pd.items()))
+            for s in nxt:
+                stack.append((s, ws + step, vcc, npairs))
     # one line per (mfma, reader) pair
     seen, out = set(), []
     for f in findings:
