@@ -5,20 +5,11 @@
 // The CP master copy, the Adam moments and all trajectory (smoothness) arithmetic are kept in f64:
 // they are a few MB, cost nothing next to the LSTM products, and remove the f32 cancellation in
 // the 1e5-weighted local-linear term (the reference is float64 end to end, paule/paule.py:124).
+#include "cp_update.h"
 #include "kernels.h"
 #include "pl_types.h"
 
 namespace pl {
-
-// correlation taps: d[t] = sum_k taps[k] * x[t + k]
-//   velocity     : five-point stencil, paule/util.py:600 (delta_t = 1, paule/paule.py:78)
-//   jerk         : the same stencil applied three times (paule/util.py:633-636) = one 13-tap correlation
-//   local linear : paule/util.py:614
-__constant__ double kVelTaps[5] = {1.0 / 12, -8.0 / 12, 0.0, 8.0 / 12, -1.0 / 12};
-__constant__ double kJerkTaps[13] = {1.0 / 1728,    -24.0 / 1728, 192.0 / 1728,  -488.0 / 1728, -387.0 / 1728,
-                                     1584.0 / 1728, 0.0,          -1584.0 / 1728, 387.0 / 1728,  488.0 / 1728,
-                                     -192.0 / 1728, 24.0 / 1728,  -1.0 / 1728};
-__constant__ double kLlTaps[3] = {-0.5, 1.0, -0.5};
 
 static inline int blocks_for(int64_t n, int bs = 256) { return (int)((n + bs - 1) / bs); }
 
@@ -407,108 +398,50 @@ void launch_dy(hipStream_t stream, int dt, const LossArgs& a, const float* dmel_
 // ---------------------------------------------------------------------------------------------
 // gradient of the smoothness terms + Adam
 // ---------------------------------------------------------------------------------------------
-// loss = w * mean(d^2), d[u] = sum_j taps[j] x[u+j], u in [0, n)  =>  dloss/dx[t] = w*2/(n*C) * sum_k taps[k] d[t-k]
-// dc: the correlations d[u] of this channel (stride C over u), computed by loss_reduce_kernel of the same iteration
-template <int K>
-__device__ __forceinline__ double corr_grad(const double* __restrict__ dc, int T, int C, const double* taps, int t,
-                                            double w) {
-    const int n = T - K + 1;
-    double g = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int u = t - k;
-        if (u >= 0 && u < n) g += taps[k] * dc[(size_t)u * C];
-    }
-    return g * (w * 2.0 / ((double)n * C));
-}
-
-// the same for TG consecutive frames t0 .. t0 + TG - 1 of one channel: the K + TG - 1 correlations are loaded once
-template <int K, int TG>
-__device__ __forceinline__ void corr_grad_run(const double* __restrict__ dc, int T, int C, const double* taps, int t0, double w,
-                                              double (&g)[TG]) {
-    const int n = T - K + 1;
-    double d[K + TG - 1];                       // d[i] = correlation at u = t0 - (K - 1) + i, zero outside [0, n)
-#pragma unroll
-    for (int i = 0; i < K + TG - 1; ++i) {
-        const int u = t0 - (K - 1) + i;
-        d[i] = (u >= 0 && u < n) ? dc[(size_t)u * C] : 0.0;
-    }
-    const double scale = w * 2.0 / ((double)n * C);
-#pragma unroll
-    for (int j = 0; j < TG; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc += taps[k] * d[(K - 1) + j - k];   // u = t0 + j - k, same order of terms as corr_grad
-        g[j] += acc * scale;
-    }
-}
-
+// (the per-element arithmetic -- smoothness gradients, total gradient, Adam, projection -- is in cp_update.h)
 constexpr int kGradRun = 4;   // frames per thread
 
-__global__ void total_grad_kernel(AdamArgs a) {
+// Total gradient (model gradient(s) + the three smoothness terms), torch.optim.Adam (no amsgrad / weight decay) and paule/paule.py:1201-1211 on the
+// CP tensor, one thread per (utterance, channel, run of kGradRun frames).  One kernel since round 5 (two before: the total gradient went out to
+// memory and came back, every workgroup of the second waited for its first thread's two pow() before it loaded anything, and a thread carried one
+// element's dependent f64 chain -- 25 + 31 us at cfg3): the loads of a run go out first, the step's scalars are computed under them, and four
+// independent chains of divisions and square roots fill each other's latencies.  Same operations per element in the same order (cp_update.h).
+__global__ __launch_bounds__(256) void cp_update_kernel(AdamArgs a) {
+    __shared__ double step_sc[2];   // lr / (1 - beta1^k), sqrt(1 - beta2^k)
     const int nrun = (a.T + kGradRun - 1) / kGradRun;
     const int64_t n = (int64_t)a.B * nrun * a.C;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const int c = (int)(idx % a.C);
-    const int t0 = (int)((idx / a.C) % nrun) * kGradRun;
-    const int b = (int)(idx / ((int64_t)a.C * nrun));
-    const size_t per = (size_t)a.T * a.C;
-    const double* dws = a.dwork + (size_t)b * 3 * per + c;   // channel c of utterance b, stride C over time
+    const bool on = idx < n;
+    const int64_t id = on ? idx : 0;
+    const int c = (int)(id % a.C);
+    const int t0 = (int)((id / a.C) % nrun) * kGradRun;
+    const int b = (int)(id / ((int64_t)a.C * nrun));
+    const int b_first = (int)(((int64_t)blockIdx.x * blockDim.x) / ((int64_t)a.C * nrun));   // the workgroup's first utterance: the buffer's base
     double gv[kGradRun] = {}, gj[kGradRun] = {}, gl[kGradRun] = {};
-    corr_grad_run<5, kGradRun>(dws, a.T, a.C, kVelTaps, t0, (double)a.w_vel, gv);
-    corr_grad_run<13, kGradRun>(dws + per, a.T, a.C, kJerkTaps, t0, (double)a.w_jerk, gj);
-    corr_grad_run<3, kGradRun>(dws + 2 * per, a.T, a.C, kLlTaps, t0, (double)a.w_ll, gl);
+    smooth_grads<kGradRun>(a, dwork_rsrc(a, b_first < a.B ? b_first : a.B - 1), b_first < a.B ? b_first : a.B - 1, b, c, t0, gv, gj, gl);
+    double g[kGradRun], m[kGradRun], v[kGradRun], x[kGradRun];
+#pragma unroll
+    for (int j = 0; j < kGradRun; ++j) {
+        const int t = t0 + j < a.T ? t0 + j : a.T - 1;   // (a frame beyond T: loaded from the last one, never stored)
+        const size_t e = ((size_t)t * a.Bp + b) * a.Cp + c;
+        const size_t k = ((size_t)b * a.T + t) * a.C + c;
+        g[j] = total_grad_of((double)a.dX[e], a.dX2 != nullptr, a.dX2 ? (double)a.dX2[e] : 0.0, gv[j], gj[j], gl[j]);
+        m[j] = a.m[k]; v[j] = a.v[k]; x[j] = a.x[k];
+    }
+    if (threadIdx.x == 0) adam_step_scalars(a, step_sc[0], step_sc[1]);
+    __syncthreads();
+    const double lr_bc1 = step_sc[0], sqrt_bc2 = step_sc[1];
+#pragma unroll
+    for (int j = 0; j < kGradRun; ++j) adam_value(a, b, t0 + j < a.T ? t0 + j : a.T - 1, c, g[j], lr_bc1, sqrt_bc2, m[j], v[j], x[j]);
+    if (!on) return;
 #pragma unroll
     for (int j = 0; j < kGradRun; ++j) {
         const int t = t0 + j;
         if (t < a.T) {
-            double g = (double)a.dX[((size_t)t * a.Bp + b) * a.Cp + c];
-            if (a.dX2) g += (double)a.dX2[((size_t)t * a.Bp + b) * a.Cp + c];
-            g += gv[j];
-            g += gj[j];
-            g += gl[j];
-            a.grad[((size_t)b * a.T + t) * a.C + c] = g;
+            const size_t k = ((size_t)b * a.T + t) * a.C + c;
+            a.grad[k] = g[j]; a.m[k] = m[j]; a.v[k] = v[j]; a.x[k] = x[j];
         }
     }
-}
-
-void launch_total_grad(hipStream_t stream, const AdamArgs& a) {
-    const int64_t n = (int64_t)a.B * ((a.T + kGradRun - 1) / kGradRun) * a.C;
-    hipLaunchKernelGGL(total_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a);
-}
-
-// torch.optim.Adam (no amsgrad / weight decay) on the CP tensor, then paule/paule.py:1201-1211.
-__global__ void adam_update_kernel(AdamArgs a) {
-    __shared__ double bias_corr[2];   // 1 - beta^k: two f64 pow() per workgroup instead of per element
-    if (threadIdx.x == 0) {
-        const int k = *a.step_count + 1;
-        bias_corr[0] = 1.0 - pow(a.beta1, (double)k);
-        bias_corr[1] = 1.0 - pow(a.beta2, (double)k);
-    }
-    __syncthreads();
-    const int64_t n = (int64_t)a.B * a.T * a.C;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const int c = (int)(idx % a.C);
-    const int t = (int)((idx / a.C) % a.T);
-    const int b = (int)(idx / ((int64_t)a.C * a.T));
-    const double g = a.grad[idx];
-    const double m = a.beta1 * a.m[idx] + (1.0 - a.beta1) * g;
-    const double v = a.beta2 * a.v[idx] + (1.0 - a.beta2) * g * g;
-    a.m[idx] = m;
-    a.v[idx] = v;
-    const double bc1 = bias_corr[0], bc2 = bias_corr[1];
-    const double denom = sqrt(v) / sqrt(bc2) + a.eps;
-    double x = a.x[idx] - (a.lr / bc1) * (m / denom);
-    x = fmin(fmax(x, a.clamp_lo), a.clamp_hi);
-    if (a.smiling) {
-        if (c == 4) x = -1.0;   // "LP"
-        if (c == 1) x = 1.0;    // "HY"
-    }
-    if (a.past && t < a.past_len)
-        x = a.past[((size_t)(a.past_per_utt ? b : 0) * a.past_len + t) * a.C + c];
-    a.x[idx] = x;
 }
 
 __global__ void bump_counters_kernel(int* step_count, int* iter_slot) {
@@ -518,9 +451,9 @@ __global__ void bump_counters_kernel(int* step_count, int* iter_slot) {
     }
 }
 
-void launch_adam_update(hipStream_t stream, const AdamArgs& a) {
-    const int64_t n = (int64_t)a.B * a.T * a.C;
-    hipLaunchKernelGGL(adam_update_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a);
+void launch_cp_update(hipStream_t stream, const AdamArgs& a) {
+    const int64_t n = (int64_t)a.B * ((a.T + kGradRun - 1) / kGradRun) * a.C;
+    hipLaunchKernelGGL(cp_update_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, stream, a.step_count, a.iter_slot);
 }
 

@@ -43,6 +43,25 @@ void launch_lstm_bwd_step(hipStream_t stream, int dt, const LstmStepArgs& a);
 
 // ---- lstm_persist.hip -----------------------------------------------------------------------
 // One launch = all T steps of one layer (bf16, register-resident W_hh, in-launch exchange).
+// Arguments of the CP update (total gradient + Adam + projection, elementwise.hip, cp_update.h)
+struct AdamArgs {
+    int B, T, C, Bp, Cp;
+    double lr, beta1, beta2, eps, clamp_lo, clamp_hi;
+    float w_vel, w_jerk, w_ll;
+    int smiling;
+    const float* dX;       // model gradient f32 time-major [T][Bp][Cp]
+    const float* dX2;      // second model gradient (the CP -> tube model of the somatosensory path), same layout, or null
+    double* x;             // CP master [B][T][C]
+    double* m;
+    double* v;
+    double* grad;          // total gradient [B][T][C] (model + smoothness)
+    const double* dwork;   // correlations written by the loss reduction of this iteration
+    int* step_count;       // device counter k (incremented by the update kernel)
+    int* iter_slot;        // device counter (incremented by the update kernel)
+    const double* past;    // past_cp [B or 1][P][C] or null
+    int past_len, past_per_utt;
+};
+
 struct LstmSweepArgs {
     int Bp, T;
     int group_rows;        // batch rows per group (8..32, multiple of 8): lstm_sweep_group_rows()
@@ -278,27 +297,8 @@ void launch_add2_act(hipStream_t stream, int dt, const float* a, const float* b,
 // time-major padded f32 [T][Bp][Cp] -> batch-major [B][T][C]
 void launch_tm_to_bm(hipStream_t stream, const float* src, int B, int T, int C, int Bp, int Cp, float* dst);
 
-struct AdamArgs {
-    int B, T, C, Bp, Cp;
-    double lr, beta1, beta2, eps, clamp_lo, clamp_hi;
-    float w_vel, w_jerk, w_ll;
-    int smiling;
-    const float* dX;       // model gradient f32 time-major [T][Bp][Cp]
-    const float* dX2;      // second model gradient (the CP -> tube model of the somatosensory path), same layout, or null
-    double* x;             // CP master [B][T][C]
-    double* m;
-    double* v;
-    double* grad;          // total gradient [B][T][C] (model + smoothness)
-    const double* dwork;   // correlations written by the loss reduction of this iteration
-    int* step_count;       // device counter k (incremented by the update kernel)
-    int* iter_slot;        // device counter (incremented by the update kernel)
-    const double* past;    // past_cp [B or 1][P][C] or null
-    int past_len, past_per_utt;
-};
-// grad = dX^T + d(smoothness)/dx     (reads x, writes grad)
-void launch_total_grad(hipStream_t stream, const AdamArgs& a);
-// Adam + clamp + smiling + past_cp, in place on x/m/v; bumps step_count and iter_slot
-void launch_adam_update(hipStream_t stream, const AdamArgs& a);
+// grad = dX^T (+ dX2^T) + d(smoothness)/dx, then Adam + clamp + smiling + past_cp in place on x/m/v; bumps step_count and iter_slot
+void launch_cp_update(hipStream_t stream, const AdamArgs& a);
 
 // misc conversions
 void launch_f64_to_f32(hipStream_t stream, const double* src, float* dst, int64_t n);

@@ -1941,8 +1941,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     if (tube_nc) tube_backward_pipeline(h, st, tube_nc, la);
     else if (h->tube_on()) tube_backward(h, st, la);
     AdamArgs aa = adam_args(h);
-    launch_total_grad(st, aa);
-    launch_adam_update(st, aa);
+    launch_cp_update(st, aa);
     h->sweep_slot = -1;
 }
 

@@ -7,7 +7,7 @@ import sys
 f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof/runc/*_kernel_trace.csv"))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_update" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "cp_update" in r["Kernel_Name"] or "adam_update" in r["Kernel_Name"]]
 a, b = idx[-2] + 1, idx[-1] + 1
 tot = 0.0
 t_first = int(rows[a]["Start_Timestamp"])
