@@ -468,6 +468,233 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward sweep, STREAMED form of the reduce-scatter (round 5): the per-tile hand-off of lstm_persist_rs.hip on the f32 tiles.
+// In the kernel above a step is a chain of whole-workgroup phases -- 46 tiles, drain (vmcnt(0)), barrier, ONE flag, (consumers) poll all
+// 46 flags, barrier, 46 tile loads, sums -- and the last tile's way to its consumer starts only when the producer's slowest wave has
+// drained.  Here every 16 x 16 tile travels on its own:
+//   * a tile is produced by ONE wave (16 MFMAs, one 16-byte store per lane), so that wave alone waits for its store (counted vmcnt, one
+//     tile behind: the wait sits under the next tile's MFMAs) and raises the tile's OWN flag,
+//     tflags[slot][group][destination][source] = step + 1 (a 64-int row per destination, zeroed with the other flags);
+//   * source p produces its tiles in the rotated order destination p + 1, p + 2, ... (mod P), four waves at a time, so that every
+//     destination receives a share of its tiles per round instead of all of them in one;
+//   * wave w of a destination sums the tiles of sources w * TPG ..: it polls THEIR flags with one wave instruction, loads (16 bytes per
+//     lane: one instruction = one 1-KB tile) whatever has newly arrived, and polls again.
+// Same tiles, same 16 MFMAs per tile, same fixed order of every sum (a wave's tiles in source order, then the four waves' sums):
+// bit-identical to the kernel above (tests/test_hip_parity.py::test_f32_streamed_backward_is_bit_identical).  Two workgroup barriers per
+// step instead of four; hand-off rules as before (write-through sc1 both sides, or plain / nt through the shared L2 for a group that
+// verified it sits on one XCD); every spin bounded.  Whole sequences on the MFMA path only (time chunks and the few-row kernels keep
+// the form above).
+__device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a value the unrolled caller knows at compile time
+    switch (n) {
+#define PL_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        PL_VM(0) PL_VM(1) PL_VM(2) PL_VM(3) PL_VM(4) PL_VM(5) PL_VM(6) PL_VM(7) PL_VM(8) PL_VM(9) PL_VM(10) PL_VM(11) PL_VM(12) PL_VM(13) PL_VM(14) PL_VM(15) PL_VM(16)
+#undef PL_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+#ifndef PL_F32_STREAM_D
+#define PL_F32_STREAM_D 6
+#endif
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_stream_f32_kernel(LstmSweepArgs a) {
+    constexpr int D = PL_F32_STREAM_D < (KS + 3) / 4 ? PL_F32_STREAM_D : (KS + 3) / 4;   // tiles in flight behind a flag (<= 8: the exact counts fit wait_vm)
+    constexpr int Hp = 16 * KS;
+    constexpr int P = KS;                        // workgroups per group = N tiles of 16 hidden units
+    constexpr int NT = (P + 3) / 4;              // tiles per wave: positions k = wave + 4 i of the rotated order
+    constexpr int TPG = (P + 3) / 4;             // sources per wave of the ingest: w * TPG ..
+    constexpr int DRS = 64 * 4 + 16;             // dA^T image [16 batch rows][64 local gate rows] f32
+    static_assert(P <= 64, "one flag word per source in a 64-int row");
+    __shared__ __attribute__((aligned(16))) unsigned char da_img[16 * DRS];
+    __shared__ __attribute__((aligned(16))) float red[4][16][16];   // per-wave sums of the partial tiles
+    __shared__ int lds_flag, lds_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_res = gridDim.x / P;
+    const int g_first = blockIdx.x % n_res, p = blockIdx.x / n_res;
+    const int Bp = a.Bp, T = a.T, G4 = 4 * Hp;
+    const int n_groups = (Bp + 15) / 16;
+    const float* __restrict__ WT = static_cast<const float*>(a.W);   // Whh^T packed [Hp][4*Hp]
+    const int kq = lane >> 4;
+
+    // weights -> registers: the wave's tile at position k = wave + 4 i goes to destination nt = (p + 1 + k) mod P: A row = hidden column
+    // n = 16 nt + (lane & 15); chunk c = gate c: k = 4 kq + e  <->  gate row c * Hp + 16 p + 4 kq + e
+    float4 wreg[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int k = wave + 4 * i;
+        const int nt = k < P ? (p + 1 + k) % P : 0;
+        const int n = 16 * nt + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wreg[i][c] = *reinterpret_cast<const float4*>(WT + (size_t)n * G4 + c * Hp + 16 * p + 4 * kq);
+    }
+
+    // cell ownership: thread -> batch row tid >> 4, unit 16p + (tid & 15)
+    const int erow = tid >> 4, eu = tid & 15;
+    const int j = 16 * p + eu;
+    PL_ST_DECL
+    const size_t slabG = (size_t)Bp * G4, slabH = (size_t)Bp * Hp;
+    float* __restrict__ G = static_cast<float*>(a.G);
+    const float* __restrict__ Cs = static_cast<const float*>(a.c);
+    const float* __restrict__ dhe = static_cast<const float*>(a.dh_ext);
+    const float* __restrict__ dhl = static_cast<const float*>(a.dh_last);
+    // exchange [2 slots][groups][P destinations][P sources][16 rows][16 columns] f32 (1-KB tiles)
+    float* __restrict__ X = static_cast<float*>(a.xchg);
+    constexpr size_t TILE = 16 * 16;
+    const size_t grp_stride = (size_t)P * P * TILE;
+    const size_t slot_stride = (size_t)n_groups * grp_stride;
+    int* const tf = a.tflags;   // [2 slots][groups][P destinations][64]: the row of destination d holds one word per source
+    // the sources this wave sums: w * TPG .. (the last wave's share may be short)
+    const int n_src = P - wave * TPG < TPG ? P - wave * TPG : TPG;
+    const unsigned full = n_src >= 32 ? 0xffffffffu : ((1u << n_src) - 1u);
+    if (tid == 0) lds_abort = 0;
+    __syncthreads();
+
+    for (int g = g_first; g < n_groups; g += n_res) {
+        const int b = 16 * g + erow;
+        float dc_next = 0.f;
+        int* xtab = a.xcc_tab + (size_t)g * 64;
+        bool plain_handoff = false;
+
+        for (int t = T - 1; t >= 0; --t) {
+            const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
+            const float gi = g_row[0], gf = g_row[Hp], gg = g_row[2 * Hp], go = g_row[3 * Hp];
+            const float c = Cs[(size_t)t * slabH + (size_t)b * Hp + j];
+            const float cp = t > 0 ? Cs[(size_t)(t - 1) * slabH + (size_t)b * Hp + j] : 0.f;
+            float dh = 0.f;
+            if (dhe) dh = dhe[(size_t)t * slabH + (size_t)b * Hp + j];
+            else if (dhl && t == T - 1) dh = dhl[(size_t)b * Hp + j];
+            PL_ST(0);
+            if (t + 1 < T) {
+                // the tiles of step t + 1 for this workgroup's units, loaded as their flags come up (vmcnt retires in order, so a poll's answer
+                // is seen after the tile loads issued before it have landed -- loads the step needs anyway)
+                const int token = t + 2;
+                const int* frow = tf + ((size_t)((t + 1) & 1) * n_groups + g) * P * 64 + (size_t)p * 64 + wave * TPG;
+                const __amdgpu_buffer_rsrc_t rf = make_rsrc(frow, (unsigned)(TPG * 4));
+                const float* xs = X + (size_t)((t + 1) & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * P * TILE;
+                const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (unsigned)(P * TILE * 4));
+                const int r16 = lane >> 2, quad = lane & 3;
+                const unsigned o0 = (unsigned)((wave * TPG * TILE + r16 * 16 + quad * 4) * 4);
+                uint4 pw[TPG];
+#pragma unroll
+                for (int i = 0; i < TPG; ++i) pw[i] = make_uint4(0u, 0u, 0u, 0u);
+                unsigned issued = 0;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (unsigned spin = 1;; ++spin) {
+                    int v = 0;
+                    if (lane < TPG)
+                        v = plain_handoff ? (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxNt)
+                                          : (int)__builtin_amdgcn_raw_buffer_load_b32(rf, (unsigned)(lane * 4), 0, kAuxSc1);
+                    const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(v == token) & full;
+                    const unsigned newly = (unsigned)__builtin_amdgcn_readfirstlane((int)(mask & ~issued));
+#pragma unroll
+                    for (int i = 0; i < TPG; ++i)
+                        if ((newly >> i) & 1u) pw[i] = ld16_ho(rx, o0 + (unsigned)(i * TILE * 4), plain_handoff);
+                    issued |= newly;
+                    if (issued == full) break;
+                    if ((spin & a.poll_mask) == 0 &&
+                        (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0 ||
+                         __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks)) {
+                        if (lane == 0) {
+                            __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            lds_abort = 1;
+                        }
+                        break;   // (what was not issued stays zero; the workgroup leaves behind the barrier below)
+                    }
+                }
+                PL_ST(1);   // polls + tile loads issued
+                float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < TPG; ++i) {
+                    part.x += __builtin_bit_cast(float, pw[i].x);
+                    part.y += __builtin_bit_cast(float, pw[i].y);
+                    part.z += __builtin_bit_cast(float, pw[i].z);
+                    part.w += __builtin_bit_cast(float, pw[i].w);
+                }
+                *reinterpret_cast<float4*>(&red[wave][r16][quad * 4]) = part;
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(lds_abort) != 0) return;
+                dh += (red[0][erow][eu] + red[1][erow][eu]) + (red[2][erow][eu] + red[3][erow][eu]);
+                if (t == T - 2 && a.xcd_fast) plain_handoff = group_on_one_xcd(xtab, P, &lds_flag);
+            }
+            PL_ST(2);   // tiles landed + sums
+
+            const float tc = tanhf(c);
+            const float dc = dc_next + dh * go * (1.f - tc * tc);
+            const float dai = dc * gg * gi * (1.f - gi);
+            const float daf = dc * cp * gf * (1.f - gf);
+            const float dag = dc * gi * (1.f - gg * gg);
+            const float dao = dh * tc * go * (1.f - go);
+            dc_next = dc * gf;
+            {   // dA_t overwrites the gate stash in place (read later by the dX / dH GEMM launches)
+                float* go_ = G + (size_t)t * slabG + (size_t)b * G4 + j;
+                go_[0] = dai;
+                go_[Hp] = daf;
+                go_[2 * Hp] = dag;
+                go_[3 * Hp] = dao;
+            }
+            if (t == 0) break;   // nobody consumes the partials of step 0
+            if (t == T - 1 && tid == 0) {   // this workgroup's XCD, in place before ANY of its flags (they are raised behind the barrier below)
+                __hip_atomic_store(xtab + p, xcc_id_plus1(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            {   // dA_t of this slice as the MFMA B operand: image [batch row][gate * 16 + unit]
+                float* drow = reinterpret_cast<float*>(da_img + erow * DRS) + eu;
+                drow[0] = dai;
+                drow[16] = daf;
+                drow[32] = dag;
+                drow[48] = dao;
+            }
+            __syncthreads();
+            PL_ST(3);   // cell + stash stores + dA image + barrier
+            float* xd = X + (size_t)(t & 1) * slot_stride + (size_t)g * grp_stride + (size_t)p * TILE;   // [dest][this source]
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(xd, (unsigned)(((size_t)(P - 1) * P + 1) * TILE * 4));
+            int* const fcol = tf + ((size_t)(t & 1) * n_groups + g) * P * 64 + p;   // + 64 * destination
+            const __amdgpu_buffer_rsrc_t rfl = make_rsrc(fcol, (unsigned)(((P - 1) * 64 + 1) * 4));
+            auto raise = [&](int nt) {   // the wave's own store of that tile is acknowledged: its flag
+                if (lane == 0) {
+                    if (plain_handoff) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), rfl, (unsigned)(nt * 64 * 4), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), rfl, (unsigned)(nt * 64 * 4), 0, kAuxSc1);
+                }
+            };
+            float4 bfr[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) bfr[c4] = *reinterpret_cast<const float4*>(da_img + (lane & 15) * DRS + c4 * 64 + kq * 16);
+            int n_done = 0;   // tiles this wave has stored in this step
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int k = wave + 4 * i;
+                // (the test is a compile-time fact for all but a wave's last tile and sits IN FRONT of the tile's MFMAs: no MFMA result is read
+                // across it.  An `if`, not a `break`: with a break hipcc gave up unrolling at KS = 46 and moved the weights to scratch)
+                if (4 * i + 3 < P || k < P) {
+                    const int nt = (p + 1 + k) % P;
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) acc = mfma4(wreg[i][c4], bfr[c4], acc);
+                    // acc[r] = partial[n = 16 nt + 4 kq + r][batch lane & 15]: a lane's 4 registers are 16 contiguous bytes of tile row b
+                    st16_handoff(ro, (unsigned)(((size_t)nt * P * TILE + (lane & 15) * 16 + 4 * kq) * 4),
+                                 make_float4(acc[0], acc[1], acc[2], acc[3]), plain_handoff);
+                    // The flag of the tile D positions back: its store is acknowledged once at most N younger operations are outstanding -- the D tiles
+                    // behind it and the flags raised meanwhile, min(D, i - D) of them (exact: a looser count would let the flag overtake its tile).
+                    // D tiles in flight because a write-through acknowledge takes ~1.5 us and a tile's MFMAs 0.2: waiting one tile back (D = 1,
+                    // the bf16 kernel's distance, whose stores are acknowledged by the L2) stalls the wave on every tile: cfg2 3.79 -> 4.16 ms.
+                    if (i >= D) {
+                        wait_vm(D + (i - D < D ? i - D : D));
+                        raise((p + 1 + wave + 4 * (i - D)) % P);
+                    }
+                    n_done = i + 1;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last D tiles: flags behind the wave's final drain (the last tile's flag cannot be earlier)
+#pragma unroll
+            for (int r = D; r >= 1; --r)
+                if (n_done - r >= 0) raise((p + 1 + wave + 4 * (n_done - r)) % P);
+            PL_ST(4);   // tiles + flags
+        }
+    }
+    PL_ST_DUMP(a.stamps);
+}
+
+// ---------------------------------------------------------------------------------------------------
 #ifndef PL_F32_FEW_ROWS
 #define PL_F32_FEW_ROWS 2
 #endif
@@ -504,7 +731,9 @@ static int few_rows(const LstmSweepArgs& a) { return (a.Bp == 16 && a.n_valid >=
 
 template <int K, int NV>
 static void launch_f32_nv(hipStream_t stream, bool backward, int ksx, int grid, const LstmSweepArgs& a) {
-    if (backward) hipLaunchKernelGGL((lstm_bwd_sweep_f32_kernel<K, NV>), dim3(grid), dim3(256), 0, stream, a);
+    if (backward && NV == 0 && a.tflags && a.t0 == 0 && (a.t1 == 0 || a.t1 == a.T) && (a.stash_via_lds & 2))   // whole sequence on the MFMAs: streamed hand-off
+        hipLaunchKernelGGL((lstm_bwd_stream_f32_kernel<K>), dim3(grid), dim3(256), 0, stream, a);
+    else if (backward) hipLaunchKernelGGL((lstm_bwd_sweep_f32_kernel<K, NV>), dim3(grid), dim3(256), 0, stream, a);
     else if (ksx == 2) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 2, NV>), dim3(grid), dim3(256), 0, stream, a);
     else if (ksx == 4) hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 4, NV>), dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((lstm_fwd_sweep_f32_kernel<K, 0, NV>), dim3(grid), dim3(256), 0, stream, a);

@@ -281,6 +281,7 @@ struct pl_handle {
     bool fused_fwd_ok = false;  // PAULE_HIP_FUSED bit 0 and the shapes / CU budget fit (plan_fused)
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
     int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
+    int f32_stream = 0;   // PAULE_HIP_F32_STREAM: 1 = per-tile hand-off in the whole-sequence f32 backward sweeps (lstm_bwd_stream_f32_kernel; opt-in: bit-identical, measured neutral -- profiles/r05_f32_stream.txt), 0 = one flag per workgroup and step
     int bwd_pf = -1, bwd_pf_dist = 4;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf): -1 auto, 0 off
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
@@ -477,9 +478,13 @@ void launch_sweep(pl_handle* h, hipStream_t st, bool bwd, int Hp, int grid, cons
             if (bwd) { sc.n_pf = bwd_prefetchers_for(h, Hp, cgrid, 16); sc.pf_dist = h->bwd_pf_dist; }
             launch_lstm_chain_f32(st, bwd, Hp, cgrid, sc);
         } else {
+            // PAULE_HIP_F32_STREAM=1 (round 5, opt-in): whole-sequence backward sweeps on the MFMAs with the streamed per-tile hand-off;
+            // its tile flags sit behind the XCD-id table of the same flag slice, as in bf16
+            LstmSweepArgs sf = s;
+            if (bwd && h->f32_stream && s.t0 == 0 && (s.t1 == 0 || s.t1 == s.T)) sf.tflags = s.xcc_tab + (size_t)((h->Bp + 7) / 8) * 64;
             // (no prefetchers beside the one-chain f32 sweeps: their step is MFMA issue, 3.1 of 6.0 us, and the flag wait 0.8 -- cfg2 3.88 ms
             // per iteration with and without, profiles/r05_ab_prefetchers.txt; the chains kernel above gains 4 %)
-            launch_lstm_sweep_f32(st, bwd, Hp, grid, s);
+            launch_lstm_sweep_f32(st, bwd, Hp, grid, sf);
         }
     }
     else if (use_sweep16(h, Hp, bwd))
@@ -2280,6 +2285,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_CHAINS")) h->bwd_chains = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_PF")) h->bwd_pf = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_F32_STREAM")) h->f32_stream = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_PF_DIST")) h->bwd_pf_dist = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
         if (const char* z = std::getenv("PAULE_HIP_BWD_DMA")) h->bwd_dma = std::atoi(z) & 3;
@@ -2388,7 +2394,8 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
             if (md->L > 0 && md->Hp / slice > pmax) pmax = md->Hp / slice;
         h->flag_stride = (pmax + 15) / 16 * 16;
         // arrival flags, then the XCD-id table, then (bf16) the per-tile flags of the streamed backward hand-off [2][groups][P][32]
-        const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64 + (h->dt == BF16 ? 2 * n_groups_max * (size_t)pmax * 32 : 0);
+        // (f32: [2][groups][P][64] for lstm_bwd_stream_f32_kernel)
+        const size_t n = n_groups_max * T * h->flag_stride + n_groups_max * 64 + 2 * n_groups_max * (size_t)pmax * (h->dt == BF16 ? 32 : 64);
         h->sweep_cnt_bytes = (n * sizeof(int) + 15) / 16 * 16;
         // forward + backward sweep of every layer of an iteration, + the head / projection roles of the fused launches
         h->n_sweep_slots = 2 * (cfg->pred_layers + cfg->emb_layers + cfg->cp_tube_layers + cfg->tube_mel_layers + cfg->tube_emb_layers) +

@@ -216,6 +216,43 @@ def test_f32_chains_equal_groups_taking_turns(shape, monkeypatch):
             np.testing.assert_allclose(cp, outs["0"][1], atol=CP_ATOL_F32, rtol=0)
 
 
+@pytest.mark.parametrize("shape", [dict(B=64, T=31, H=720), dict(B=20, T=40, H=720), dict(B=96, T=21, H=720, chains="0"), dict(B=150, T=30, H=96),
+                                   dict(B=7, T=24, H=96)])
+def test_f32_streamed_backward_is_bit_identical(shape, monkeypatch):
+    """Round 5: the whole-sequence f32 backward sweeps hand every 16 x 16 partial tile over on its own (lstm_bwd_stream_f32_kernel: the
+    producing wave's counted wait and the tile's own flag, rotated destination order, each ingest wave polling the flags of the sources it
+    sums) instead of one flag per workgroup and step.  Same tiles, same MFMAs, same fixed order of every sum: against
+    PAULE_HIP_F32_STREAM=0 the loss log, every layer's dA, dL/dCP and CP are the same bits.  cfg2's shape (4 groups x 46 workgroups), a
+    ragged group, groups taking turns (two passes with the chains off), a narrow model (6 workgroups a group: the same-XCD hand-off,
+    odd and even T), a batch smaller than a group."""
+    from paule_amd.engine import HipPlanner
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    wl = synthetic.make_workload(B, T, None, pred=dict(num_lstm_layers=1, hidden_size=H), emb=dict(num_lstm_layers=2, hidden_size=H))
+    if "chains" in shape:
+        monkeypatch.setenv("PAULE_HIP_F32_CHAINS", shape["chains"])
+    monkeypatch.setenv("PAULE_HIP_F32_VALU", "0")
+    outs = {}
+    for st in ("0", "1"):
+        monkeypatch.setenv("PAULE_HIP_F32_STREAM", st)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec")
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        l1 = _n(eng.step(1))
+        eng.synchronize()
+        bufs = {k: _n(eng.debug_read(k)) for k in ("emb.G1", "emb.G0", "pred.G0", "dX")}
+        l4 = _n(eng.step(3))
+        eng.synchronize()
+        outs[st] = (l1, bufs, l4, _n(eng.get_cp()))
+        eng.close()
+    a, b = outs["1"], outs["0"]
+    np.testing.assert_array_equal(a[0], b[0])
+    for k in b[1]:
+        assert np.isfinite(a[1][k]).all() and np.abs(a[1][k]).max() > 0, k
+        np.testing.assert_array_equal(a[1][k], b[1][k], err_msg=k)
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
+
+
 def test_optimizer_state_persists_and_resets(HipPlanner, golden_small):
     """Adam state continues across pl_step calls (= outer iterations, paule/paule.py:797) and resets on request."""
     g = golden_small
