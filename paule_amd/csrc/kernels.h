@@ -212,6 +212,8 @@ struct FusedArgs {
     unsigned long long census_ticks;   // holds CUs) sets status 2 and leaves within census_ticks instead of spinning for seconds in its waits
     unsigned long long census_late_ticks;   // test hook (PAULE_HIP_DEBUG=census_late_ms=N): workgroup 0 signs in this late; 0 = off
     unsigned long long* stamps;
+    int prio;                 // lstm_fused2.hip (round 5, PAULE_HIP_FUSED2_PRIO): roles of at most this many chains raise their waves' issue priority (s_setprio 3) -- the
+                              // predictor's recurrence is the launch's dependent chain and shares its CU with a role that has slack; 0 = all waves equal
     const FusedRole* roles;   // [n_roles] in device memory (a table in the kernel arguments would have to be indexed dynamically,
                               // which makes the compiler copy it to scratch)
 };

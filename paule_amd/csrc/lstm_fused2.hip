@@ -779,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd2_kernel(FusedArgs a) {
     if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
     __syncthreads();
     const FusedRole R = uniform_role(a.roles[role]);
+    if (a.prio > 0 && R.C <= a.prio) __builtin_amdgcn_s_setprio(3);
     const int set_step = a.gpp > 0 ? uni(a.gpp / R.C) : 0;   // passes: as in fused_fwd_kernel
     for (int s2 = set;; s2 += set_step) {
         if constexpr (KSP == KSE) {

@@ -282,6 +282,8 @@ struct pl_handle {
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
     int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
     int f32_stream = 0;   // PAULE_HIP_F32_STREAM: 1 = per-tile hand-off in the whole-sequence f32 backward sweeps (lstm_bwd_stream_f32_kernel; opt-in: bit-identical, measured neutral -- profiles/r05_f32_stream.txt), 0 = one flag per workgroup and step
+    int fused2_prio = -1;  // PAULE_HIP_FUSED2_PRIO (FusedArgs::prio): -1 auto = 1 where a one-layer predictor runs on ONE chain beside embedder roles on two or more (set A at
+                           // 193 ... 256 rows: its 300 chain-steps are the launch; cfg3 4.088 -> 4.052 ms), else 0 (set B: 3.99 -> 4.02 with it); profiles/r05_ab_fused2_prio.txt
     int bwd_pf = -1, bwd_pf_dist = 4;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf): -1 auto, 0 off
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
     int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
@@ -1643,6 +1645,7 @@ void fused_common_args(pl_handle* h, FusedArgs& a, int grid, const short* tab, c
         if (debug_value("census_expect_extra", &z)) a.n_active += (int)z;
         if (debug_value("census_late_ms", &z)) a.census_late_ticks = 100000ull * (unsigned long long)z;
     }
+    a.prio = bwd ? 0 : (h->fused2_prio >= 0 ? h->fused2_prio : ((h->pred.L == 1 && h->fused_Cp == 1 && h->fused_Ce >= 2) ? 1 : 0));
     a.census_ticks = h->census_ticks;
     if (h->debug_fused)
         fprintf(stderr, "[pl] fused %s launch: grid %d, %d role-bearing workgroups expected, census word at slice int %zu, bound %llu ticks, Cp %d Ce %d\n",
@@ -2285,6 +2288,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_XT")) h->bwd_xt = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_CHAINS")) h->bwd_chains = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_PF")) h->bwd_pf = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_FUSED2_PRIO")) h->fused2_prio = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_F32_STREAM")) h->f32_stream = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_PF_DIST")) h->bwd_pf_dist = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library
