@@ -216,6 +216,7 @@ __device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh)[6]) { bl
 // chunking is a function of T alone, so an utterance's sums are the same bits in whatever batch it is planned (the row-independence
 // tests); the chunks' partial sums are added in order by loss_finalize_kernel.
 constexpr int kLossChunkT = 256;
+constexpr int kCorrRun = 10;   // frames per thread of the correlation window (T = 300 on 32 runs of a 1024-thread workgroup)
 // up to 511 frames one workgroup per utterance (T = 300 at B = 256: two half-size workgroups per utterance measured no faster), then
 // one per ~256 frames, of equal length
 int loss_chunks(int T) { return T < 2 * kLossChunkT ? 1 : (T + kLossChunkT - 1) / kLossChunkT; }
@@ -258,9 +259,38 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(LossArgs a, int nchun
     double* dws = a.dwork + (size_t)b * 3 * per;     // [vel | jerk | ll] correlations of this utterance
     const int tc = (a.T + nchunk - 1) / nchunk;   // frames per chunk
     const int t0 = ch * tc, t1 = ch == nchunk - 1 ? a.T : (ch + 1) * tc;
-    s[2] = corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws, t0, t1);
-    s[3] = corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per, t0, t1);
-    s[4] = corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per, t0, t1);
+    // The three correlations of this workgroup's frames from ONE window of CP rows per thread (round 5): a thread owns channel tid & 31 of a run of
+    // kCorrRun frames, loads its kCorrRun + 12 rows once (all in flight; channel-fastest over the lanes: whole 240-byte rows) and forms every
+    // d[t] = sum_k taps[k] x[t + k] in the taps' order -- the same bits per correlation as one load per tap (21 loads per frame and channel from L2:
+    // 42 us at cfg3), only the order in which their squares are added differs (fixed: a function of T alone, so the row-independence rule holds).
+    if (a.C <= 32) {
+        const int c = tid & 31, nrun = nt >> 5;
+        for (int ta = t0 + (tid >> 5) * kCorrRun; ta < t1; ta += nrun * kCorrRun) {
+            if (c >= a.C) continue;
+            double xw[kCorrRun + 12];
+#pragma unroll
+            for (int k = 0; k < kCorrRun + 12; ++k) xw[k] = ta + k < a.T ? x[(size_t)(ta + k) * a.C + c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < kCorrRun; ++i) {
+                const int t = ta + i;
+                double dv = 0.0, dj = 0.0, dl = 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dv += kVelTaps[k] * xw[i + k];
+#pragma unroll
+                for (int k = 0; k < 13; ++k) dj += kJerkTaps[k] * xw[i + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dl += kLlTaps[k] * xw[i + k];
+                const size_t e = (size_t)t * a.C + c;
+                if (t < t1 && t < a.T - 4) { dws[e] = dv; s[2] += dv * dv; }
+                if (t < t1 && t < a.T - 12) { dws[per + e] = dj; s[3] += dj * dj; }
+                if (t < t1 && t < a.T - 2) { dws[2 * per + e] = dl; s[4] += dl * dl; }
+            }
+        }
+    } else {
+        s[2] = corr_sumsq<5>(x, a.T, a.C, kVelTaps, tid, nt, dws, t0, t1);
+        s[3] = corr_sumsq<13>(x, a.T, a.C, kJerkTaps, tid, nt, dws + per, t0, t1);
+        s[4] = corr_sumsq<3>(x, a.T, a.C, kLlTaps, tid, nt, dws + 2 * per, t0, t1);
+    }
     block_sum_n<8>(s, sh);
     if (tid == 0) {
         double* pr = a.part + ((size_t)b * nchunk + ch) * 8;
