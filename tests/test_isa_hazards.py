@@ -14,6 +14,10 @@ spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(ROOT, "to
 isa_scan = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(isa_scan)
 
+spec2 = importlib.util.spec_from_file_location("isa_asm_scan", os.path.join(ROOT, "tools", "isa_asm_hazard_scan.py"))
+isa_asm = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(isa_asm)
+
 # the shape of the bug as hipcc compiled it at 81e779f^: an MFMA directly in front of a conditional branch whose target reads its result
 BUGGY = """
 _Z5buggyv:
@@ -81,6 +85,71 @@ def test_scanner_follows_the_compilers_flag_idiom(tmp_path):
     assert any("v_mul_lo_u32 v2" in f[4] for f in bad), bad
 
 
+# ---- hazards inline asm can break (tools/isa_asm_hazard_scan.py): the LDS-DMA blocks read M0 and an SGPR base the surrounding code wrote ----
+# the library's block as it is written (s_nop 0 behind the M0 write) with its SGPR operands produced far enough ahead ...
+DMA_OK = """
+_Z6dma_okv:
+	v_readfirstlane_b32 s4, v10
+	v_readfirstlane_b32 s5, v11
+	v_readfirstlane_b32 s6, v12
+	v_add_u32_e32 v1, v2, v3
+	v_add_u32_e32 v4, v2, v3
+	s_mov_b32 s20, m0
+	s_mov_b32 m0, s6
+	s_nop 0
+	global_load_lds_dwordx4 v9, s[4:5] sc1
+	s_mov_b32 m0, s20
+	s_endpgm
+.Lfunc_end0:
+"""
+# ... the M0 write directly in front of the load (H1), and the base address read two wait states behind its v_readfirstlane on the TAKEN edge (H2)
+DMA_NO_NOP = DMA_OK.replace("\ts_nop 0\n", "")
+DMA_SGPR_LATE = """
+_Z8dma_latev:
+	v_readfirstlane_b32 s5, v11
+	s_cbranch_scc1 .LBB0_2
+; %bb.1:
+	s_nop 7
+.LBB0_2:
+	s_mov_b32 m0, s6
+	s_nop 0
+	global_load_lds_dwordx4 v9, s[4:5] sc1
+	s_endpgm
+.Lfunc_end0:
+"""
+LANE_SELECT = """
+_Z4lanev:
+	v_readfirstlane_b32 s7, v3
+	s_nop 1
+	v_readlane_b32 s8, v5, s7
+	v_cmp_lt_f32_e32 vcc, v1, v2
+	s_nop 2
+	v_div_fmas_f32 v6, v7, v8, v9
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def _asm_scan_text(text, tmp_path, name):
+    p = tmp_path / name
+    p.write_text(text)
+    out = []
+    for fn, lines in isa_asm.functions(str(p)):
+        out += isa_asm.scan_function(fn, lines)[0]
+    return out
+
+
+def test_asm_hazard_scanner_on_the_lds_dma_block(tmp_path):
+    assert _asm_scan_text(DMA_OK, tmp_path, "ok.s") == []
+    bad = _asm_scan_text(DMA_NO_NOP, tmp_path, "nonop.s")
+    assert len(bad) == 1 and bad[0][5].startswith("H1") and "0 wait" in bad[0][5], bad
+    bad = _asm_scan_text(DMA_SGPR_LATE, tmp_path, "late.s")
+    assert len(bad) == 1 and bad[0][5].startswith("H2") and "(s5)" in bad[0][5] and "3 wait" in bad[0][5], bad   # branch, s_mov, s_nop 0 on the taken edge
+    bad = _asm_scan_text(LANE_SELECT, tmp_path, "lane.s")
+    assert sorted(f[5][:2] for f in bad) == ["H3", "H4"], bad
+    assert _asm_scan_text(LANE_SELECT.replace("s_nop 1", "s_nop 3").replace("s_nop 2", "s_nop 3"), tmp_path, "lane_ok.s") == []
+
+
 def _makefile_sources():
     """The SRCS of paule_amd/csrc/Makefile: what the shipped library is built from -- a new kernel file is scanned without anybody listing it here."""
     mk = open(os.path.join(ROOT, "paule_amd", "csrc", "Makefile")).read()
@@ -93,7 +162,7 @@ MFMA_FLOOR = {"gemm.hip": 430, "gemm_big.hip": 120, "lstm.hip": 36, "lstm_chain_
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-def test_shipped_kernels_have_no_mfma_read_hazard(tmp_path):
+def test_shipped_kernels_have_no_mfma_read_hazard_and_no_asm_hazard(tmp_path):
     files = _makefile_sources()
     assert set(MFMA_FLOOR) <= set(files), (sorted(MFMA_FLOOR), files)
 
@@ -105,13 +174,19 @@ def test_shipped_kernels_have_no_mfma_read_hazard(tmp_path):
 
     with ThreadPoolExecutor(8) as ex:
         outs = list(ex.map(build, files))
-    findings, n_mfma = [], {}
+    findings, n_mfma, n_dma = [], {}, 0
     for f, o in zip(files, outs):
         n_mfma[f] = 0
         for fn, lines in isa_scan.functions(o):
             res, cnt = isa_scan.scan_function(fn, lines)
             findings += res
             n_mfma[f] += cnt
+            # ... and none of the hazards inline asm can break: M0 written directly in front of an LDS-DMA load, a VMEM instruction reading an SGPR
+            # a VALU instruction wrote less than five wait states ago, VALU-written lane selects, v_div_fmas behind a VALU write of VCC
+            res2, dma, _ = isa_asm.scan_function(fn, lines)
+            findings += res2
+            n_dma += dma
+    assert n_dma >= 600, n_dma   # the LDS-DMA loads of lstm_fused.hip, lstm_fused2.hip, gemm_big.hip were really seen
     for f, floor in MFMA_FLOOR.items():
         assert n_mfma[f] >= floor, (f, n_mfma[f], floor)
     for f in files:   # a file that grew matrix code gets a floor of its own
