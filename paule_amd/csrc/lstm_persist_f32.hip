@@ -340,11 +340,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_sweep_f32_kernel(LstmSweepArg
         int* xtab = a.xcc_tab + (size_t)g * 64;
         bool plain_handoff = false;
 
+        float c_carry = 0.f;   // c_{t-1} of the step before = c_t of this one: loaded once
         for (int t = t_end - 1; t >= t_begin; --t) {
             const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
             const float gi = g_row[0], gf = g_row[Hp], gg = g_row[2 * Hp], go = g_row[3 * Hp];
-            const float c = Cs[(size_t)t * slabH + (size_t)b * Hp + j];
+            const float c = t == t_end - 1 ? Cs[(size_t)t * slabH + (size_t)b * Hp + j] : c_carry;
             const float cp = t > 0 ? Cs[(size_t)(t - 1) * slabH + (size_t)b * Hp + j] : 0.f;
+            c_carry = cp;
             float dh = 0.f;
             if (dhe) dh = dhe[(size_t)t * slabH + (size_t)b * Hp + j];
             else if (dhl && t == T - 1) dh = dhl[(size_t)b * Hp + j];
@@ -555,11 +557,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_stream_f32_kernel(LstmSweepAr
         int* xtab = a.xcc_tab + (size_t)g * 64;
         bool plain_handoff = false;
 
+        float c_carry = 0.f;   // c_{t-1} of the step before = c_t of this one: loaded once
         for (int t = T - 1; t >= 0; --t) {
             const float* g_row = G + (size_t)t * slabG + (size_t)b * G4 + j;
             const float gi = g_row[0], gf = g_row[Hp], gg = g_row[2 * Hp], go = g_row[3 * Hp];
-            const float c = Cs[(size_t)t * slabH + (size_t)b * Hp + j];
+            const float c = t == T - 1 ? Cs[(size_t)t * slabH + (size_t)b * Hp + j] : c_carry;
             const float cp = t > 0 ? Cs[(size_t)(t - 1) * slabH + (size_t)b * Hp + j] : 0.f;
+            c_carry = cp;
             float dh = 0.f;
             if (dhe) dh = dhe[(size_t)t * slabH + (size_t)b * Hp + j];
             else if (dhl && t == T - 1) dh = dhl[(size_t)b * Hp + j];

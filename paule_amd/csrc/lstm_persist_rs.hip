@@ -391,6 +391,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
             __syncthreads();
         }
 
+        uint2 c_carry = make_uint2(0u, 0u);   // c_{t-1} of the step before = c_t of this one: loaded once (one stash row of seven less in front of the polls)
         for (int t = T - 1; t >= 0; --t) {
             uint2 sg[4] = {}, sc = make_uint2(0u, 0u), scp = make_uint2(0u, 0u), sdh = make_uint2(0u, 0u);
             if (DMA && !cellw && t > 0) prefetch(t - 1);   // next step's stash rows, under this step's ingest and cell update
@@ -398,8 +399,10 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_rs_stream_kernel(LstmSweepArg
                 const bf16_t* g_row = G + (size_t)t * slabG + (size_t)bc * G4 + j;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sg[q] = *reinterpret_cast<const uint2*>(g_row + q * Hp);
-                sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+                if (t == T - 1) sc = *reinterpret_cast<const uint2*>(Cs + (size_t)t * slabH + (size_t)bc * Hp + j);
+                else sc = c_carry;
                 if (t > 0) scp = *reinterpret_cast<const uint2*>(Cs + (size_t)(t - 1) * slabH + (size_t)bc * Hp + j);
+                c_carry = scp;
                 if (dhe) sdh = *reinterpret_cast<const uint2*>(dhe + (size_t)t * slabH + (size_t)bc * Hp + j);
                 else if (dhl && t == T - 1) sdh = *reinterpret_cast<const uint2*>(dhl + (size_t)bc * Hp + j);
             }

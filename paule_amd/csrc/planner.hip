@@ -286,7 +286,10 @@ struct pl_handle {
                            // 193 ... 256 rows: its 300 chain-steps are the launch; cfg3 4.088 -> 4.052 ms), else 0 (set B: 3.99 -> 4.02 with it); profiles/r05_ab_fused2_prio.txt
     int bwd_pf = -1, bwd_pf_dist = 4;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf): -1 auto, 0 off
     int bwd_chains = 0;           // PAULE_HIP_BWD_CHAINS: > 0: the 32-row streamed backward sweeps in chained form, that many groups per workgroup (lstm_bwd_rs_chain_kernel)
-    int bwd_xt = 1;               // PAULE_HIP_BWD_XT: the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT)
+    int bwd_xt = 2;               // PAULE_HIP_BWD_XT: 2 (default) = the predictor's input gradient rides along in its streamed backward sweep (lstm_persist_rs.hip, XT) and the
+                                  // sweep does not write the layer's dA over the gate stash (nothing in a planning iteration reads it once dL/dCP comes from the ride-along
+                                  // tile: 454 MB of stores per launch at cfg3, 4.10 -> 4.04 ms); 1 = ride-along, dA kept (pl_debug_read of pred.G0 behind a step); 0 = dL/dCP by the batched product
+    bool pred_dA_skipped = false; // the last planning iteration left the predictor's first-layer gate stash as the forward pass wrote it (pl_debug_read refuses to pass it off as dA)
     float* dx_part = nullptr;         // its scratch: the workgroups' partial tiles, f32 [T][groups][P][32 x 32]
     bool fused2_xcd = false;          // PAULE_HIP_FUSED2_XCD=1: the two-per-CU forward roles' own exchange through the XCD's L2 from a private tile-major copy (round 5:
                                       // bit-identical; the predictor's chain-step 5.3 -> 5.1 us, the embedder's roles -- the launch's longest -- unchanged, the iteration
@@ -642,7 +645,7 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             // summed by launch_dx_reduce below) where the streamed 32-row form runs the whole sequence; otherwise the batched product
             ride_along = l == 0 && &md == &h->pred && train_nb == 0 && dIn == h->dX && h->dx_part && Tl == h->T && h->dt == BF16 &&
                          !use_sweep16(h, Hp, true) && h->bwd_mode == 1 && h->sweep_xchg && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_dma == 0;
-            if (ride_along) { s.WihT = ly.WihT; s.xpart = h->dx_part; s.skip_dA = h->bwd_xt == 2 ? 1 : 0; }
+            if (ride_along) { s.WihT = ly.WihT; s.xpart = h->dx_part; s.skip_dA = h->bwd_xt == 2 ? 1 : 0; h->pred_dA_skipped = s.skip_dA != 0; }
             launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
@@ -917,6 +920,7 @@ void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const voi
 }
 
 void pred_forward(pl_handle* h, hipStream_t st) {
+    h->pred_dA_skipped = false;   // the forward pass rewrites the gate stash
     launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
     model_forward(h, st, h->pred, h->X0);
     Model& p = h->pred;
@@ -1089,6 +1093,7 @@ struct PipeCtx {
 };
 
 void acoustic_forward_pipeline(pl_handle* h, hipStream_t st, int nc) {
+    h->pred_dA_skipped = false;   // the forward pass rewrites the gate stash
     Model &p = h->pred, &e = h->emb;
     const int Bp = h->Bp, T = h->T, Tp = h->Tp;
     const size_t a = h->act;
@@ -1844,7 +1849,8 @@ int build_fused_roles(pl_handle* h) {
 
 // predictor + mel head + embedder LSTM layers as one launch; false = not taken (the caller runs the per-layer path)
 bool fused_acoustic_forward(pl_handle* h, hipStream_t st) {
-    if (!h->fused_fwd_ok || h->sweep_slot < 0) return false;   // the flag slices are zeroed at the top of an iteration only
+    if (!h->fused_fwd_ok || h->sweep_slot < 0) return false;
+    h->pred_dA_skipped = false;   // the forward pass rewrites the gate stash   // the flag slices are zeroed at the top of an iteration only
     launch_pack_cp(st, h->dt, h->x, h->B, h->T, h->C, h->X0, h->Bp, h->Cp);
     FusedArgs a{};
     fused_common_args(h, a, h->fused_grid_fwd, h->fused_tab_fwd, h->fused_roles_fwd, false);
@@ -1909,6 +1915,7 @@ void enqueue_iteration(pl_handle* h, hipStream_t st) {
     const bool with_sem = h->need_emb_in_step();
     h->wf_next = 0;
     h->wf_stream_next = 0;
+    h->pred_dA_skipped = false;
     zero_all_sweep_slots(h, st);   // the flags of all sweeps of the iteration in one launch
     const int pipe_nc = h->fused_fwd_ok ? 0 : acoustic_pipeline_chunks(h);   // the fused launches (batches of 49+ rows) come first
     if (pipe_nc) {
@@ -3314,6 +3321,8 @@ int pl_debug_read(pl_handle* h, const char* name, float* out, int64_t max_elems,
         }
     };
     bool ok = false;
+    if (nm == "pred.G0" && h->pred_dA_skipped)
+        return fail(PL_ERR_STATE, "pl_debug_read: the last planning iteration did not keep the predictor's dA (dL/dCP rode along in the sweep); PAULE_HIP_BWD_XT=1 keeps it");
     if (nm.rfind("pred.", 0) == 0) ok = model_buf(h->pred, nm.substr(5));
     else if (nm.rfind("emb.", 0) == 0 && h->emb.L > 0) ok = model_buf(h->emb, nm.substr(4));
     else if (nm == "X0") { src = h->X0; n = (int64_t)h->T * h->Bp * h->Cp; kind = 0; ok = true; }

@@ -472,12 +472,37 @@ def test_ride_along_input_gradient_equals_the_batched_product(HipPlanner, monkey
         eng.synchronize()
         out[xt] = (l1, bufs, l5, _n(eng.get_cp()))
         eng.close()
-    monkeypatch.delenv("PAULE_HIP_BWD_XT")
     np.testing.assert_array_equal(out["1"][0], out["0"][0])
     for k in ("emb.G1", "emb.G0", "pred.G0"):
         np.testing.assert_array_equal(out["1"][1][k], out["0"][1][k], err_msg=k)
     a, b = out["1"][1]["dX"], out["0"][1]["dX"]
     assert np.isfinite(a).all() and np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    # The default since round 5 (PAULE_HIP_BWD_XT=2): the same sweep WITHOUT its stores of dA over the predictor's gate stash -- nothing in a
+    # planning iteration reads them once dL/dCP rides along.  Same bits everywhere else; the debug read of that stash says so instead of handing
+    # out forward gates as dA (a 16-row batch has no ride-along: its dA is there).
+    monkeypatch.setenv("PAULE_HIP_BWD_XT", "2")
+    eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+    eng.set_targets(wl.target_mel, wl.target_semvec)
+    eng.set_cp(wl.cp0)
+    l1 = _n(eng.step(1))
+    eng.synchronize()
+    np.testing.assert_array_equal(l1, out["1"][0])
+    for k in ("emb.G1", "emb.G0", "dX"):
+        np.testing.assert_array_equal(_n(eng.debug_read(k)), out["1"][1][k], err_msg=k)
+    try:
+        g0 = _n(eng.debug_read("pred.G0"))
+    except ValueError as e:
+        assert "did not keep the predictor's dA" in str(e), e
+        g0 = None
+    assert B != 256 or g0 is None            # cfg3's shape rides along for certain
+    if g0 is not None:                       # (a shape whose backward pass another kernel carries keeps dA as before)
+        np.testing.assert_array_equal(g0, out["1"][1]["pred.G0"])
+    l5 = _n(eng.step(4))
+    eng.synchronize()
+    np.testing.assert_array_equal(l5, out["1"][2])
+    np.testing.assert_array_equal(_n(eng.get_cp()), out["1"][3])
+    eng.close()
+    monkeypatch.delenv("PAULE_HIP_BWD_XT")
     np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=1e-6, atol=1e-9)
     assert np.abs(out["1"][3] - out["0"][3]).max() <= 2e-5   # Adam: where |g| ~ eps a last-bit difference of g moves the update by a fraction of lr
 
@@ -958,10 +983,12 @@ def test_fused16_launches_are_reproducible_run_to_run(HipPlanner):
                                    dict(B=40, T=300, set="A", what="16-row fused launches, three groups"),
                                    dict(B=40, T=300, set="C", what="chunk pipelines of the 16-row sweeps (an embedder variant keeps them)"),
                                    dict(B=256, T=100, set="B", what="fused forward + backward launches of two widths (stacked predictor)")])
-def test_every_bf16_schedule_is_reproducible_run_to_run(HipPlanner, shape):
+def test_every_bf16_schedule_is_reproducible_run_to_run(HipPlanner, monkeypatch, shape):
     """The check that found the 16-row fused role's stale accumulator register, applied to the other bf16 schedules the planner picks:
-    six fresh engines, two iterations each -- every layer's dA, dL/dCP and the updated CP carry the same bits in all six."""
+    six fresh engines, two iterations each -- every layer's dA, dL/dCP and the updated CP carry the same bits in all six.  (The predictor's
+    dA is asked for: where dL/dCP rides along in the sweep a planning iteration does not keep it by default, round 5.)"""
     import hashlib
+    monkeypatch.setenv("PAULE_HIP_BWD_XT", "1")
     B, T = shape["B"], shape["T"]
     wl = synthetic.make_workload(B, T, shape["set"])
     n_pred = 4 if shape["set"] == "B" else 1
