@@ -537,6 +537,16 @@ int wavefront_depth(pl_handle* h, const Model& md);
 int wavefront_chunks(pl_handle* h, const Model& md, int Tl, int train_nb);
 void model_forward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl, int nc, int lb, int le);
 void model_backward_wavefront(pl_handle* h, hipStream_t st, Model& md, const void* dh_last, float* dIn, int Tl, int nc, int lb, int le);
+// the predictor's first layer in a planning iteration: its streamed 32-row backward sweep carries dL/dCP as a ride-along tile (lstm_persist_rs.hip, XT)
+bool pred_ride_along(pl_handle* h) {
+    const int Hp = h->pred.Hp;
+    return h->dx_part && h->dt == BF16 && !use_sweep16(h, Hp, true) && h->bwd_mode == 1 && h->sweep_xchg && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_dma == 0;
+}
+void set_ride_along(pl_handle* h, LstmLayer& ly, LstmSweepArgs& s) {
+    s.WihT = ly.WihT;
+    s.xpart = h->dx_part;
+    s.skip_dA = h->bwd_xt == 2 ? 1 : 0;
+}
 
 // stacked LSTM forward over all Tl steps; in_act = time-major [Tl][Bp][in_p]
 void model_forward(pl_handle* h, hipStream_t st, Model& md, const void* in_act, int Tl_use = 0) {
@@ -643,9 +653,8 @@ void model_backward(pl_handle* h, hipStream_t st, Model& md, const void* dh_last
             s.stash_via_lds = h->dt == F32 ? (h->wide_ingest ? 2 : 0) : ((h->own_store ? 2 : 0) | (h->wide_ingest16 ? 4 : 0));
             // the predictor's first layer in a planning iteration: dL/dCP = dA W_ih rides along in the sweep (partial tiles to dx_part,
             // summed by launch_dx_reduce below) where the streamed 32-row form runs the whole sequence; otherwise the batched product
-            ride_along = l == 0 && &md == &h->pred && train_nb == 0 && dIn == h->dX && h->dx_part && Tl == h->T && h->dt == BF16 &&
-                         !use_sweep16(h, Hp, true) && h->bwd_mode == 1 && h->sweep_xchg && h->bwd_stream == 1 && h->bwd_waves != 4 && h->bwd_dma == 0;
-            if (ride_along) { s.WihT = ly.WihT; s.xpart = h->dx_part; s.skip_dA = h->bwd_xt == 2 ? 1 : 0; h->pred_dA_skipped = s.skip_dA != 0; }
+            ride_along = l == 0 && &md == &h->pred && train_nb == 0 && dIn == h->dX && Tl == h->T && pred_ride_along(h);
+            if (ride_along) { set_ride_along(h, ly, s); h->pred_dA_skipped = s.skip_dA != 0; }
             launch_sweep(h, st, true, Hp, sweep_grid, s);
         } else
         for (int t = Tl - 1; t >= 0; --t) {
@@ -3157,24 +3166,29 @@ int pl_bench_kernel(pl_handle* h, int kernel, int model_id, int reps, float* avg
         s.counters = h->sweep_cnt; s.status = h->sweep_status; s.spin_ticks = h->spin_ticks; s.poll_mask = h->poll_mask;
         s.flag_stride = h->flag_stride;
         s.xcc_tab = h->sweep_cnt + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride; s.xcd_fast = bwd ? (h->xcd_fast >> 1) & 1 : h->xcd_fast & 1;
-        hipEvent_t e0, e1;
-        PL_HIP(hipEventCreate(&e0));
-        PL_HIP(hipEventCreate(&e1));
-        PL_HIP(hipEventRecord(e0, h->stream));
         s.xchg = h->sweep_xchg;
         s.n_valid = (h->dt == F32 && h->f32_valu) ? h->rows_in_use : 0;   // the kernel the planning path runs at this batch
         s.stash_via_lds = bwd ? (h->dt == F32 ? (h->wide_ingest ? 2 : 0) : (h->own_store ? 2 : 0)) : (h->stash_lds ? 1 : 0);
+        // ... with the arguments the planning path gives it: the predictor's backward sweep carries the ride-along tile (and, by default, leaves dA unwritten)
+        if (bwd && &md == &h->pred && h->bwd_xt != 0 && ly.WihT && lstm_rs_ride_along_supported(Hp, ly.in_p) && Tl == h->T && pred_ride_along(h)) set_ride_along(h, ly, s);
+        // the sweep alone between the events of every repetition (the zeroing of its flag slice, a kernel of its own outside an iteration, stays outside)
+        std::vector<hipEvent_t> ev(2 * (size_t)reps);
+        for (auto& e : ev) PL_HIP(hipEventCreate(&e));
         for (int i = 0; i < reps; ++i) {
             s.counters = take_sweep_slice(h, h->stream);
             s.xcc_tab = s.counters + (size_t)((Bp + 7) / 8) * h->T * h->flag_stride;
+            PL_HIP(hipEventRecord(ev[2 * i], h->stream));
             launch_sweep(h, h->stream, bwd, Hp, grid, s);
+            PL_HIP(hipEventRecord(ev[2 * i + 1], h->stream));
         }
-        PL_HIP(hipEventRecord(e1, h->stream));
-        PL_HIP(hipEventSynchronize(e1));
+        PL_HIP(hipEventSynchronize(ev.back()));
         float ms = 0.f;
-        PL_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        for (int i = 0; i < reps; ++i) {
+            float m1 = 0.f;
+            PL_HIP(hipEventElapsedTime(&m1, ev[2 * i], ev[2 * i + 1]));
+            ms += m1;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
         *avg_ms_out = ms / reps;
         if (flops_per_launch_out) *flops_per_launch_out = 2.0 * h->B * 4.0 * md.H * md.H * (Tl - 1);
         return check_launch();
