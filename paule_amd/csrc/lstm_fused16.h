@@ -398,8 +398,57 @@ struct LstmBwd16Lds {
     static constexpr int O_RED = O_OUT + 16 * ORS;
     static constexpr int O_MEL = O_RED + RED_BYTES;
     static constexpr int O_FLAG = O_MEL + 16 * MRS;
-    static constexpr int BYTES = O_FLAG + 64;
+    static constexpr int GRS = 4 * 64 + 16;       // gate rows of the step [16 batch rows][4 gates][32 units] bf16 (fetched as 16-byte pieces, read back as cells)
+    static constexpr int O_GST = O_FLAG + 64;
+    static constexpr int BYTES = O_GST + 16 * GRS;
 };
+
+// Stash prefetcher of a 16-row backward recurrence (round 5; block-table entries with a prefetcher index behind a role's set, on its XCD slot).
+// The role fetches the six stash rows of a step (gates, c_{t-1}, dL/dh) one step ahead, from HBM, and everything its waves ask for next returns
+// behind them (one row less was worth 4.3 % at cfg5).  Prefetcher q of n follows the role's write-through flags -- slice 0's flag of step t + D --
+// and reads one dword of every 128-byte line of the group's gate rows of step t and of its c rows of step t - 1, so that they sit in the
+// XCD's L2 when the role asks.  Speed only: nothing waits for a prefetcher, it waits for nobody longer than 20 us at a time and gives up
+// after eight time-outs in a row (a role it cannot see), and a launch without them computes the same bits.
+template <int KS>
+__device__ __forceinline__ void fused_pf_bwd16(const FusedArgs& a, const FusedRole& R, const int set, const int q, const int n, int* lflag) {
+    constexpr int Hp = 16 * KS, G4 = 4 * Hp, D = 4;
+    const int tid = threadIdx.x, Bp = a.Bp, T = R.T, g = set, fs = a.flag_stride;
+    if (16 * g >= Bp || n < 1) return;
+    const size_t slabG = (size_t)Bp * G4 * 2, slabH = (size_t)Bp * Hp * 2;   // bytes per step
+    const unsigned char* G = static_cast<const unsigned char*>(R.G) + (size_t)16 * g * G4 * 2;
+    const unsigned char* Cs = static_cast<const unsigned char*>(R.c) + (size_t)16 * g * Hp * 2;
+    const int* Fpub = R.flags + (size_t)g * T * fs;
+    constexpr unsigned bytesG = 16u * G4 * 2u, bytesC = 16u * Hp * 2u, linesG = (bytesG + 127u) / 128u, linesC = (bytesC + 127u) / 128u;
+    unsigned acc = 0;
+    int misses = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        if (t + D <= T - 1) {   // pace: step t + D of the role has been handed over (its write-through flag trails by one step)
+            if (tid < 64) {
+                int ok = 1;
+                if (tid == 0) {
+                    const __amdgpu_buffer_rsrc_t rf = make_rsrc(Fpub + (size_t)(t + D) * fs, 4u);
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (__builtin_amdgcn_raw_buffer_load_b32(rf, 0u, 0, kAuxSc1) == 0) {
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000ull) { ok = 0; break; }
+                        __builtin_amdgcn_s_sleep(48);
+                    }
+                    *lflag = ok;
+                }
+            }
+            __syncthreads();
+            misses = *lflag ? 0 : misses + 1;
+            __syncthreads();
+            if (misses >= 8 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        }
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, bytesG);
+        for (unsigned l = (unsigned)(q * 256 + tid); l < linesG; l += (unsigned)(n * 256)) acc ^= __builtin_amdgcn_raw_buffer_load_b32(rg, l * 128u, 0, 0);
+        if (t > 0) {
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(Cs + (size_t)(t - 1) * slabH, bytesC);
+            for (unsigned l = (unsigned)(q * 256 + tid); l < linesC; l += (unsigned)(n * 256)) acc ^= __builtin_amdgcn_raw_buffer_load_b32(rc, l * 128u, 0, 0);
+        }
+    }
+    if (acc == 0x7fc01234u) __hip_atomic_fetch_or(a.status, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // keeps the loads alive, changes nothing
+}
 
 template <int KS, bool MEL>
 __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
@@ -472,14 +521,18 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     // Stash rows (and dL/dh from above) of the NEXT step are fetched one step ahead, BEHIND this step's tile loads: a wave's loads
     // return in order, so a memory-latency load issued in front of the flag poll (wave 0) or of the tile loads delays them by its
     // whole latency -- 0.7 us per step when the stash rows were fetched at the top of their own step.
-    unsigned n_g[4] = {0u, 0u, 0u, 0u}, n_c = 0u, n_cp = 0u, n_dh = 0u;
+    // The slice's gate rows of a step are 16 rows x 4 gates x 64 bytes = 256 pieces of 16 bytes: ONE load per lane (piece tid: row tid >> 4, gate
+    // (tid >> 2) & 3, quarter tid & 3), handed to the cell threads through an LDS image at the top of the step that uses them -- as four 4-byte
+    // loads per lane they were four of the seven stash rows in the waves' in-order queues (round 5: one row less had been worth 4.3 % at cfg5)
+    uint4 n_gv = make_uint4(0u, 0u, 0u, 0u);
+    unsigned n_c = 0u, n_cp = 0u, n_dh = 0u;
+    unsigned char* const gst = lds + L::O_GST;
     bool n_dh_valid = false;
     auto dh_row_of = [&](int t2) { return dh_ext_half ? (t2 >> 1) : t2; };
     auto fetch_stash = [&](int t2) {
-        const bf16_t* g_row = G + (size_t)t2 * slabG + (size_t)erow * G4 + j;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) n_g[q] = *(const PL_GLOBAL unsigned*)(g_row + q * Hp);
-        n_c = *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j);
+        n_gv = gld<uint4>(G + (size_t)t2 * slabG + (size_t)(tid >> 4) * G4 + ((tid >> 2) & 3) * Hp + 32 * p + 8 * (tid & 3));
+        // c_t of step t2 is the c_{t-1} fetched for step t2 + 1 (one chain: consecutive calls are consecutive steps): loaded once
+        n_c = t2 == T - 1 ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j) : n_cp;
         n_cp = t2 > 0 ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)(t2 - 1) * slabH + (size_t)erow * Hp + j) : 0u;
     };
     auto fetch_dh = [&](int t2) -> unsigned {
@@ -507,8 +560,9 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         if (t > 1) ext_2 = ext_flags(a, R, g32, t - 2, p);
         const bool la_here = !ext_empty(ext_2);
         if (wave == 3 && la_here) la_pv = ext_poll(ext_2, lane);
-        // this step's operands: fetched one step ago
-        const unsigned u_g0 = n_g[0], u_g1 = n_g[1], u_g2 = n_g[2], u_g3 = n_g[3], u_c = n_c, u_cp = n_cp;
+        // this step's operands: fetched one step ago; the gate pieces go through the image (read behind the barrier of the ingest, below)
+        *reinterpret_cast<uint4*>(gst + (tid >> 4) * L::GRS + ((tid >> 2) & 3) * 64 + (tid & 3) * 16) = n_gv;
+        const unsigned u_c = n_c, u_cp = n_cp;
         unsigned dh_bits = n_dh;
         const bool dh_have = n_dh_valid;
         const bool wait_ext = has_ext && !known_cur;
@@ -552,13 +606,19 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8) = make_float4(acc8[0], acc8[1], acc8[2], acc8[3]);
             *reinterpret_cast<float4*>(redw + row * 36 + c8 * 8 + 4) = make_float4(acc8[4], acc8[5], acc8[6], acc8[7]);
             __syncthreads();
-        } else if (t > 0) {
-            fetch_stash(t - 1);
-            const bool ext1 = !ext_empty(ext_flags(a, R, g32, t - 1, p));
-            n_dh_valid = !dhe || !ext1 || known_nxt;
-            n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
+        } else {
+            if (t > 0) {
+                fetch_stash(t - 1);
+                const bool ext1 = !ext_empty(ext_flags(a, R, g32, t - 1, p));
+                n_dh_valid = !dhe || !ext1 || known_nxt;
+                n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
+            }
+            __syncthreads();   // (the gate image: every other step has the ingest's barrier)
         }
         PL_ST(1);   // ingest: tile loads, wave sums, barrier
+        const unsigned char* gcell = gst + erow * L::GRS + jq * 4;
+        const unsigned u_g0 = *reinterpret_cast<const unsigned*>(gcell), u_g1 = *reinterpret_cast<const unsigned*>(gcell + 64),
+                       u_g2 = *reinterpret_cast<const unsigned*>(gcell + 128), u_g3 = *reinterpret_cast<const unsigned*>(gcell + 192);
         float gi[2], gf[2], gg[2], go[2], c[2], cp[2], dh[2];
         unpack2(u_g0, gi);
         unpack2(u_g1, gf);
@@ -582,6 +642,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         if (t == T - 1 && tid == 0 && xtab) flag_store(xtab + p, xcc_id_plus1());
         {   // dA_t overwrites the gate stash in place: read by a role of this launch (write-through) or by the dL/dCP product after it.
             // Issued FIRST: by the time of the flag these stores are a tile phase old and do not sit in front of the next poll
+            // (round 5: as ONE 16-byte piece per lane from the image behind the barrier below: neutral, 13.43 / 13.34 against 13.36 / 13.37 ms at cfg5)
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + (size_t)t * slabG, (unsigned)(slabG * 2));
             const unsigned o = (unsigned)(((size_t)erow * G4 + j) * 2);
             if (dA_sc1) {

@@ -282,6 +282,7 @@ struct pl_handle {
     int fused_Cp = 0, fused_Ce = 0;   // chains per workgroup of the predictor's / the embedder's roles: forward launch
     int fused_Cp_bwd = 0, fused_Ce_bwd = 0;   // ... backward launch (the same unless the forward launch runs two workgroups per CU)
     int f32_stream = 0;   // PAULE_HIP_F32_STREAM: 1 = per-tile hand-off in the whole-sequence f32 backward sweeps (lstm_bwd_stream_f32_kernel; opt-in: bit-identical, measured neutral -- profiles/r05_f32_stream.txt), 0 = one flag per workgroup and step
+    int fused16_pf = 2;    // PAULE_HIP_FUSED16_PF: stash prefetcher workgroups behind every recurrence set of the 16-row fused backward launch (0: none; cfg5 13.72 -> 13.54 ms with 2, 4 or 8)
     int fused2_prio = -1;  // PAULE_HIP_FUSED2_PRIO (FusedArgs::prio): -1 auto = 1 where a one-layer predictor runs on ONE chain beside embedder roles on two or more (set A at
                            // 193 ... 256 rows: its 300 chain-steps are the launch; cfg3 4.088 -> 4.052 ms), else 0 (set B: 3.99 -> 4.02 with it); profiles/r05_ab_fused2_prio.txt
     int bwd_pf = -1, bwd_pf_dist = 4;   // PAULE_HIP_BWD_PF / _PF_DIST: stash prefetcher workgroups of the streamed backward sweeps (LstmSweepArgs::n_pf): -1 auto, 0 off
@@ -1387,7 +1388,7 @@ void tube_backward_pipeline(pl_handle* h, hipStream_t st, int nc, const LossArgs
 // then per further embedder layer l its input projection (3 + 2 (l - 1)) and its recurrence (4 + 2 (l - 1)).
 // Placement (speed only): the grid has one block per CU, block b sits on XCD b % 8 (observed dealing); a recurrence set's
 // P workgroups take consecutive depths of ONE XCD slot while one has room, everything else fills what is left.
-struct FusedSet { int role, set, P; bool together; };
+struct FusedSet { int role, set, P; bool together; int npf = 0; };   // npf: stash prefetcher blocks wanted behind the set, on its slot (16-row backward recurrences)
 // Role indices of the fused launches.  Forward: the predictor's layers first -- recurrence of layer l at 2 l, the projection that
 // feeds it (l >= 1) at 2 l - 1 -- then the mel head, then the embedder: its first layer, and per further layer its projection and its
 // recurrence.  With a one-layer predictor (the only shape the backward launch takes) that is 0 predictor, 1 head, 2 embedder layer 1,
@@ -1402,30 +1403,40 @@ inline int fr_emb_proj(int pL, int l) { return 2 * pL + 2 * l - 1; }
 std::vector<short> fused_block_table(int n_cu, const std::vector<FusedSet>& sets, int* grid_out) {
     const int slots = 8, depth = n_cu / slots;
     std::vector<short> tab((size_t)slots * depth * 4, -1);
-    std::vector<int> used(slots, 0);
-    auto put = [&](int slot, const FusedSet& fs, int p) {
+    std::vector<int> used(slots, 0), slot_of(sets.size(), -1);
+    auto put = [&](int slot, const FusedSet& fs, int p, int pf) {
         const int b = used[slot]++ * slots + slot;
-        tab[(size_t)b * 4] = (short)fs.role; tab[(size_t)b * 4 + 1] = (short)fs.set; tab[(size_t)b * 4 + 2] = (short)p; tab[(size_t)b * 4 + 3] = 0;
+        tab[(size_t)b * 4] = (short)fs.role; tab[(size_t)b * 4 + 1] = (short)fs.set; tab[(size_t)b * 4 + 2] = (short)p; tab[(size_t)b * 4 + 3] = (short)pf;
     };
     for (int pass = 0; pass < 2; ++pass)
-        for (const FusedSet& fs : sets) {
+        for (size_t i = 0; i < sets.size(); ++i) {
+            const FusedSet& fs = sets[i];
             if ((pass == 0) != fs.together) continue;
             int best = -1;
             if (fs.together)
                 for (int s = 0; s < slots; ++s)
                     if (depth - used[s] >= fs.P && (best < 0 || used[s] < used[best])) best = s;
             if (best >= 0) {
-                for (int p = 0; p < fs.P; ++p) put(best, fs, p);
+                for (int p = 0; p < fs.P; ++p) put(best, fs, p, 0);
+                slot_of[i] = best;
             } else {
                 for (int p = 0; p < fs.P; ++p) {
                     int s = 0;
                     for (int k = 1; k < slots; ++k)
                         if (used[k] < used[s]) s = k;
                     if (used[s] >= depth) { *grid_out = 0; return tab; }
-                    put(s, fs, p);
+                    put(s, fs, p, 0);
                 }
             }
         }
+    // stash prefetchers (speed only) behind everything else: as many of a set's as its slot still holds; entry [3] = (count << 8) | (index + 1)
+    for (size_t i = 0; i < sets.size(); ++i) {
+        const FusedSet& fs = sets[i];
+        if (fs.npf <= 0 || slot_of[i] < 0) continue;
+        const int s = slot_of[i];
+        const int n = fs.npf < depth - used[s] ? fs.npf : depth - used[s];
+        for (int q = 0; q < n; ++q) put(s, fs, q, (n << 8) | (q + 1));
+    }
     int top = 0;
     for (int s = 0; s < slots; ++s) top = used[s] > top ? used[s] : top;
     *grid_out = top * slots;
@@ -1595,10 +1606,11 @@ int plan_fused(pl_handle* h) {
         // dL/dh product of layer l for the layer below, fr_head the backward mel head, fr_emb / fr_emb_proj the embedder's.  With one
         // predictor layer that is 0 predictor, 1 head, 2 embedder layer 1, 3 + 2 (l - 1) / 4 + 2 (l - 1) product / recurrence of layer l
         std::vector<FusedSet> sets;
+        const int npf16 = rows16 ? h->fused16_pf : 0;   // stash prefetchers behind every 16-row recurrence set (fused_pf_bwd16)
         for (int l = 0; l < p.L; ++l)
-            for (int s = 0; s < sp_bl; ++s) sets.push_back({fr_pred(l), s, Pp, true});
+            for (int s = 0; s < sp_bl; ++s) sets.push_back({fr_pred(l), s, Pp, true, npf16});
         for (int l = 0; l < e.L; ++l)
-            for (int s = 0; s < se_bl; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true});
+            for (int s = 0; s < se_bl; ++s) sets.push_back({fr_emb(p.L, l), s, Pe, true, npf16});
         for (int l = 1; l < p.L; ++l)
             for (int s = 0; s < sp_b; ++s) sets.push_back({fr_pred_proj(l), s, Pp, false});
         for (int l = 1; l < e.L; ++l)
@@ -2305,6 +2317,7 @@ int pl_create(const pl_config* cfg, pl_handle** out) {
         if (const char* z = std::getenv("PAULE_HIP_BWD_CHAINS")) h->bwd_chains = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_PF")) h->bwd_pf = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_FUSED2_PRIO")) h->fused2_prio = std::atoi(z);
+        if (const char* z = std::getenv("PAULE_HIP_FUSED16_PF")) h->fused16_pf = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_F32_STREAM")) h->f32_stream = std::atoi(z);
         if (const char* z = std::getenv("PAULE_HIP_BWD_PF_DIST")) h->bwd_pf_dist = std::atoi(z);
 #ifdef PL_EXPERIMENTS   // round 4's hand-off experiments (profiles/r04_token_handoff.txt): not in the shipped library

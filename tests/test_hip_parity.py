@@ -1007,6 +1007,35 @@ def test_every_bf16_schedule_is_reproducible_run_to_run(HipPlanner, monkeypatch,
     assert all(len(v) == 1 for v in seen.values()), (shape["what"], {k: len(v) for k, v in seen.items()})
 
 
+@pytest.mark.parametrize("shape", [dict(B=16, T=61), dict(B=40, T=30), dict(B=1, T=24)])
+def test_fused16_stash_prefetchers_change_nothing(HipPlanner, monkeypatch, shape):
+    """Round 5: the 16-row fused backward launch gets stash prefetcher workgroups behind every recurrence set (block-table entries with a
+    prefetcher index, lstm_fused16.h: fused_pf_bwd16) -- they only read, paced on the role's flags.  With PAULE_HIP_FUSED16_PF=0, 2 and 8 the
+    loss log, every layer's dA, dL/dCP and CP are the same bits; the census of the launch counts them (a plan with them still runs)."""
+    B, T = shape["B"], shape["T"]
+    wl = synthetic.make_workload(B, T, "A")
+    out = {}
+    for pf in ("0", "2", "8"):
+        monkeypatch.setenv("PAULE_HIP_FUSED16_PF", pf)
+        eng = HipPlanner(wl.pred_sd, wl.emb_sd, batch=B, n_frames=T, objective="acoustic_semvec", dtype="bf16")
+        assert eng.plan_info()["fused_rows"] == 16
+        eng.set_targets(wl.target_mel, wl.target_semvec)
+        eng.set_cp(wl.cp0)
+        l1 = _n(eng.step(1))
+        eng.synchronize()
+        bufs = {k: _n(eng.debug_read(k)) for k in ("emb.G1", "emb.G0", "pred.G0", "dX")}
+        l3 = _n(eng.step(3))
+        eng.synchronize()
+        out[pf] = (l1, bufs, l3, _n(eng.get_cp()))
+        eng.close()
+    for pf in ("2", "8"):
+        np.testing.assert_array_equal(out[pf][0], out["0"][0])
+        for k in out["0"][1]:
+            np.testing.assert_array_equal(out[pf][1][k], out["0"][1][k], err_msg=f"{k} pf={pf}")
+        np.testing.assert_array_equal(out[pf][2], out["0"][2])
+        np.testing.assert_array_equal(out[pf][3], out["0"][3])
+
+
 @pytest.mark.parametrize("shape", [dict(B=3, T=24, H=720), dict(B=16, T=40, H=96), dict(B=1, T=64, H=720)])
 def test_fused16_vs_oracle_and_rounding_emulation(HipPlanner, shape):
     """The 16-row fused launches against the float64 oracle (model gradient <= 2 %) and against the rounding emulation
