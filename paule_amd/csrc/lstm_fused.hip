@@ -1367,21 +1367,14 @@ __global__ __launch_bounds__(256, 1) void fused_bwd16_kernel2(FusedArgs a) {
     if (a.census && !census_ok(a, reinterpret_cast<int*>(lds))) return;
     __syncthreads();
     const FusedRole R = uniform_role(a.roles[role]);
-    const int pfi = __builtin_amdgcn_readfirstlane((int)bt[3]);   // > 0: a stash prefetcher of this role's set: (count << 8) | (index + 1)
-    if (pfi > 0) {
-        if (R.type == FR_LSTM_BWD) {
-            if (R.wide) fused_pf_bwd16<KSE>(a, R, set, (pfi & 255) - 1, pfi >> 8, reinterpret_cast<int*>(lds));
-            else fused_pf_bwd16<KSP>(a, R, set, (pfi & 255) - 1, pfi >> 8, reinterpret_cast<int*>(lds));
-        }
-        return;
-    }
+    // (no stash prefetchers in the two-width launch: they change nothing there, and their code in this kernel cost its roles 23 more scalar spills)
     switch (R.type) {
         case FR_LSTM_BWD:
             if (R.wide) {
-                if (R.xchg_mel) fused_lstm_bwd16<KSE, true>(a, R, set, p, lds);
-                else fused_lstm_bwd16<KSE, false>(a, R, set, p, lds);
+                if (R.xchg_mel) fused_lstm_bwd16<KSE, true, false>(a, R, set, p, lds);
+                else fused_lstm_bwd16<KSE, false, false>(a, R, set, p, lds);
             } else {
-                fused_lstm_bwd16<KSP, false>(a, R, set, p, lds);
+                fused_lstm_bwd16<KSP, false, false>(a, R, set, p, lds);
             }
             break;
         case FR_DX_BWD:

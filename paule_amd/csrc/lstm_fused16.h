@@ -450,7 +450,7 @@ __device__ __forceinline__ void fused_pf_bwd16(const FusedArgs& a, const FusedRo
     if (acc == 0x7fc01234u) __hip_atomic_fetch_or(a.status, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // keeps the loads alive, changes nothing
 }
 
-template <int KS, bool MEL>
+template <int KS, bool MEL, bool OPT = true>   // OPT: the round-5 stash forms (gate image, carried c row); off in the two-width launch, which they slow down
 __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const FusedRole& R, const int set, const int p, unsigned char* lds) {
     using L = LstmBwd16Lds<KS>;
     constexpr int Hp = 16 * KS, G4 = 4 * Hp, P = Hp / 32;
@@ -524,15 +524,28 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     // The slice's gate rows of a step are 16 rows x 4 gates x 64 bytes = 256 pieces of 16 bytes: ONE load per lane (piece tid: row tid >> 4, gate
     // (tid >> 2) & 3, quarter tid & 3), handed to the cell threads through an LDS image at the top of the step that uses them -- as four 4-byte
     // loads per lane they were four of the seven stash rows in the waves' in-order queues (round 5: one row less had been worth 4.3 % at cfg5)
+    // (the equal-width launch only: in the two-width launch of model set B -- narrow predictor roles, a wide embedder role with slack -- cfg5_setB
+    // went 12.86 -> 13.06 ms with these forms, whichever of its roles had them)
+    constexpr bool GIMG = OPT && KS >= 24;
     uint4 n_gv = make_uint4(0u, 0u, 0u, 0u);
+    unsigned n_g[4] = {0u, 0u, 0u, 0u};
     unsigned n_c = 0u, n_cp = 0u, n_dh = 0u;
     unsigned char* const gst = lds + L::O_GST;
     bool n_dh_valid = false;
     auto dh_row_of = [&](int t2) { return dh_ext_half ? (t2 >> 1) : t2; };
     auto fetch_stash = [&](int t2) {
-        n_gv = gld<uint4>(G + (size_t)t2 * slabG + (size_t)(tid >> 4) * G4 + ((tid >> 2) & 3) * Hp + 32 * p + 8 * (tid & 3));
+        if constexpr (GIMG) {
+            n_gv = gld<uint4>(G + (size_t)t2 * slabG + (size_t)(tid >> 4) * G4 + ((tid >> 2) & 3) * Hp + 32 * p + 8 * (tid & 3));
+        } else {
+            const bf16_t* g_row = G + (size_t)t2 * slabG + (size_t)erow * G4 + j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) n_g[q] = *(const PL_GLOBAL unsigned*)(g_row + q * Hp);
+        }
         // c_t of step t2 is the c_{t-1} fetched for step t2 + 1 (one chain: consecutive calls are consecutive steps): loaded once
-        n_c = t2 == T - 1 ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j) : n_cp;
+        // (wide roles, as the image above: cfg5_setB 12.85 -> 13.05 ms with the carry in its narrow roles.  The test on t2 stays a run-time one: with the
+        // first call peeled off -- no c load in the loop at all -- set A's gain shrank from 7 % to 2.4 %: what the compiler makes of the merge matters
+        // more here than the load it saves, see NOTEBOOK.md A.18)
+        n_c = (!GIMG || t2 == T - 1) ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j) : n_cp;
         n_cp = t2 > 0 ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)(t2 - 1) * slabH + (size_t)erow * Hp + j) : 0u;
     };
     auto fetch_dh = [&](int t2) -> unsigned {
@@ -561,7 +574,8 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         const bool la_here = !ext_empty(ext_2);
         if (wave == 3 && la_here) la_pv = ext_poll(ext_2, lane);
         // this step's operands: fetched one step ago; the gate pieces go through the image (read behind the barrier of the ingest, below)
-        *reinterpret_cast<uint4*>(gst + (tid >> 4) * L::GRS + ((tid >> 2) & 3) * 64 + (tid & 3) * 16) = n_gv;
+        if constexpr (GIMG) *reinterpret_cast<uint4*>(gst + (tid >> 4) * L::GRS + ((tid >> 2) & 3) * 64 + (tid & 3) * 16) = n_gv;
+        const unsigned d_g0 = n_g[0], d_g1 = n_g[1], d_g2 = n_g[2], d_g3 = n_g[3];   // (the direct form's operands)
         const unsigned u_c = n_c, u_cp = n_cp;
         unsigned dh_bits = n_dh;
         const bool dh_have = n_dh_valid;
@@ -613,12 +627,15 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
                 n_dh_valid = !dhe || !ext1 || known_nxt;
                 n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
             }
-            __syncthreads();   // (the gate image: every other step has the ingest's barrier)
+            if constexpr (GIMG) __syncthreads();   // (the gate image: every other step has the ingest's barrier)
         }
         PL_ST(1);   // ingest: tile loads, wave sums, barrier
         const unsigned char* gcell = gst + erow * L::GRS + jq * 4;
-        const unsigned u_g0 = *reinterpret_cast<const unsigned*>(gcell), u_g1 = *reinterpret_cast<const unsigned*>(gcell + 64),
-                       u_g2 = *reinterpret_cast<const unsigned*>(gcell + 128), u_g3 = *reinterpret_cast<const unsigned*>(gcell + 192);
+        unsigned u_g0 = d_g0, u_g1 = d_g1, u_g2 = d_g2, u_g3 = d_g3;
+        if constexpr (GIMG) {
+            u_g0 = *reinterpret_cast<const unsigned*>(gcell); u_g1 = *reinterpret_cast<const unsigned*>(gcell + 64);
+            u_g2 = *reinterpret_cast<const unsigned*>(gcell + 128); u_g3 = *reinterpret_cast<const unsigned*>(gcell + 192);
+        }
         float gi[2], gf[2], gg[2], go[2], c[2], cp[2], dh[2];
         unpack2(u_g0, gi);
         unpack2(u_g1, gf);

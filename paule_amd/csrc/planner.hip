@@ -1606,7 +1606,7 @@ int plan_fused(pl_handle* h) {
         // dL/dh product of layer l for the layer below, fr_head the backward mel head, fr_emb / fr_emb_proj the embedder's.  With one
         // predictor layer that is 0 predictor, 1 head, 2 embedder layer 1, 3 + 2 (l - 1) / 4 + 2 (l - 1) product / recurrence of layer l
         std::vector<FusedSet> sets;
-        const int npf16 = rows16 ? h->fused16_pf : 0;   // stash prefetchers behind every 16-row recurrence set (fused_pf_bwd16)
+        const int npf16 = rows16 && !two_width ? h->fused16_pf : 0;   // stash prefetchers behind every 16-row recurrence set of the equal-width launch (fused_pf_bwd16)
         for (int l = 0; l < p.L; ++l)
             for (int s = 0; s < sp_bl; ++s) sets.push_back({fr_pred(l), s, Pp, true, npf16});
         for (int l = 0; l < e.L; ++l)
