@@ -533,7 +533,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
     unsigned char* const gst = lds + L::O_GST;
     bool n_dh_valid = false;
     auto dh_row_of = [&](int t2) { return dh_ext_half ? (t2 >> 1) : t2; };
-    auto fetch_stash = [&](int t2, bool first) {
+    auto fetch_stash = [&](int t2) {
         if constexpr (GIMG) {
             n_gv = gld<uint4>(G + (size_t)t2 * slabG + (size_t)(tid >> 4) * G4 + ((tid >> 2) & 3) * Hp + 32 * p + 8 * (tid & 3));
         } else {
@@ -545,7 +545,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         // (wide roles, as the image above: cfg5_setB 12.85 -> 13.05 ms with the carry in its narrow roles.  The test on t2 stays a run-time one: with the
         // first call peeled off -- no c load in the loop at all -- set A's gain shrank from 7 % to 2.4 %: what the compiler makes of the merge matters
         // more here than the load it saves, see NOTEBOOK.md A.18)
-        n_c = (!GIMG || first) ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j) : n_cp;
+        n_c = (!GIMG || t2 == T - 1) ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)t2 * slabH + (size_t)erow * Hp + j) : n_cp;
         n_cp = t2 > 0 ? *(const PL_GLOBAL unsigned*)(Cs + (size_t)(t2 - 1) * slabH + (size_t)erow * Hp + j) : 0u;
     };
     auto fetch_dh = [&](int t2) -> unsigned {
@@ -562,7 +562,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
         f[1] = bf16_val16((unsigned short)(u >> 16));
     };
     PL_ST_DECL
-    fetch_stash(T - 1, true);
+    fetch_stash(T - 1);
     if (!dhe && dhl) { n_dh = *(const PL_GLOBAL unsigned*)(dhl + (size_t)erow * Hp + j); n_dh_valid = true; }
     else if (!dhe) n_dh_valid = true;
 
@@ -599,10 +599,9 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
                 const int src = wave * TPG + i;
                 pw[i] = src < P ? ld16_handoff(rx, (unsigned)(src * TILE * 2 + lane * 16), fast) : make_uint4(0, 0, 0, 0);
             }
-            if constexpr (GIMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EXPERIMENT: the tile loads have landed before the next step's stash loads go out
-            else asm volatile("" ::: "memory");   // the next step's operands behind the tile loads
+            asm volatile("" ::: "memory");   // the next step's operands behind the tile loads
             if (t > 0) {
-                fetch_stash(t - 1, false);
+                fetch_stash(t - 1);
                 const bool ext1 = !ext_empty(ext_flags(a, R, g32, t - 1, p));
                 n_dh_valid = !dhe || !ext1 || known_nxt;
                 n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
@@ -623,7 +622,7 @@ __device__ __forceinline__ void fused_lstm_bwd16(const FusedArgs& a, const Fused
             __syncthreads();
         } else {
             if (t > 0) {
-                fetch_stash(t - 1, false);
+                fetch_stash(t - 1);
                 const bool ext1 = !ext_empty(ext_flags(a, R, g32, t - 1, p));
                 n_dh_valid = !dhe || !ext1 || known_nxt;
                 n_dh = (dhe && n_dh_valid) ? fetch_dh(t - 1) : 0u;
